@@ -1,0 +1,105 @@
+!> TEST INFRASTRUCTURE ONLY (oracle).  Our own driver around the *reference's*
+!> solver modules: reads a flat binary system, fills hecmwST_matrix /
+!> hecmwST_local_mesh exactly as fistr1 would (m_fstr.f90:807-857 allocates the
+!> same members) and calls the reference entry points
+!>   mode 1: hecmw_solve_iterative   (hecmw_solver_Iterative.f90:13)
+!>   mode 2: hecmw_matvec            (hecmw_solver_las.f90:57)
+!>   mode 3: hecmw_precond_setup + hecmw_precond_apply (hecmw_precond.f90:28,75)
+!> stdout carries the reference's own ITERLOG / summary lines.
+!>
+!> usage: ref_solve in.bin out.bin
+!> in.bin  (little endian, stream):
+!>   int32  magic(=1179210580) mode N NP NPL NPU nrepeat
+!>   int32  Iarray(100);  real64 Rarray(100)
+!>   int32  indexL(0:NP) indexU(0:NP) itemL(NPL) itemU(NPU)
+!>   real64 D(9NP) AL(9NPL) AU(9NPU) B(3NP) X(3NP)
+!> out.bin: int32 Iarray(100); real64 Rarray(100); real64 X(3NP) (mode 2/3: Y/Z)
+!>          real64 t_total
+program ref_solve
+  use hecmw_util
+  use hecmw_matrix_misc
+  use hecmw_solver_iterative
+  use hecmw_solver_las
+  use hecmw_precond
+  implicit none
+  type(hecmwST_local_mesh) :: hecMESH
+  type(hecmwST_matrix)     :: hecMAT
+  character(len=1024) :: fin, fout
+  integer(kind=4) :: magic, mode, N, NP, NPL, NPU, nrepeat, u, irep
+  integer(kind=4) :: Iarr(100)
+  real(kind=8)    :: Rarr(100), t0, t1, tcomm
+  real(kind=8), allocatable :: Y(:), WK(:), X0(:)
+
+  call get_command_argument(1, fin)
+  call get_command_argument(2, fout)
+  open(newunit=u, file=trim(fin), access='stream', form='unformatted', status='old')
+  read(u) magic, mode, N, NP, NPL, NPU, nrepeat
+  if (magic /= 1179210580) stop 'bad magic'
+  read(u) Iarr
+  read(u) Rarr
+
+  call hecmw_nullify_mesh(hecMESH)
+  call hecmw_mat_init(hecMAT)
+  hecMAT%Iarray = Iarr
+  hecMAT%Rarray = Rarr
+  hecMAT%N = N; hecMAT%NP = NP; hecMAT%NPL = NPL; hecMAT%NPU = NPU; hecMAT%NDOF = 3
+  hecMAT%NPCL = 0; hecMAT%NPCU = 0
+  allocate(hecMAT%indexL(0:NP), hecMAT%indexU(0:NP), hecMAT%itemL(NPL), hecMAT%itemU(NPU))
+  allocate(hecMAT%D(9*NP), hecMAT%AL(9*NPL), hecMAT%AU(9*NPU), hecMAT%B(3*NP), hecMAT%X(3*NP))
+  read(u) hecMAT%indexL
+  read(u) hecMAT%indexU
+  read(u) hecMAT%itemL
+  read(u) hecMAT%itemU
+  read(u) hecMAT%D
+  read(u) hecMAT%AL
+  read(u) hecMAT%AU
+  read(u) hecMAT%B
+  read(u) hecMAT%X
+  close(u)
+
+  hecMESH%zero = 0; hecMESH%MPI_COMM = 0; hecMESH%PETOT = 1; hecMESH%PEsmpTOT = 1
+  hecMESH%my_rank = 0; hecMESH%n_subdomain = 1; hecMESH%n_neighbor_pe = 0
+  hecMESH%n_node = NP; hecMESH%nn_internal = N; hecMESH%n_dof = 3
+  hecMESH%nn_middle = NP
+  hecMESH%mpc%n_mpc = 0
+  allocate(hecMESH%neighbor_pe(0), hecMESH%import_index(0:0), hecMESH%export_index(0:0))
+  allocate(hecMESH%import_item(0), hecMESH%export_item(0))
+  hecMESH%import_index(0) = 0; hecMESH%export_index(0) = 0
+
+  allocate(Y(3*NP), WK(3*NP), X0(3*NP))
+  X0 = hecMAT%X
+  t0 = hecmw_Wtime()
+  select case (mode)
+  case (1)
+    do irep = 1, max(nrepeat, 1)
+      if (irep > 1) then
+        hecMAT%X = X0
+        hecMAT%Iarray = Iarr
+      endif
+      call hecmw_solve_iterative(hecMESH, hecMAT)
+    enddo
+    Y = hecMAT%X
+  case (2)
+    tcomm = 0.d0
+    do irep = 1, max(nrepeat, 1)
+      call hecmw_matvec(hecMESH, hecMAT, hecMAT%X, Y, tcomm)
+    enddo
+    Y(3*N+1:) = 0.d0
+  case (3)
+    tcomm = 0.d0
+    call hecmw_precond_setup(hecMAT, hecMESH, 1)
+    do irep = 1, max(nrepeat, 1)
+      call hecmw_precond_apply(hecMESH, hecMAT, hecMAT%B, Y, WK, tcomm)
+    enddo
+  case default
+    stop 'bad mode'
+  end select
+  t1 = hecmw_Wtime()
+
+  open(newunit=u, file=trim(fout), access='stream', form='unformatted', status='replace')
+  write(u) hecMAT%Iarray
+  write(u) hecMAT%Rarray
+  write(u) Y
+  write(u) t1 - t0
+  close(u)
+end program ref_solve

@@ -1,0 +1,184 @@
+"""TEST INFRASTRUCTURE ONLY: run the reference executables built by
+oracle/build_ref.py (oracle/_ref/ref_solve[_omp], oracle/_ref/ref_fem) on flat
+binary files and parse what they print.  Used by tests/, by
+tests/golden/make_golden.py and by bench.py's cpu_baseline leg -- never by the
+product path.
+"""
+import os
+import re
+import subprocess
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REFDIR = os.path.join(HERE, "_ref")
+MAGIC_SOLVE = 1179210580
+MAGIC_FEM = 1179206989
+
+
+def have_ref(name="ref_solve"):
+    return os.path.exists(os.path.join(REFDIR, name))
+
+
+class BSR:
+    """Plain container mirroring hecmwST_matrix's members (1-based items)."""
+
+    def __init__(self, N, NP, indexL, itemL, indexU, itemU, D, AL, AU, B=None, X=None):
+        self.N, self.NP = int(N), int(NP)
+        self.indexL = np.ascontiguousarray(indexL, dtype=np.int32)
+        self.indexU = np.ascontiguousarray(indexU, dtype=np.int32)
+        self.itemL = np.ascontiguousarray(itemL, dtype=np.int32)
+        self.itemU = np.ascontiguousarray(itemU, dtype=np.int32)
+        self.D = np.ascontiguousarray(D, dtype=np.float64)
+        self.AL = np.ascontiguousarray(AL, dtype=np.float64)
+        self.AU = np.ascontiguousarray(AU, dtype=np.float64)
+        self.B = np.zeros(3 * self.NP) if B is None else np.ascontiguousarray(B, dtype=np.float64)
+        self.X = np.zeros(3 * self.NP) if X is None else np.ascontiguousarray(X, dtype=np.float64)
+
+    @property
+    def NPL(self):
+        return int(self.itemL.size)
+
+    @property
+    def NPU(self):
+        return int(self.itemU.size)
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        N = self.N
+        rows, cols, vals = [], [], []
+        for idx, item, A in ((self.indexL, self.itemL, self.AL), (self.indexU, self.itemU, self.AU)):
+            nblk = idx[N]
+            r = np.repeat(np.arange(N), np.diff(idx[:N + 1]))
+            rows.append(r)
+            cols.append(item[:nblk] - 1)
+            vals.append(A[:9 * nblk].reshape(-1, 3, 3))
+        rows.append(np.arange(N))
+        cols.append(np.arange(N))
+        vals.append(self.D[:9 * N].reshape(-1, 3, 3))
+        r = np.concatenate(rows)
+        c = np.concatenate(cols)
+        v = np.concatenate(vals)
+        order = np.lexsort((c, r))
+        r, c, v = r[order], c[order], v[order]
+        indptr = np.zeros(N + 1, dtype=np.int64)
+        np.add.at(indptr, r + 1, 1)
+        indptr = np.cumsum(indptr)
+        return sp.bsr_matrix((v, c, indptr), shape=(3 * N, 3 * self.NP))
+
+
+def default_params(method=1, precond=3, maxit=10000, tol=1e-8, iterlog=1, timelog=1,
+                   ncolor=10, sigma_diag=1.0, iterpremax=1):
+    """Iarray/Rarray as hecmw_mat_init (hecmw_matrix_misc.f90:142-182) + !SOLVER card."""
+    I = np.zeros(100, dtype=np.int32)
+    R = np.zeros(100, dtype=np.float64)
+    I[0] = maxit; I[1] = method; I[2] = precond; I[3] = 0; I[4] = iterpremax
+    I[5] = 10; I[6] = 0; I[20] = iterlog; I[21] = timelog
+    I[33] = ncolor; I[34] = 3; I[12] = 3
+    I[96] = 1; I[97] = 1; I[98] = 1
+    R[0] = tol; R[1] = sigma_diag; R[2] = 0.0; R[3] = 0.10; R[4] = 0.10; R[10] = 1.0e4
+    return I, R
+
+
+def write_system(path, mode, m, I, R, nrepeat=1):
+    with open(path, "wb") as f:
+        np.array([MAGIC_SOLVE, mode, m.N, m.NP, m.NPL, m.NPU, nrepeat], dtype=np.int32).tofile(f)
+        I.astype(np.int32).tofile(f)
+        R.astype(np.float64).tofile(f)
+        for a in (m.indexL, m.indexU, m.itemL, m.itemU):
+            a.astype(np.int32).tofile(f)
+        for a in (m.D, m.AL, m.AU, m.B, m.X):
+            a.astype(np.float64).tofile(f)
+
+
+HIST_RE = re.compile(r"^\s*(\d+)\s+([0-9.]+E[+-]\d+)\s*$")
+
+
+def parse_stdout(text):
+    hist, info = [], {}
+    for line in text.splitlines():
+        m = HIST_RE.match(line)
+        if m:
+            hist.append((int(m.group(1)), float(m.group(2))))
+            continue
+        m = re.match(r"\s*(\d+) iterations\s+([0-9.E+-]+)", line)
+        if m:
+            info["iter"] = int(m.group(1))
+            info["resid"] = float(m.group(2))
+        m = re.match(r"### Relative residual =\s*([0-9.E+-]+)", line)
+        if m:
+            info["rel_resid"] = float(m.group(1))
+        for key, tag in (("setup", "set-up time"), ("solver", "solver time"), ("matvec", "solver/matvec"),
+                         ("precond", "solver/precond"), ("per_iter", "solver/1 iter")):
+            if tag in line:
+                try:
+                    info["t_" + key] = float(line.split(":")[1])
+                except (IndexError, ValueError):
+                    pass
+        if line.startswith("### ") and "BLOCK" in line:
+            info["banner"] = line.strip()
+        if "HEC-MW-SOLVER" in line:
+            info.setdefault("messages", []).append(line.strip())
+    info["history"] = hist
+    return info
+
+
+def run_solve(m, I, R, mode=1, threads=1, nrepeat=1, workdir=None, timeout=None):
+    """Run the reference.  threads==1 -> serial build (natural-order SSOR);
+    threads>=2 -> OpenMP build (RCM + multicolour SSOR)."""
+    exe = os.path.join(REFDIR, "ref_solve_omp" if threads > 1 else "ref_solve")
+    if not os.path.exists(exe):
+        raise FileNotFoundError(exe + " (run python oracle/build_ref.py where /root/reference exists)")
+    with tempfile.TemporaryDirectory(dir=workdir) as td:
+        fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        write_system(fin, mode, m, I, R, nrepeat)
+        env = dict(os.environ)
+        env["OMP_NUM_THREADS"] = str(threads)
+        p = subprocess.run([exe, fin, fout], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           text=True, env=env, timeout=timeout)
+        info = parse_stdout(p.stdout)
+        info["stdout"] = p.stdout
+        info["returncode"] = p.returncode
+        if os.path.exists(fout):
+            with open(fout, "rb") as f:
+                info["Iarray"] = np.fromfile(f, dtype=np.int32, count=100)
+                info["Rarray"] = np.fromfile(f, dtype=np.float64, count=100)
+                info["X"] = np.fromfile(f, dtype=np.float64, count=3 * m.NP)
+                info["t_total"] = float(np.fromfile(f, dtype=np.float64, count=1)[0])
+    return info
+
+
+def run_fem(coord, conn, E, nu, bc_node, bc_dof, bc_val, B0, elemopt=1, workdir=None):
+    """Reference profile + element stiffness + assembly + Dirichlet BC."""
+    exe = os.path.join(REFDIR, "ref_fem")
+    if not os.path.exists(exe):
+        raise FileNotFoundError(exe)
+    n_node, n_elem = coord.shape[0], conn.shape[0]
+    with tempfile.TemporaryDirectory(dir=workdir) as td:
+        fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        with open(fin, "wb") as f:
+            np.array([MAGIC_FEM, elemopt, n_node, n_elem, len(bc_node)], dtype=np.int32).tofile(f)
+            np.array([E, nu], dtype=np.float64).tofile(f)
+            np.ascontiguousarray(coord, dtype=np.float64).tofile(f)
+            np.ascontiguousarray(conn, dtype=np.int32).tofile(f)
+            np.ascontiguousarray(bc_node, dtype=np.int32).tofile(f)
+            np.ascontiguousarray(bc_dof, dtype=np.int32).tofile(f)
+            np.ascontiguousarray(bc_val, dtype=np.float64).tofile(f)
+            np.ascontiguousarray(B0, dtype=np.float64).tofile(f)
+        p = subprocess.run([exe, fin, fout], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if p.returncode != 0 or not os.path.exists(fout):
+            raise RuntimeError("ref_fem failed: " + p.stdout)
+        with open(fout, "rb") as f:
+            N, NP, NPL, NPU = np.fromfile(f, dtype=np.int32, count=4)
+            indexL = np.fromfile(f, dtype=np.int32, count=NP + 1)
+            indexU = np.fromfile(f, dtype=np.int32, count=NP + 1)
+            itemL = np.fromfile(f, dtype=np.int32, count=NPL)
+            itemU = np.fromfile(f, dtype=np.int32, count=NPU)
+            D = np.fromfile(f, dtype=np.float64, count=9 * NP)
+            AL = np.fromfile(f, dtype=np.float64, count=9 * NPL)
+            AU = np.fromfile(f, dtype=np.float64, count=9 * NPU)
+            B = np.fromfile(f, dtype=np.float64, count=3 * NP)
+            ke = np.fromfile(f, dtype=np.float64, count=576).reshape(24, 24).T.copy()
+            t = float(np.fromfile(f, dtype=np.float64, count=1)[0])
+    return BSR(N, NP, indexL, itemL, indexU, itemU, D, AL, AU, B), ke, t
