@@ -1,0 +1,1173 @@
+/* TEST INFRASTRUCTURE ONLY -- CPU restatement (oracle) of the HEC-MW hot path.
+ * See hecmw_oracle.h.  Loops are kept in the reference's order (1-based
+ * accessors below) so that, compiled without FMA contraction, results agree
+ * with the flang-built reference to the last bits where the algorithm is
+ * deterministic.
+ */
+#include "hecmw_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* 1-based views, Fortran style */
+#define F1(a, i) ((a)[(i)-1])
+
+/* ------------------------------------------------------------------ */
+/* las                                                                  */
+/* ------------------------------------------------------------------ */
+
+/* hecmw_matvec_33_inner, hecmw_solver_las_33.f90:245 (halo) + :263-300 (loop) */
+void orc_matvec_33(const orc_matrix *A, const orc_comm *c, double *X, double *Y) {
+  const int32_t N = A->N;
+  const int32_t *indexL = A->indexL, *indexU = A->indexU, *itemL = A->itemL, *itemU = A->itemU;
+  const double *D = A->D, *AL = A->AL, *AU = A->AU;
+  if (c && c->halo) c->halo(X, c->ctx); /* hecmw_update_3_R */
+  for (int32_t i = 1; i <= N; i++) {
+    double X1 = F1(X, 3 * i - 2), X2 = F1(X, 3 * i - 1), X3 = F1(X, 3 * i);
+    double YV1 = F1(D, 9 * i - 8) * X1 + F1(D, 9 * i - 7) * X2 + F1(D, 9 * i - 6) * X3;
+    double YV2 = F1(D, 9 * i - 5) * X1 + F1(D, 9 * i - 4) * X2 + F1(D, 9 * i - 3) * X3;
+    double YV3 = F1(D, 9 * i - 2) * X1 + F1(D, 9 * i - 1) * X2 + F1(D, 9 * i) * X3;
+    for (int32_t j = indexL[i - 1] + 1; j <= indexL[i]; j++) {
+      int32_t in = F1(itemL, j);
+      X1 = F1(X, 3 * in - 2); X2 = F1(X, 3 * in - 1); X3 = F1(X, 3 * in);
+      YV1 = YV1 + F1(AL, 9 * j - 8) * X1 + F1(AL, 9 * j - 7) * X2 + F1(AL, 9 * j - 6) * X3;
+      YV2 = YV2 + F1(AL, 9 * j - 5) * X1 + F1(AL, 9 * j - 4) * X2 + F1(AL, 9 * j - 3) * X3;
+      YV3 = YV3 + F1(AL, 9 * j - 2) * X1 + F1(AL, 9 * j - 1) * X2 + F1(AL, 9 * j) * X3;
+    }
+    for (int32_t j = indexU[i - 1] + 1; j <= indexU[i]; j++) {
+      int32_t in = F1(itemU, j);
+      X1 = F1(X, 3 * in - 2); X2 = F1(X, 3 * in - 1); X3 = F1(X, 3 * in);
+      YV1 = YV1 + F1(AU, 9 * j - 8) * X1 + F1(AU, 9 * j - 7) * X2 + F1(AU, 9 * j - 6) * X3;
+      YV2 = YV2 + F1(AU, 9 * j - 5) * X1 + F1(AU, 9 * j - 4) * X2 + F1(AU, 9 * j - 3) * X3;
+      YV3 = YV3 + F1(AU, 9 * j - 2) * X1 + F1(AU, 9 * j - 1) * X2 + F1(AU, 9 * j) * X3;
+    }
+    F1(Y, 3 * i - 2) = YV1; F1(Y, 3 * i - 1) = YV2; F1(Y, 3 * i) = YV3;
+  }
+}
+
+/* hecmw_matresid_33, hecmw_solver_las_33.f90:358-380 */
+void orc_matresid_33(const orc_matrix *A, const orc_comm *c, double *X, const double *B, double *R) {
+  orc_matvec_33(A, c, X, R);
+  for (int32_t i = 0; i < 3 * A->N; i++) R[i] = B[i] - R[i];
+}
+
+/* hecmw_InnerProduct_R, hecmw_solver_misc.f90:46-70: sequential sum + allreduce */
+double orc_inner_product(int32_t nn_internal, const double *X, const double *Y, const orc_comm *c) {
+  double sum = 0.0;
+  for (int32_t i = 0; i < 3 * nn_internal; i++) sum = sum + X[i] * Y[i];
+  if (c && c->allreduce) c->allreduce(&sum, 1, c->ctx);
+  return sum;
+}
+
+/* ------------------------------------------------------------------ */
+/* 3x3 helpers shared by DIAG / SSOR / ILU                              */
+/* ------------------------------------------------------------------ */
+
+/* In-place LU of a 3x3 block storing reciprocal pivots:
+ * hecmw_precond_DIAG_33.f90:96-105 == hecmw_precond_SSOR_33.f90:190-201 ==
+ * ILU1a33 hecmw_precond_BILU_33.f90:1493-1528.  a is row-major a[3*(i-1)+(j-1)]. */
+static void lu33(double *a) {
+#define AA(i, j) a[3 * ((i)-1) + ((j)-1)]
+  double PW[4];
+  for (int k = 1; k <= 3; k++) {
+    AA(k, k) = 1.0 / AA(k, k);
+    for (int i = k + 1; i <= 3; i++) {
+      AA(i, k) = AA(i, k) * AA(k, k);
+      for (int j = k + 1; j <= 3; j++) PW[j] = AA(i, j) - AA(i, k) * AA(k, j);
+      for (int j = k + 1; j <= 3; j++) AA(i, j) = PW[j];
+    }
+  }
+#undef AA
+}
+
+/* forward/back substitution with the LU above:
+ * hecmw_precond_DIAG_33.f90:140-144 (same lines in SSOR :341-345, BILU :118-122) */
+static inline void lusolve33(const double *ALU, int32_t i, double *X1, double *X2, double *X3) {
+  double x1 = *X1, x2 = *X2, x3 = *X3;
+  x2 = x2 - F1(ALU, 9 * i - 5) * x1;
+  x3 = x3 - F1(ALU, 9 * i - 2) * x1 - F1(ALU, 9 * i - 1) * x2;
+  x3 = F1(ALU, 9 * i) * x3;
+  x2 = F1(ALU, 9 * i - 4) * (x2 - F1(ALU, 9 * i - 3) * x3);
+  x1 = F1(ALU, 9 * i - 8) * (x1 - F1(ALU, 9 * i - 6) * x3 - F1(ALU, 9 * i - 7) * x2);
+  *X1 = x1; *X2 = x2; *X3 = x3;
+}
+
+/* ------------------------------------------------------------------ */
+/* orderings                                                            */
+/* ------------------------------------------------------------------ */
+
+/* find_minimum_degrees, hecmw_matrix_ordering_CM.f90:138-167 */
+static void find_minimum_degrees(int32_t N, const int32_t *indexL, const int32_t *indexU,
+                                 const int32_t *itemU, int nminmax, int *nmin, int32_t *mins) {
+  int32_t degmin = N;
+  *nmin = 0;
+  for (int32_t i = 1; i <= N; i++) {
+    int32_t deg = indexL[i] - indexL[i - 1];
+    for (int32_t j = indexU[i - 1] + 1; j <= indexU[i]; j++)
+      if (F1(itemU, j) <= N) deg++;
+    if (deg == 0) continue;
+    if (deg < degmin) {
+      degmin = deg; *nmin = 1; mins[0] = i;
+    } else if (deg == degmin) {
+      (*nmin)++;
+      if (*nmin <= nminmax) mins[*nmin - 1] = i;
+    }
+  }
+  if (*nmin > nminmax) *nmin = nminmax;
+}
+
+/* ordering_CM_inner, hecmw_matrix_ordering_CM.f90:68-136 (plain BFS levels) */
+static void ordering_cm_inner(int32_t N, const int32_t *indexL, const int32_t *itemL,
+                              const int32_t *indexU, const int32_t *itemU, int32_t nstart,
+                              int32_t *nlevel, int32_t *lv_index /*0..N*/, int32_t *lv_item /*1..N*/) {
+  int32_t *iwk = (int32_t *)calloc((size_t)N + 1, sizeof(int32_t));
+  lv_index[0] = 0;
+  iwk[nstart] = 1;
+  int32_t cntall = 1;
+  F1(lv_item, 1) = nstart;
+  lv_index[1] = 1;
+  *nlevel = 1;
+  if (N == 1) { free(iwk); return; }
+  for (int32_t level = 2; level <= N; level++) {
+    int32_t cnt = 0;
+    int done = 0;
+    for (int32_t j = lv_index[level - 2] + 1; j <= lv_index[level - 1] && !done; j++) {
+      int32_t jnode = F1(lv_item, j);
+      for (int32_t k = indexL[jnode - 1] + 1; k <= indexL[jnode]; k++) {
+        int32_t knode = F1(itemL, k);
+        if (iwk[knode] == 0) {
+          iwk[knode] = level; cnt++; cntall++;
+          F1(lv_item, cntall) = knode;
+          if (cntall == N) { done = 1; break; }
+        }
+      }
+      if (done) break;
+      for (int32_t k = indexU[jnode - 1] + 1; k <= indexU[jnode]; k++) {
+        int32_t knode = F1(itemU, k);
+        if (knode > N) continue;
+        if (iwk[knode] == 0) {
+          iwk[knode] = level; cnt++; cntall++;
+          F1(lv_item, cntall) = knode;
+          if (cntall == N) { done = 1; break; }
+        }
+      }
+    }
+    if (cnt == 0) {
+      for (int32_t knode = 1; knode <= N; knode++) {
+        if (iwk[knode] == 0) {
+          iwk[knode] = level; cnt++; cntall++;
+          F1(lv_item, cntall) = knode;
+          break;
+        }
+      }
+    }
+    lv_index[level] = cntall;
+    if (cntall == N) { *nlevel = level; break; }
+  }
+  free(iwk);
+}
+
+/* hecmw_matrix_ordering_CM :16-55 then reverse_ordering :169-178
+ * (which mirrors node ids, perm(i) -> N+1-perm(i); it does not reverse the sequence) */
+void orc_ordering_rcm(int32_t N, const int32_t *indexL, const int32_t *itemL, const int32_t *indexU,
+                      const int32_t *itemU, int32_t *perm, int32_t *iperm) {
+  enum { NMINMAX = 5 };
+  int nmin;
+  int32_t mins[NMINMAX];
+  find_minimum_degrees(N, indexL, indexU, itemU, NMINMAX, &nmin, mins);
+  int32_t *nlevel = (int32_t *)calloc(NMINMAX, sizeof(int32_t));
+  int32_t **lv_index = (int32_t **)calloc(NMINMAX, sizeof(int32_t *));
+  int32_t **lv_item = (int32_t **)calloc(NMINMAX, sizeof(int32_t *));
+  for (int i = 0; i < nmin; i++) {
+    lv_index[i] = (int32_t *)calloc((size_t)N + 1, sizeof(int32_t));
+    lv_item[i] = (int32_t *)calloc((size_t)N, sizeof(int32_t));
+    ordering_cm_inner(N, indexL, itemL, indexU, itemU, mins[i], &nlevel[i], lv_index[i], lv_item[i]);
+  }
+  int32_t nlevel_max = nlevel[0];
+  int max_id = 0;
+  for (int i = 1; i < nmin; i++)
+    if (nlevel[i] > nlevel_max) { nlevel_max = nlevel[i]; max_id = i; }
+  for (int32_t i = 1; i <= N; i++) {
+    F1(perm, i) = F1(lv_item[max_id], i);
+    F1(iperm, F1(perm, i)) = i;
+  }
+  for (int i = 0; i < nmin; i++) { free(lv_index[i]); free(lv_item[i]); }
+  free(nlevel); free(lv_index); free(lv_item);
+  /* reverse_ordering */
+  int32_t N1 = N + 1;
+  for (int32_t i = 1; i <= N; i++) {
+    F1(perm, i) = N1 - F1(perm, i);
+    F1(iperm, F1(perm, i)) = i;
+  }
+}
+
+/* hecmw_matrix_ordering_MC, hecmw_matrix_ordering_MC.f90:15-72 */
+void orc_ordering_mc(int32_t N, const int32_t *indexL, const int32_t *itemL, const int32_t *indexU,
+                     const int32_t *itemU, const int32_t *perm_cur, int ncolor_in, int32_t *ncolor_out,
+                     int32_t *COLORindex, int32_t *perm, int32_t *iperm) {
+  int32_t *iwk = (int32_t *)calloc((size_t)N + 1, sizeof(int32_t));
+  int32_t nn_color = N / ncolor_in;
+  int32_t cntall = 0;
+  COLORindex[0] = 0;
+  for (int32_t color = 1; color <= N; color++) {
+    int32_t cnt = 0;
+    for (int32_t i = 1; i <= N; i++) {
+      int32_t inode = F1(perm_cur, i);
+      if (iwk[inode] > 0 || iwk[inode] == -1) continue;
+      iwk[inode] = color;
+      cntall++;
+      F1(perm, cntall) = inode;
+      cnt++;
+      if (cnt == nn_color) break;
+      if (cntall == N) break;
+      for (int32_t j = indexL[inode - 1] + 1; j <= indexL[inode]; j++) {
+        int32_t jnode = F1(itemL, j);
+        if (iwk[jnode] == 0) iwk[jnode] = -1;
+      }
+      for (int32_t j = indexU[inode - 1] + 1; j <= indexU[inode]; j++) {
+        int32_t jnode = F1(itemU, j);
+        if (jnode > N) continue;
+        if (iwk[jnode] == 0) iwk[jnode] = -1;
+      }
+    }
+    COLORindex[color] = cntall;
+    if (cntall == N) { *ncolor_out = color; break; }
+    for (int32_t i = 1; i <= N; i++)
+      if (iwk[i] == -1) iwk[i] = 0;
+  }
+  free(iwk);
+  for (int32_t i = 1; i <= N; i++) F1(iperm, F1(perm, i)) = i;
+}
+
+static int cmp_i32(const void *a, const void *b) {
+  int32_t x = *(const int32_t *)a, y = *(const int32_t *)b;
+  return (x > y) - (x < y);
+}
+
+/* bsearch_int_array, hecmw_matrix_reorder.f90:346-371 (1-based range) */
+static int32_t bsearch_1(const int32_t *array, int32_t istart, int32_t iend, int32_t val) {
+  int32_t left = istart, right = iend;
+  for (;;) {
+    if (left > right) return -1;
+    int32_t center = (left + right) / 2;
+    int32_t pivot = F1(array, center);
+    if (val < pivot) right = center - 1;
+    else if (pivot < val) left = center + 1;
+    else return center;
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* preconditioners                                                      */
+/* ------------------------------------------------------------------ */
+
+struct orc_precond {
+  int kind; /* 1 SSOR, 3 DIAG, 10 ILU0 */
+  int32_t N, NP;
+  /* DIAG / SSOR */
+  double *ALU;
+  /* SSOR private reordered copy */
+  int32_t NColor;
+  int32_t *COLORindex, *perm, *iperm;
+  int32_t *indexL, *indexU, *itemL, *itemU;
+  double *D, *AL, *AU;
+  /* ILU(0) */
+  double *Dlu0, *ALlu0, *AUlu0;
+  const int32_t *inumFI1L, *inumFI1U, *FI1L, *FI1U; /* borrowed from A */
+};
+
+/* hecmw_precond_DIAG_33_setup, hecmw_precond_DIAG_33.f90:27-123 */
+static void diag_setup(orc_precond *P, const orc_matrix *A, double SIGMA_DIAG) {
+  int32_t N = A->N, NP = A->NP;
+  P->ALU = (double *)calloc((size_t)9 * NP, sizeof(double));
+  for (int32_t ii = 1; ii <= N; ii++)
+    for (int k = 0; k < 9; k++) P->ALU[9 * (ii - 1) + k] = A->D[9 * (ii - 1) + k];
+  for (int32_t ii = 1; ii <= N; ii++) {
+    double t[9];
+    memcpy(t, &P->ALU[9 * (ii - 1)], sizeof t);
+    t[0] *= SIGMA_DIAG; t[4] *= SIGMA_DIAG; t[8] *= SIGMA_DIAG;
+    lu33(t);
+    memcpy(&P->ALU[9 * (ii - 1)], t, sizeof t);
+  }
+}
+
+/* hecmw_precond_DIAG_33_apply, hecmw_precond_DIAG_33.f90:125-152 */
+static void diag_apply(const orc_precond *P, double *WW) {
+  for (int32_t i = 1; i <= P->N; i++)
+    lusolve33(P->ALU, i, &F1(WW, 3 * i - 2), &F1(WW, 3 * i - 1), &F1(WW, 3 * i));
+}
+
+/* hecmw_matrix_reorder_profile, hecmw_matrix_reorder.f90:19-65 */
+static void reorder_profile(int32_t N, const int32_t *perm, const int32_t *iperm, const int32_t *indexL,
+                            const int32_t *indexU, const int32_t *itemL, const int32_t *itemU,
+                            int32_t *indexLp, int32_t *indexUp, int32_t *itemLp, int32_t *itemUp) {
+  int32_t cntL = 0, cntU = 0;
+  indexLp[0] = 0; indexUp[0] = 0;
+  for (int32_t inew = 1; inew <= N; inew++) {
+    int32_t iold = F1(perm, inew);
+    for (int32_t j = indexL[iold - 1] + 1; j <= indexL[iold]; j++) {
+      int32_t jnew = F1(iperm, F1(itemL, j));
+      if (jnew < inew) { cntL++; F1(itemLp, cntL) = jnew; }
+      else { cntU++; F1(itemUp, cntU) = jnew; }
+    }
+    for (int32_t j = indexU[iold - 1] + 1; j <= indexU[iold]; j++) {
+      int32_t jold = F1(itemU, j);
+      if (jold > N) continue; /* halo columns dropped */
+      int32_t jnew = F1(iperm, jold);
+      if (jnew < inew) { cntL++; F1(itemLp, cntL) = jnew; }
+      else { cntU++; F1(itemUp, cntU) = jnew; }
+    }
+    indexLp[inew] = cntL; indexUp[inew] = cntU;
+    qsort(itemLp + indexLp[inew - 1], (size_t)(cntL - indexLp[inew - 1]), sizeof(int32_t), cmp_i32);
+    qsort(itemUp + indexUp[inew - 1], (size_t)(cntU - indexUp[inew - 1]), sizeof(int32_t), cmp_i32);
+  }
+}
+
+/* reorder_off_diag2, hecmw_matrix_reorder.f90:258-312 */
+static void reorder_off_diag2(int32_t N, const int32_t *iperm, const int32_t *indexX,
+                              const int32_t *itemX, const double *AX, const int32_t *indexLp,
+                              const int32_t *indexUp, const int32_t *itemLp, const int32_t *itemUp,
+                              double *ALp, double *AUp) {
+  for (int32_t iold = 1; iold <= N; iold++) {
+    int32_t inew = F1(iperm, iold);
+    for (int32_t jold = indexX[iold - 1] + 1; jold <= indexX[iold]; jold++) {
+      int32_t kold = F1(itemX, jold);
+      if (kold > N) continue;
+      int32_t knew = F1(iperm, kold);
+      if (knew < inew) {
+        int32_t jnew = bsearch_1(itemLp, indexLp[inew - 1] + 1, indexLp[inew], knew);
+        memcpy(&ALp[9 * (jnew - 1)], &AX[9 * (jold - 1)], 9 * sizeof(double));
+      } else {
+        int32_t jnew = bsearch_1(itemUp, indexUp[inew - 1] + 1, indexUp[inew], knew);
+        memcpy(&AUp[9 * (jnew - 1)], &AX[9 * (jold - 1)], 9 * sizeof(double));
+      }
+    }
+  }
+}
+
+/* hecmw_precond_SSOR_33_setup, hecmw_precond_SSOR_33.f90:55-223 */
+static void ssor_setup(orc_precond *P, const orc_matrix *A, double SIGMA_DIAG, int NCOLOR_IN,
+                       int nthreads) {
+  int32_t N = A->N;
+  P->perm = (int32_t *)calloc((size_t)N, sizeof(int32_t));
+  P->iperm = (int32_t *)calloc((size_t)N, sizeof(int32_t));
+  if (nthreads == 1) { /* :93-101 */
+    P->NColor = 1;
+    P->COLORindex = (int32_t *)calloc(2, sizeof(int32_t));
+    P->COLORindex[0] = 0; P->COLORindex[1] = N;
+    for (int32_t i = 1; i <= N; i++) { F1(P->perm, i) = i; F1(P->iperm, i) = i; }
+  } else { /* :102-111 */
+    P->COLORindex = (int32_t *)calloc((size_t)N + 1, sizeof(int32_t));
+    int32_t *perm_tmp = (int32_t *)calloc((size_t)N, sizeof(int32_t));
+    orc_ordering_rcm(N, A->indexL, A->itemL, A->indexU, A->itemU, perm_tmp, P->iperm);
+    orc_ordering_mc(N, A->indexL, A->itemL, A->indexU, A->itemU, perm_tmp, NCOLOR_IN, &P->NColor,
+                    P->COLORindex, P->perm, P->iperm);
+    free(perm_tmp);
+  }
+  int32_t NPL = A->indexL[N], NPU = A->indexU[N];
+  P->indexL = (int32_t *)calloc((size_t)N + 1, sizeof(int32_t));
+  P->indexU = (int32_t *)calloc((size_t)N + 1, sizeof(int32_t));
+  /* after the L/U re-split the two parts can each hold up to NPL+NPU entries */
+  P->itemL = (int32_t *)calloc((size_t)NPL + NPU + 1, sizeof(int32_t));
+  P->itemU = (int32_t *)calloc((size_t)NPL + NPU + 1, sizeof(int32_t));
+  reorder_profile(N, P->perm, P->iperm, A->indexL, A->indexU, A->itemL, A->itemU, P->indexL,
+                  P->indexU, P->itemL, P->itemU);
+  P->D = (double *)calloc((size_t)9 * N, sizeof(double));
+  P->AL = (double *)calloc((size_t)9 * (NPL + NPU) + 9, sizeof(double));
+  P->AU = (double *)calloc((size_t)9 * (NPL + NPU) + 9, sizeof(double));
+  /* hecmw_matrix_reorder_values :67-96: reorder_diag2 + reorder_off_diag2 x2 */
+  for (int32_t iold = 1; iold <= N; iold++) {
+    int32_t inew = F1(P->iperm, iold);
+    memcpy(&P->D[9 * (inew - 1)], &A->D[9 * (iold - 1)], 9 * sizeof(double));
+  }
+  reorder_off_diag2(N, P->iperm, A->indexL, A->itemL, A->AL, P->indexL, P->indexU, P->itemL,
+                    P->itemU, P->AL, P->AU);
+  reorder_off_diag2(N, P->iperm, A->indexU, A->itemU, A->AU, P->indexL, P->indexU, P->itemL,
+                    P->itemU, P->AL, P->AU);
+  /* hecmw_matrix_reorder_renum_item :142-157: back to OLD ids (ZP stays in old numbering) */
+  for (int32_t i = 1; i <= P->indexL[N]; i++) F1(P->itemL, i) = F1(P->perm, F1(P->itemL, i));
+  for (int32_t i = 1; i <= P->indexU[N]; i++) F1(P->itemU, i) = F1(P->perm, F1(P->itemU, i));
+  /* :155-211 LU of the (reordered) diagonal blocks */
+  P->ALU = (double *)calloc((size_t)9 * N, sizeof(double));
+  for (int32_t ii = 1; ii <= N; ii++) {
+    double t[9];
+    memcpy(t, &P->D[9 * (ii - 1)], sizeof t);
+    t[0] *= SIGMA_DIAG; t[4] *= SIGMA_DIAG; t[8] *= SIGMA_DIAG;
+    lu33(t);
+    memcpy(&P->ALU[9 * (ii - 1)], t, sizeof t);
+  }
+}
+
+/* hecmw_precond_SSOR_33_apply, hecmw_precond_SSOR_33.f90:225-418.  The thread
+ * block partition (:242-285) only changes who executes a row, not the result:
+ * rows of one colour are independent. */
+static void ssor_apply(const orc_precond *P, double *ZP) {
+  const int32_t *indexL = P->indexL, *indexU = P->indexU, *itemL = P->itemL, *itemU = P->itemU;
+  const double *AL = P->AL, *AU = P->AU, *ALU = P->ALU;
+  /* FORWARD :300-352 */
+  for (int32_t ic = 1; ic <= P->NColor; ic++) {
+    for (int32_t i = P->COLORindex[ic - 1] + 1; i <= P->COLORindex[ic]; i++) {
+      int32_t iold = F1(P->perm, i);
+      double SW1 = F1(ZP, 3 * iold - 2), SW2 = F1(ZP, 3 * iold - 1), SW3 = F1(ZP, 3 * iold);
+      for (int32_t j = indexL[i - 1] + 1; j <= indexL[i]; j++) {
+        int32_t k = F1(itemL, j);
+        double X1 = F1(ZP, 3 * k - 2), X2 = F1(ZP, 3 * k - 1), X3 = F1(ZP, 3 * k);
+        SW1 = SW1 - F1(AL, 9 * j - 8) * X1 - F1(AL, 9 * j - 7) * X2 - F1(AL, 9 * j - 6) * X3;
+        SW2 = SW2 - F1(AL, 9 * j - 5) * X1 - F1(AL, 9 * j - 4) * X2 - F1(AL, 9 * j - 3) * X3;
+        SW3 = SW3 - F1(AL, 9 * j - 2) * X1 - F1(AL, 9 * j - 1) * X2 - F1(AL, 9 * j) * X3;
+      }
+      lusolve33(ALU, i, &SW1, &SW2, &SW3);
+      F1(ZP, 3 * iold - 2) = SW1; F1(ZP, 3 * iold - 1) = SW2; F1(ZP, 3 * iold) = SW3;
+    }
+  }
+  /* BACKWARD :355-410 */
+  for (int32_t ic = P->NColor; ic >= 1; ic--) {
+    for (int32_t i = P->COLORindex[ic]; i >= P->COLORindex[ic - 1] + 1; i--) {
+      double SW1 = 0.0, SW2 = 0.0, SW3 = 0.0;
+      for (int32_t j = indexU[i]; j >= indexU[i - 1] + 1; j--) {
+        int32_t k = F1(itemU, j);
+        double X1 = F1(ZP, 3 * k - 2), X2 = F1(ZP, 3 * k - 1), X3 = F1(ZP, 3 * k);
+        SW1 = SW1 + F1(AU, 9 * j - 8) * X1 + F1(AU, 9 * j - 7) * X2 + F1(AU, 9 * j - 6) * X3;
+        SW2 = SW2 + F1(AU, 9 * j - 5) * X1 + F1(AU, 9 * j - 4) * X2 + F1(AU, 9 * j - 3) * X3;
+        SW3 = SW3 + F1(AU, 9 * j - 2) * X1 + F1(AU, 9 * j - 1) * X2 + F1(AU, 9 * j) * X3;
+      }
+      lusolve33(ALU, i, &SW1, &SW2, &SW3);
+      int32_t iold = F1(P->perm, i);
+      F1(ZP, 3 * iold - 2) -= SW1; F1(ZP, 3 * iold - 1) -= SW2; F1(ZP, 3 * iold) -= SW3;
+    }
+  }
+}
+
+/* ILU1b33, hecmw_precond_BILU_33.f90:1538-1596 */
+static void ilu1b33(double *RHS /*3x3 rm*/, const double *Dk, const double *Aik, const double *Akj) {
+#define M(a, i, j) a[3 * ((i)-1) + ((j)-1)]
+  for (int col = 1; col <= 3; col++) {
+    double X1 = M(Akj, 1, col), X2 = M(Akj, 2, col), X3 = M(Akj, 3, col);
+    X2 = X2 - M(Dk, 2, 1) * X1;
+    X3 = X3 - M(Dk, 3, 1) * X1 - M(Dk, 3, 2) * X2;
+    X3 = M(Dk, 3, 3) * X3;
+    X2 = M(Dk, 2, 2) * (X2 - M(Dk, 2, 3) * X3);
+    X1 = M(Dk, 1, 1) * (X1 - M(Dk, 1, 3) * X3 - M(Dk, 1, 2) * X2);
+    M(RHS, 1, col) = M(Aik, 1, 1) * X1 + M(Aik, 1, 2) * X2 + M(Aik, 1, 3) * X3;
+    M(RHS, 2, col) = M(Aik, 2, 1) * X1 + M(Aik, 2, 2) * X2 + M(Aik, 2, 3) * X3;
+    M(RHS, 3, col) = M(Aik, 3, 1) * X1 + M(Aik, 3, 2) * X2 + M(Aik, 3, 3) * X3;
+  }
+#undef M
+}
+
+/* FORM_ILU0_33, hecmw_precond_BILU_33.f90:185-362.  The reference clears two
+ * NP-length work arrays per row (:255-256, O(NP^2)); here only the touched
+ * entries are reset -- same values, linear cost. */
+static void ilu0_setup(orc_precond *P, const orc_matrix *A, double SIGMA_DIAG) {
+  int32_t NP = A->NP;
+  int32_t NPL = A->indexL[NP], NPU = A->indexU[NP];
+  const int32_t *INL = A->indexL, *INU = A->indexU, *IAL = A->itemL, *IAU = A->itemU;
+  P->Dlu0 = (double *)malloc((size_t)9 * NP * sizeof(double));
+  P->ALlu0 = (double *)malloc(((size_t)9 * NPL + 9) * sizeof(double));
+  P->AUlu0 = (double *)malloc(((size_t)9 * NPU + 9) * sizeof(double));
+  memcpy(P->Dlu0, A->D, (size_t)9 * NP * sizeof(double));
+  memcpy(P->ALlu0, A->AL, (size_t)9 * NPL * sizeof(double));
+  memcpy(P->AUlu0, A->AU, (size_t)9 * NPU * sizeof(double));
+  P->inumFI1L = INL; P->inumFI1U = INU; P->FI1L = IAL; P->FI1U = IAU;
+  double *Dlu0 = P->Dlu0, *ALlu0 = P->ALlu0, *AUlu0 = P->AUlu0;
+  int32_t *IW1 = (int32_t *)calloc((size_t)NP + 1, sizeof(int32_t));
+  int32_t *IW2 = (int32_t *)calloc((size_t)NP + 1, sizeof(int32_t));
+  for (int32_t i = 1; i <= NP; i++) {
+    F1(Dlu0, 9 * i - 8) *= SIGMA_DIAG; F1(Dlu0, 9 * i - 4) *= SIGMA_DIAG; F1(Dlu0, 9 * i) *= SIGMA_DIAG;
+  }
+  lu33(&Dlu0[0]); /* i = 1, :240-253 */
+  for (int32_t i = 2; i <= NP; i++) {
+    for (int32_t k = INL[i - 1] + 1; k <= INL[i]; k++) IW1[F1(IAL, k)] = k;
+    for (int32_t k = INU[i - 1] + 1; k <= INU[i]; k++) IW2[F1(IAU, k)] = k;
+    for (int32_t kk = INL[i - 1] + 1; kk <= INL[i]; kk++) {
+      int32_t k = F1(IAL, kk);
+      const double *DkINV = &Dlu0[9 * (k - 1)];
+      double Aik[9];
+      memcpy(Aik, &ALlu0[9 * (kk - 1)], sizeof Aik);
+      for (int32_t jj = INU[k - 1] + 1; jj <= INU[k]; jj++) {
+        int32_t j = F1(IAU, jj);
+        /* :294 `if (IW1(j).eq.0.and.IW2(j).eq.0) cycle`.  Row i never lists itself in
+         * IW1/IW2, so j==i is skipped here and the `j.eq.i` diagonal update (:309-319) is
+         * dead code in the reference.  Kept as is: that IS the reference's ILU(0). */
+        if (IW1[j] == 0 && IW2[j] == 0) continue;
+        double RHS[9];
+        ilu1b33(RHS, DkINV, Aik, &AUlu0[9 * (jj - 1)]);
+        if (j == i) for (int q = 0; q < 9; q++) Dlu0[9 * (i - 1) + q] -= RHS[q];
+        if (j < i) { int32_t ij0 = IW1[j]; for (int q = 0; q < 9; q++) ALlu0[9 * (ij0 - 1) + q] -= RHS[q]; }
+        if (j > i) { int32_t ij0 = IW2[j]; for (int q = 0; q < 9; q++) AUlu0[9 * (ij0 - 1) + q] -= RHS[q]; }
+      }
+    }
+    lu33(&Dlu0[9 * (i - 1)]);
+    for (int32_t k = INL[i - 1] + 1; k <= INL[i]; k++) IW1[F1(IAL, k)] = 0;
+    for (int32_t k = INU[i - 1] + 1; k <= INU[i]; k++) IW2[F1(IAU, k)] = 0;
+  }
+  free(IW1); free(IW2);
+}
+
+/* hecmw_precond_BILU_33_apply, hecmw_precond_BILU_33.f90:90-157 */
+static void ilu_apply(const orc_precond *P, double *WW) {
+  int32_t N = P->N;
+  const double *Dlu0 = P->Dlu0, *ALlu0 = P->ALlu0, *AUlu0 = P->AUlu0;
+  for (int32_t i = 1; i <= N; i++) {
+    double SW1 = F1(WW, 3 * i - 2), SW2 = F1(WW, 3 * i - 1), SW3 = F1(WW, 3 * i);
+    for (int32_t j = P->inumFI1L[i - 1] + 1; j <= P->inumFI1L[i]; j++) {
+      int32_t k = F1(P->FI1L, j);
+      double X1 = F1(WW, 3 * k - 2), X2 = F1(WW, 3 * k - 1), X3 = F1(WW, 3 * k);
+      SW1 = SW1 - F1(ALlu0, 9 * j - 8) * X1 - F1(ALlu0, 9 * j - 7) * X2 - F1(ALlu0, 9 * j - 6) * X3;
+      SW2 = SW2 - F1(ALlu0, 9 * j - 5) * X1 - F1(ALlu0, 9 * j - 4) * X2 - F1(ALlu0, 9 * j - 3) * X3;
+      SW3 = SW3 - F1(ALlu0, 9 * j - 2) * X1 - F1(ALlu0, 9 * j - 1) * X2 - F1(ALlu0, 9 * j) * X3;
+    }
+    lusolve33(Dlu0, i, &SW1, &SW2, &SW3);
+    F1(WW, 3 * i - 2) = SW1; F1(WW, 3 * i - 1) = SW2; F1(WW, 3 * i) = SW3;
+  }
+  for (int32_t i = N; i >= 1; i--) {
+    double SW1 = 0.0, SW2 = 0.0, SW3 = 0.0;
+    for (int32_t j = P->inumFI1U[i]; j >= P->inumFI1U[i - 1] + 1; j--) {
+      int32_t k = F1(P->FI1U, j);
+      double X1 = F1(WW, 3 * k - 2), X2 = F1(WW, 3 * k - 1), X3 = F1(WW, 3 * k);
+      SW1 = SW1 + F1(AUlu0, 9 * j - 8) * X1 + F1(AUlu0, 9 * j - 7) * X2 + F1(AUlu0, 9 * j - 6) * X3;
+      SW2 = SW2 + F1(AUlu0, 9 * j - 5) * X1 + F1(AUlu0, 9 * j - 4) * X2 + F1(AUlu0, 9 * j - 3) * X3;
+      SW3 = SW3 + F1(AUlu0, 9 * j - 2) * X1 + F1(AUlu0, 9 * j - 1) * X2 + F1(AUlu0, 9 * j) * X3;
+    }
+    lusolve33(Dlu0, i, &SW1, &SW2, &SW3);
+    F1(WW, 3 * i - 2) -= SW1; F1(WW, 3 * i - 1) -= SW2; F1(WW, 3 * i) -= SW3;
+  }
+}
+
+/* hecmw_precond_33_setup dispatch, 33/hecmw_precond_33.f90:27-50 */
+orc_precond *orc_precond_setup(const orc_matrix *A, int precond, double sigma_diag, int ncolor_in,
+                               int nthreads) {
+  orc_precond *P = (orc_precond *)calloc(1, sizeof(orc_precond));
+  P->N = A->N; P->NP = A->NP;
+  switch (precond) {
+    case 1: case 2: P->kind = 1; ssor_setup(P, A, sigma_diag, ncolor_in, nthreads); break;
+    case 3: P->kind = 3; diag_setup(P, A, sigma_diag); break;
+    case 10: P->kind = 10; ilu0_setup(P, A, sigma_diag); break;
+    default: free(P); return NULL;
+  }
+  return P;
+}
+
+void orc_precond_free(orc_precond *P) {
+  if (!P) return;
+  free(P->ALU); free(P->COLORindex); free(P->perm); free(P->iperm);
+  free(P->indexL); free(P->indexU); free(P->itemL); free(P->itemU);
+  free(P->D); free(P->AL); free(P->AU);
+  free(P->Dlu0); free(P->ALlu0); free(P->AUlu0);
+  free(P);
+}
+
+int orc_precond_ncolor(const orc_precond *P) { return P->NColor; }
+const int32_t *orc_precond_perm(const orc_precond *P) { return P->perm; }
+const int32_t *orc_precond_colorindex(const orc_precond *P) { return P->COLORindex; }
+
+/* hecmw_precond_apply hecmw_precond.f90:75-123 + hecmw_precond_33_apply 33/..._33.f90:74-115 */
+void orc_precond_apply(const orc_matrix *A, const orc_comm *c, orc_precond *P, int iterPREmax,
+                       double *R, double *Z, double *ZP) {
+  int32_t NNDOF = 3 * A->N, NPNDOF = 3 * A->NP;
+  if (iterPREmax <= 0) {
+    for (int32_t i = 0; i < NNDOF; i++) Z[i] = R[i];
+    return;
+  }
+  for (int32_t i = 0; i < NNDOF; i++) ZP[i] = R[i];
+  for (int32_t i = NNDOF; i < NPNDOF; i++) ZP[i] = 0.0;
+  for (int32_t i = 0; i < NPNDOF; i++) Z[i] = 0.0;
+  for (int iterPRE = 1; iterPRE <= iterPREmax; iterPRE++) {
+    switch (P->kind) {
+      case 1: ssor_apply(P, ZP); break;
+      case 3: diag_apply(P, ZP); break;
+      case 10: ilu_apply(P, ZP); break;
+    }
+    for (int32_t i = 0; i < NNDOF; i++) Z[i] = Z[i] + ZP[i]; /* additive Schwarz */
+    if (iterPRE == iterPREmax) break;
+    orc_matresid_33(A, c, Z, R, ZP); /* {ZP} = {R} - [A]{Z} */
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* Krylov solvers                                                       */
+/* ------------------------------------------------------------------ */
+enum { ERR_NOCONV_MAXIT = 3001, ERR_DIVERGE_MAT = 3002, ERR_DIVERGE_PC = 3003 };
+
+/* hecmw_solve_CG, hecmw_solver_CG.f90:19-312 */
+int orc_solve_cg(const orc_matrix *A, const orc_comm *c, orc_precond *P, int iterPREmax,
+                 const double *B, double *X, int MAXIT, double TOL, int *iter_out, double *resid_out,
+                 double *hist) {
+  const int N_ITER_RECOMPUTE_R = 50;
+  int32_t N = A->N, NP = A->NP, NNDOF = 3 * N;
+  size_t len = (size_t)3 * NP;
+  double *WW = (double *)calloc(4 * len, sizeof(double));
+  double *R = WW, *Z = WW + len, *Q = WW + len, *Pv = WW + 2 * len, *WK = WW + 3 * len;
+  int error = 0, n_indef_precond = 0, iter = 0;
+  double RHO = 0, RHO1 = 0, BETA = 0, C1, ALPHA, DNRM2, RESID = 0;
+
+  orc_matresid_33(A, c, X, B, R);                     /* :120 */
+  double BNRM2 = orc_inner_product(N, B, B, c);       /* :123 */
+  if (BNRM2 == 0.0) {                                 /* :124-129 */
+    iter = 0; MAXIT = 0; RESID = 0.0;
+    for (size_t i = 0; i < len; i++) X[i] = 0.0;
+  }
+  for (iter = 1; iter <= MAXIT; iter++) {             /* :153 */
+    orc_precond_apply(A, c, P, iterPREmax, R, Z, WK); /* :160 */
+    RHO = orc_inner_product(N, R, Z, c);              /* :168 */
+    if (RHO == 0.0) break;                            /* :170-172 */
+    else if (iter > 1 && RHO * RHO1 <= 0) {           /* :173-180 */
+      n_indef_precond++;
+      if (n_indef_precond >= 3) { error = ERR_DIVERGE_PC; break; }
+    }
+    if (iter == 1) {                                  /* :188-197 */
+      for (int32_t i = 0; i < NNDOF; i++) Pv[i] = Z[i];
+    } else {
+      BETA = RHO / RHO1;
+      for (int32_t i = 0; i < NNDOF; i++) Pv[i] = Z[i] + BETA * Pv[i];
+    }
+    orc_matvec_33(A, c, Pv, Q);                       /* :204 */
+    C1 = orc_inner_product(N, Pv, Q, c);              /* :211 */
+    if (C1 <= 0) { error = ERR_DIVERGE_MAT; break; }  /* :213-217 */
+    ALPHA = RHO / C1;
+    for (int32_t i = 0; i < NNDOF; i++) X[i] = X[i] + ALPHA * Pv[i]; /* :227-230 */
+    if (iter % N_ITER_RECOMPUTE_R == 0) orc_matresid_33(A, c, X, B, R); /* :232-233 */
+    else for (int32_t i = 0; i < NNDOF; i++) R[i] = R[i] - ALPHA * Q[i];
+    DNRM2 = orc_inner_product(N, R, R, c);            /* :240 */
+    RESID = sqrt(DNRM2 / BNRM2);
+    if (hist) hist[iter - 1] = RESID;                 /* :245 ITERLOG line */
+    if (RESID <= TOL) {                               /* :259-266 */
+      if (iter % N_ITER_RECOMPUTE_R == 0) break;
+      orc_matresid_33(A, c, X, B, R);
+      DNRM2 = orc_inner_product(N, R, R, c);
+      RESID = sqrt(DNRM2 / BNRM2);
+      if (RESID <= TOL) break;
+    }
+    if (iter == MAXIT) error = ERR_NOCONV_MAXIT;      /* :267 */
+    RHO1 = RHO;
+  }
+  /* Fortran DO leaves iter = MAXIT+1 on normal exhaustion */
+  if (c && c->halo) c->halo(X, c->ctx);               /* :280 hecmw_update_m_R */
+  free(WW);
+  *iter_out = iter; *resid_out = RESID;
+  return error;
+}
+
+/* hecmw_solve_BiCGSTAB, hecmw_solver_BiCGSTAB.f90:16-297 */
+int orc_solve_bicgstab(const orc_matrix *A, const orc_comm *c, orc_precond *P, int iterPREmax,
+                       const double *B, double *X, int MAXIT, double TOL, int *iter_out,
+                       double *resid_out, double *hist) {
+  const int N_ITER_RECOMPUTE_R = 100;
+  int32_t N = A->N, NP = A->NP, NNDOF = 3 * N;
+  size_t len = (size_t)3 * NP;
+  double *WW = (double *)calloc(8 * len, sizeof(double));
+  /* R=1 RT=2 P=3 PT=4 S=5 ST=1 T=6 V=7 WK=8 (hecmw_solver_BiCGSTAB.f90:45-53) */
+  double *R = WW, *RT = WW + len, *Pv = WW + 2 * len, *PT = WW + 3 * len, *S = WW + 4 * len;
+  double *ST = WW, *T = WW + 5 * len, *V = WW + 6 * len, *WK = WW + 7 * len;
+  int error = 0, iter = 0;
+  double RHO = 0, RHO1 = 0, BETA, ALPHA = 0, OMEGA = 0, C2, CG[2], DNRM2, RESID = 0;
+
+  orc_matresid_33(A, c, X, B, R);
+  for (int32_t i = 0; i < NNDOF; i++) RT[i] = R[i];
+  double BNRM2 = orc_inner_product(N, B, B, c);
+  if (BNRM2 == 0.0) {
+    iter = 0; MAXIT = 0; RESID = 0.0;
+    for (size_t i = 0; i < len; i++) X[i] = 0.0;
+  }
+  for (iter = 1; iter <= MAXIT; iter++) {
+    RHO = orc_inner_product(N, R, RT, c);                       /* :152 */
+    if (iter > 1) {                                             /* :160-170 */
+      BETA = (RHO / RHO1) * (ALPHA / OMEGA);
+      for (int32_t i = 0; i < NNDOF; i++) Pv[i] = R[i] + BETA * (Pv[i] - OMEGA * V[i]);
+    } else {
+      for (int32_t i = 0; i < NNDOF; i++) Pv[i] = R[i];
+    }
+    orc_precond_apply(A, c, P, iterPREmax, Pv, PT, WK);         /* :177 */
+    orc_matvec_33(A, c, PT, V);                                 /* :184 */
+    C2 = orc_inner_product(N, RT, V, c);                        /* :188 */
+    ALPHA = RHO / C2;
+    for (int32_t i = 0; i < NNDOF; i++) S[i] = R[i] - ALPHA * V[i]; /* :194-196 */
+    /* ST aliases R (index 1): hecmw_solver_BiCGSTAB.f90:50 `ST= 1` */
+    orc_precond_apply(A, c, P, iterPREmax, S, ST, WK);          /* :203 */
+    orc_matvec_33(A, c, ST, T);                                 /* :210 */
+    {                                                           /* :217-220 */
+      double s0 = 0.0, s1 = 0.0;
+      for (int32_t i = 0; i < NNDOF; i++) s0 = s0 + T[i] * S[i];
+      for (int32_t i = 0; i < NNDOF; i++) s1 = s1 + T[i] * T[i];
+      CG[0] = s0; CG[1] = s1;
+      if (c && c->allreduce) c->allreduce(CG, 2, c->ctx);
+    }
+    OMEGA = CG[0] / CG[1];
+    for (int32_t i = 0; i < NNDOF; i++) X[i] = X[i] + ALPHA * PT[i] + OMEGA * ST[i]; /* :231-233 */
+    if (iter % N_ITER_RECOMPUTE_R == 0) orc_matresid_33(A, c, X, B, R);
+    else for (int32_t i = 0; i < NNDOF; i++) R[i] = S[i] - OMEGA * T[i];
+    DNRM2 = orc_inner_product(N, R, R, c);
+    RESID = sqrt(DNRM2 / BNRM2);
+    if (hist) hist[iter - 1] = RESID;
+    if (RESID <= TOL) {
+      if (iter % N_ITER_RECOMPUTE_R == 0) break;
+      orc_matresid_33(A, c, X, B, R);
+      DNRM2 = orc_inner_product(N, R, R, c);
+      RESID = sqrt(DNRM2 / BNRM2);
+      if (RESID <= TOL) break;
+    }
+    if (iter == MAXIT) error = ERR_NOCONV_MAXIT;
+    RHO1 = RHO;
+  }
+  if (c && c->halo) c->halo(X, c->ctx);
+  free(WW);
+  *iter_out = iter; *resid_out = RESID;
+  return error;
+}
+
+/* hecmw_solve_iterative, hecmw_solver_Iterative.f90:13-210 (serial + comm hooks).
+ * Error codes: hecmw_solve_error.f90:9-15. */
+int orc_solve_iterative(const orc_matrix *A, const orc_comm *c, const double *B, double *X,
+                        int32_t *Iarray, double *Rarray, int nthreads, int *iter_out,
+                        double *resid_out, double *hist) {
+  int ITER = F1(Iarray, 1), METHOD = F1(Iarray, 2), METHOD2 = F1(Iarray, 8), PRECOND = F1(Iarray, 3);
+  int iterPREmax = F1(Iarray, 5), NCOLOR_IN = F1(Iarray, 34);
+  double RESID = F1(Rarray, 1), SIGMA_DIAG = F1(Rarray, 2);
+  int auto_sigma_diag = 0, error = 0, ret = 0;
+  if (SIGMA_DIAG < 0.0) { auto_sigma_diag = 1; SIGMA_DIAG = 1.0; }
+  int32_t N = A->N, NP = A->NP;
+  /* hecmw_solve_check_zerorhs :242-278 */
+  {
+    double rhs = 0.0;
+    for (int32_t i = 0; i < 3 * N; i++) rhs = rhs + B[i] * B[i];
+    if (c && c->allreduce) c->allreduce(&rhs, 1, c->ctx);
+    if (rhs == 0.0) { ret = 2002; for (int32_t i = 0; i < 3 * NP; i++) X[i] = 0.0; }
+  }
+  /* hecmw_solve_check_zerodiag :212-240 */
+  {
+    double err = 0.0;
+    for (int32_t i = 0; i < N; i++)
+      for (int j = 0; j < 3; j++)
+        if (fabs(A->D[9 * i + 4 * j]) == 0.0) err = 2001;
+    if (c && c->allreduce) { /* MAX in the reference; flags are 0/2001 so SUM>0 is equivalent */
+      c->allreduce(&err, 1, c->ctx);
+    }
+    if (err != 0.0 && (PRECOND < 10 && iterPREmax > 0)) return 2001;
+  }
+  /* hecmw_mat_recycle_precond_setting, hecmw_matrix_misc.f90:678-697 */
+  if (F1(Iarray, 98) >= 1) { F1(Iarray, 97) = 1; F1(Iarray, 96) = 0; }
+  else if (F1(Iarray, 97) > 1) { F1(Iarray, 96) = 0; F1(Iarray, 97) = 1; }
+  else if (F1(Iarray, 97) == 1) {
+    if (F1(Iarray, 96) < F1(Iarray, 35)) { F1(Iarray, 97) = 0; F1(Iarray, 96)++; }
+    else F1(Iarray, 96) = 0;
+  }
+  double resid_run = 0.0;
+  int iter_run = 0;
+  for (;;) {
+    F1(Iarray, 81) = 0; F1(Iarray, 82) = 0;
+    orc_precond *P = NULL;
+    if (iterPREmax > 0) {
+      P = orc_precond_setup(A, PRECOND, SIGMA_DIAG, NCOLOR_IN, nthreads);
+      if (!P) return 1001;
+      F1(Iarray, 98) = 0; F1(Iarray, 97) = 0;
+    }
+    if (METHOD == 1)
+      error = orc_solve_cg(A, c, P, iterPREmax, B, X, ITER, RESID, &iter_run, &resid_run, hist);
+    else if (METHOD == 2)
+      error = orc_solve_bicgstab(A, c, P, iterPREmax, B, X, ITER, RESID, &iter_run, &resid_run, hist);
+    else { orc_precond_free(P); return 1001; }
+    orc_precond_free(P);
+    if (error == ERR_DIVERGE_PC || error == ERR_DIVERGE_MAT) { /* :145-156 */
+      F1(Iarray, 82) = 1;
+      if ((PRECOND >= 10 && PRECOND < 20) && auto_sigma_diag == 1 && SIGMA_DIAG < 2.0) {
+        SIGMA_DIAG = SIGMA_DIAG + 0.1;
+        continue;
+      } else if (METHOD == 1 && METHOD2 > 1) {
+        if (auto_sigma_diag == 1) SIGMA_DIAG = 1.0;
+        METHOD = METHOD2;
+        continue;
+      }
+    }
+    break;
+  }
+  if (error != 0) ret = error;
+  /* hecmw_rel_resid_L2, hecmw_solver_las.f90:129-158 */
+  {
+    double *r = (double *)calloc((size_t)3 * NP, sizeof(double));
+    double b2 = orc_inner_product(N, B, B, c);
+    if (b2 == 0.0) b2 = 1.0;
+    orc_matresid_33(A, c, X, B, r);
+    double r2 = orc_inner_product(N, r, r, c);
+    double resid2 = sqrt(r2 / b2);
+    if (resid2 < F1(Rarray, 1)) F1(Iarray, 81) = 1;
+    free(r);
+  }
+  *iter_out = iter_run; *resid_out = resid_run;
+  return ret;
+}
+
+/* ------------------------------------------------------------------ */
+/* assembly side                                                        */
+/* ------------------------------------------------------------------ */
+
+/* hecmw_mat_con0/con1, hecmw_mat_con.f90:42-268: lower/upper neighbour lists per
+ * node from element connectivity, sorted ascending. */
+void orc_mat_con(int32_t NP, int32_t n_elem, int nn, const int32_t *conn, int32_t *indexL,
+                 int32_t *indexU, int32_t *itemL, int32_t *itemU) {
+  /* count node->element adjacency */
+  int32_t *cnt = (int32_t *)calloc((size_t)NP + 2, sizeof(int32_t));
+  for (int64_t e = 0; e < (int64_t)n_elem * nn; e++) cnt[conn[e] + 1]++;
+  for (int32_t i = 1; i <= NP + 1; i++) cnt[i] += cnt[i - 1];
+  int32_t *adj = (int32_t *)malloc(((size_t)n_elem * nn + 1) * sizeof(int32_t));
+  int32_t *pos = (int32_t *)malloc(((size_t)NP + 2) * sizeof(int32_t));
+  memcpy(pos, cnt, ((size_t)NP + 2) * sizeof(int32_t));
+  for (int32_t e = 0; e < n_elem; e++)
+    for (int j = 0; j < nn; j++) adj[pos[conn[(size_t)e * nn + j]]++] = e;
+  int32_t cap = 4096;
+  int32_t *buf = (int32_t *)malloc((size_t)cap * sizeof(int32_t));
+  int32_t cl = 0, cu = 0;
+  indexL[0] = 0; indexU[0] = 0;
+  for (int32_t i = 1; i <= NP; i++) {
+    int32_t m = 0;
+    for (int32_t a = cnt[i]; a < cnt[i + 1]; a++) {
+      int32_t e = adj[a];
+      for (int j = 0; j < nn; j++) {
+        if (m == cap) { cap *= 2; buf = (int32_t *)realloc(buf, (size_t)cap * sizeof(int32_t)); }
+        buf[m++] = conn[(size_t)e * nn + j];
+      }
+    }
+    qsort(buf, (size_t)m, sizeof(int32_t), cmp_i32);
+    int32_t prev = -1;
+    for (int32_t k = 0; k < m; k++) {
+      int32_t v = buf[k];
+      if (v == prev) continue;
+      prev = v;
+      if (v < i) { if (itemL) itemL[cl] = v; cl++; }
+      else if (v > i) { if (itemU) itemU[cu] = v; cu++; }
+    }
+    indexL[i] = cl; indexU[i] = cu;
+  }
+  free(cnt); free(adj); free(pos); free(buf);
+}
+
+/* calInverse, fistr1/src/lib/utilities/utilities.f90:247-316 (Gauss-Jordan, partial pivot).
+ * A is column-major NNxNN as in Fortran: A(i,j) = a[(j-1)*NN + (i-1)]. */
+static void cal_inverse(int NN, double *a) {
+#define A_(i, j) a[((j)-1) * NN + ((i)-1)]
+  int IP[16];
+  const double EPS = 1.0e-35;
+  for (int I = 1; I <= NN; I++) IP[I] = I;
+  for (int K = 1; K <= NN; K++) {
+    double WMAX = 0.0;
+    int LR = K;
+    for (int I = K; I <= NN; I++) {
+      double W = fabs(A_(I, K));
+      if (W > WMAX) { WMAX = W; LR = I; }
+    }
+    double PIVOT = A_(LR, K);
+    if (fabs(PIVOT) <= EPS) { fprintf(stderr, "PIVOT ERROR AT %d\n", K); abort(); }
+    if (LR != K) {
+      int IW = IP[K]; IP[K] = IP[LR]; IP[LR] = IW;
+      for (int J = 1; J <= NN; J++) { double W = A_(K, J); A_(K, J) = A_(LR, J); A_(LR, J) = W; }
+    }
+    for (int I = 1; I <= NN; I++) A_(K, I) = A_(K, I) / PIVOT;
+    for (int I = 1; I <= NN; I++) {
+      if (I != K) {
+        double W = A_(I, K);
+        if (W != 0.0) {
+          for (int J = 1; J <= NN; J++)
+            if (J != K) A_(I, J) = A_(I, J) - W * A_(K, J);
+          A_(I, K) = -W / PIVOT;
+        }
+      }
+    }
+    A_(K, K) = 1.0 / PIVOT;
+  }
+  for (int I = 1; I <= NN; I++) {
+    int K = IP[I];
+    if (K != I) {
+      int IW = IP[K]; IP[K] = IP[I]; IP[I] = IW;
+      for (int J = 1; J <= NN; J++) { double W = A_(J, I); A_(J, I) = A_(J, K); A_(J, K) = W; }
+    }
+  }
+#undef A_
+}
+
+/* ShapeDeriv_hex8n, element/hex8n.f90:24-53: deriv[a][d] */
+static void shape_deriv_hex8(const double *lc, double deriv[8][3]) {
+  static const double sx[8] = {-1, 1, 1, -1, -1, 1, 1, -1};
+  static const double sy[8] = {-1, -1, 1, 1, -1, -1, 1, 1};
+  static const double sz[8] = {-1, -1, -1, -1, 1, 1, 1, 1};
+  for (int a = 0; a < 8; a++) {
+    double fx = 1.0 + sx[a] * lc[0], fy = 1.0 + sy[a] * lc[1], fz = 1.0 + sz[a] * lc[2];
+    deriv[a][0] = sx[a] * 0.125 * fy * fz;
+    deriv[a][1] = sy[a] * 0.125 * fx * fz;
+    deriv[a][2] = sz[a] * 0.125 * fx * fy;
+  }
+}
+
+/* jacobian / det / inverse: getJacobian element/element.f90:772-818 (3-D branch) */
+static void jacobian_hex8(const double *lc, const double *ec /*8x3*/, double *det, double XJ[3][3],
+                          double XJI[3][3], double deriv[8][3]) {
+  shape_deriv_hex8(lc, deriv);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double s = 0.0;
+      for (int a = 0; a < 8; a++) s += ec[3 * a + i] * deriv[a][j]; /* matmul(elecoord, deriv) */
+      XJ[i][j] = s;
+    }
+  double DET = XJ[0][0] * XJ[1][1] * XJ[2][2] + XJ[1][0] * XJ[2][1] * XJ[0][2] +
+               XJ[2][0] * XJ[0][1] * XJ[1][2] - XJ[2][0] * XJ[1][1] * XJ[0][2] -
+               XJ[1][0] * XJ[0][1] * XJ[2][2] - XJ[0][0] * XJ[2][1] * XJ[1][2];
+  double DUM = 1.0 / DET;
+  XJI[0][0] = DUM * (XJ[1][1] * XJ[2][2] - XJ[2][1] * XJ[1][2]);
+  XJI[0][1] = DUM * (-XJ[0][1] * XJ[2][2] + XJ[2][1] * XJ[0][2]);
+  XJI[0][2] = DUM * (XJ[0][1] * XJ[1][2] - XJ[1][1] * XJ[0][2]);
+  XJI[1][0] = DUM * (-XJ[1][0] * XJ[2][2] + XJ[2][0] * XJ[1][2]);
+  XJI[1][1] = DUM * (XJ[0][0] * XJ[2][2] - XJ[2][0] * XJ[0][2]);
+  XJI[1][2] = DUM * (-XJ[0][0] * XJ[1][2] + XJ[1][0] * XJ[0][2]);
+  XJI[2][0] = DUM * (XJ[1][0] * XJ[2][1] - XJ[2][0] * XJ[1][1]);
+  XJI[2][1] = DUM * (-XJ[0][0] * XJ[2][1] + XJ[2][0] * XJ[0][1]);
+  XJI[2][2] = DUM * (XJ[0][0] * XJ[1][1] - XJ[1][0] * XJ[0][1]);
+  *det = DET;
+}
+
+/* getGlobalDeriv, element/element.f90:693-744 */
+static void global_deriv_hex8(const double *lc, const double *ec, double *det, double gderiv[][3]) {
+  double XJ[3][3], XJI[3][3], deriv[8][3];
+  jacobian_hex8(lc, ec, det, XJ, XJI, deriv);
+  for (int a = 0; a < 8; a++)
+    for (int j = 0; j < 3; j++)
+      gderiv[a][j] = deriv[a][0] * XJI[0][j] + deriv[a][1] * XJI[1][j] + deriv[a][2] * XJI[2][j];
+}
+
+/* calElasticMatrix (D3), physics/ElasticLinear.f90:15-59 */
+static void elastic_matrix(double EE, double PP, double D[6][6]) {
+  memset(D, 0, 36 * sizeof(double));
+  D[0][0] = EE * (1.0 - PP) / (1.0 - 2.0 * PP) / (1.0 + PP);
+  D[0][1] = EE * PP / (1.0 - 2.0 * PP) / (1.0 + PP);
+  D[0][2] = D[0][1]; D[1][0] = D[0][1]; D[1][1] = D[0][0]; D[1][2] = D[0][1];
+  D[2][0] = D[0][2]; D[2][1] = D[1][2]; D[2][2] = D[0][0];
+  D[3][3] = EE / (1.0 + PP) * 0.5; D[4][4] = D[3][3]; D[5][5] = D[3][3];
+}
+
+static const double GP = 0.577350269189626; /* element/quadrature.f90:83-91, weights 1 (:221) */
+
+static void quad_point(int LX, double *lc) {
+  lc[0] = (LX & 1) ? GP : -GP;
+  lc[1] = (LX & 2) ? GP : -GP;
+  lc[2] = (LX & 4) ? GP : -GP;
+}
+
+/* B (6 x ncol) from gderiv for nj nodes: static_LIB_3d.f90:126-136 */
+static void fill_B(int nj, double gderiv[][3], double *B, int ncol) {
+  memset(B, 0, (size_t)6 * ncol * sizeof(double));
+  for (int j = 0; j < nj; j++) {
+    B[0 * ncol + 3 * j] = gderiv[j][0];
+    B[1 * ncol + 3 * j + 1] = gderiv[j][1];
+    B[2 * ncol + 3 * j + 2] = gderiv[j][2];
+    B[3 * ncol + 3 * j] = gderiv[j][1];
+    B[3 * ncol + 3 * j + 1] = gderiv[j][0];
+    B[4 * ncol + 3 * j + 1] = gderiv[j][2];
+    B[4 * ncol + 3 * j + 2] = gderiv[j][1];
+    B[5 * ncol + 3 * j] = gderiv[j][2];
+    B[5 * ncol + 3 * j + 2] = gderiv[j][0];
+  }
+}
+
+/* stiff(i,j) += dot(B(:,i), DB(:,j)) * wg : static_LIB_3d.f90:171-174 */
+static void add_BtDB(int ncol, const double *B, double D[6][6], double wg, double *K) {
+  double DB[6 * 33];
+  for (int r = 0; r < 6; r++)
+    for (int j = 0; j < ncol; j++) {
+      double s = 0.0;
+      for (int q = 0; q < 6; q++) s += D[r][q] * B[q * ncol + j];
+      DB[r * ncol + j] = s;
+    }
+  for (int i = 0; i < ncol; i++)
+    for (int j = 0; j < ncol; j++) {
+      double s = 0.0;
+      for (int q = 0; q < 6; q++) s += B[q * ncol + i] * DB[q * ncol + j];
+      K[i * ncol + j] += s * wg;
+    }
+}
+
+void orc_stf_c3d8(int elemopt, const double *ecoord, double E, double nu, double *stiff) {
+  double D[6][6];
+  elastic_matrix(E, nu, D);
+  double lc[3], det;
+  if (elemopt == 3) { /* STF_C3, static_LIB_3d.f90:47-205, INFINITE flag */
+    double gd[8][3], B[6 * 24];
+    memset(stiff, 0, 576 * sizeof(double));
+    for (int LX = 0; LX < 8; LX++) {
+      quad_point(LX, lc);
+      global_deriv_hex8(lc, ecoord, &det, gd);
+      fill_B(8, gd, B, 24);
+      add_BtDB(24, B, D, 1.0 * det, stiff);
+    }
+  } else if (elemopt == 2) { /* STF_C3D8Bbar, static_LIB_C3D8.f90:23-200 */
+    double gd[8][3], Bbar[8][3], B[6 * 24];
+    memset(stiff, 0, 576 * sizeof(double));
+    lc[0] = lc[1] = lc[2] = 0.0;
+    global_deriv_hex8(lc, ecoord, &det, Bbar); /* dilatation at centroid :72-73 */
+    for (int LX = 0; LX < 8; LX++) {
+      quad_point(LX, lc);
+      global_deriv_hex8(lc, ecoord, &det, gd);
+      memset(B, 0, sizeof B);
+      for (int j = 0; j < 8; j++) { /* :103-126 */
+        double B4 = (Bbar[j][0] - gd[j][0]) / 3.0, B6 = (Bbar[j][1] - gd[j][1]) / 3.0,
+               B8 = (Bbar[j][2] - gd[j][2]) / 3.0;
+        B[0 * 24 + 3 * j] = gd[j][0] + B4; B[0 * 24 + 3 * j + 1] = B6; B[0 * 24 + 3 * j + 2] = B8;
+        B[1 * 24 + 3 * j] = B4; B[1 * 24 + 3 * j + 1] = gd[j][1] + B6; B[1 * 24 + 3 * j + 2] = B8;
+        B[2 * 24 + 3 * j] = B4; B[2 * 24 + 3 * j + 1] = B6; B[2 * 24 + 3 * j + 2] = gd[j][2] + B8;
+        B[3 * 24 + 3 * j] = gd[j][1]; B[3 * 24 + 3 * j + 1] = gd[j][0];
+        B[4 * 24 + 3 * j + 1] = gd[j][2]; B[4 * 24 + 3 * j + 2] = gd[j][1];
+        B[5 * 24 + 3 * j] = gd[j][2]; B[5 * 24 + 3 * j + 2] = gd[j][0];
+      }
+      add_BtDB(24, B, D, 1.0 * det, stiff);
+    }
+  } else { /* STF_C3D8IC, static_LIB_3dIC.f90:21-215 */
+    double tmp[33 * 33], gd[11][3], B[6 * 33];
+    double XJ[3][3], inv0[3][3], deriv[8][3], det0;
+    memset(tmp, 0, sizeof tmp);
+    lc[0] = lc[1] = lc[2] = 0.0;
+    jacobian_hex8(lc, ecoord, &det0, XJ, inv0, deriv); /* :79-80 */
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) inv0[i][j] *= det0;   /* :81 */
+    for (int LX = 0; LX < 8; LX++) {
+      quad_point(LX, lc);
+      global_deriv_hex8(lc, ecoord, &det, gd);
+      for (int d = 0; d < 3; d++) { /* :120-122 incompatible-mode derivatives */
+        gd[8][d] = -2.0 * lc[0] * inv0[0][d] / det;
+        gd[9][d] = -2.0 * lc[1] * inv0[1][d] / det;
+        gd[10][d] = -2.0 * lc[2] * inv0[2][d] / det;
+      }
+      fill_B(11, gd, B, 33);
+      add_BtDB(33, B, D, 1.0 * det, tmp);
+    }
+    /* static condensation :206-209 */
+    double xj[81], tmpk[24 * 9];
+    for (int i = 0; i < 9; i++)
+      for (int j = 0; j < 9; j++) xj[j * 9 + i] = tmp[(24 + i) * 33 + (24 + j)]; /* column-major */
+    cal_inverse(9, xj);
+    for (int i = 0; i < 24; i++)
+      for (int j = 0; j < 9; j++) {
+        double s = 0.0;
+        for (int q = 0; q < 9; q++) s += tmp[i * 33 + 24 + q] * xj[j * 9 + q];
+        tmpk[i * 9 + j] = s;
+      }
+    for (int i = 0; i < 24; i++)
+      for (int j = 0; j < 24; j++) {
+        double s = 0.0;
+        for (int q = 0; q < 9; q++) s += tmpk[i * 9 + q] * tmp[(24 + q) * 33 + j];
+        stiff[i * 24 + j] = tmp[i * 33 + j] - s;
+      }
+  }
+}
+
+/* hecmw_array_search_i, hecmw_mat_ass.f90:137-166 */
+static int32_t array_search(const int32_t *array, int32_t is, int32_t iE, int32_t ival) {
+  return bsearch_1(array, is, iE, ival);
+}
+
+/* hecmw_mat_ass_elem + hecmw_mat_add_node, hecmw_mat_ass.f90:31-134 */
+void orc_mat_ass_elem(int32_t NP, const int32_t *indexL, const int32_t *itemL, const int32_t *indexU,
+                      const int32_t *itemU, double *D, double *AL, double *AU, int nn,
+                      const int32_t *nodLOCAL, const double *stiff) {
+  (void)NP;
+  int ld = 3 * nn;
+  for (int ie = 0; ie < nn; ie++) {
+    int32_t inod = nodLOCAL[ie];
+    for (int je = 0; je < nn; je++) {
+      int32_t jnod = nodLOCAL[je];
+      double *dst;
+      if (inod < jnod) {
+        int32_t k = array_search(itemU, indexU[inod - 1] + 1, indexU[inod], jnod);
+        if (k < 0) { fprintf(stderr, "###ERROR### : cannot find connectivity (1)\n"); abort(); }
+        dst = &AU[9 * (k - 1)];
+      } else if (inod > jnod) {
+        int32_t k = array_search(itemL, indexL[inod - 1] + 1, indexL[inod], jnod);
+        if (k < 0) { fprintf(stderr, "###ERROR### : cannot find connectivity (2)\n"); abort(); }
+        dst = &AL[9 * (k - 1)];
+      } else {
+        dst = &D[9 * (inod - 1)];
+      }
+      for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) dst[3 * a + b] += stiff[(3 * ie + a) * ld + 3 * je + b];
+    }
+  }
+}
+
+/* hecmw_mat_ass_bc, hecmw_mat_ass.f90:292-429 (NDOF=3) */
+void orc_mat_ass_bc(int32_t NP, const int32_t *indexL, const int32_t *itemL, const int32_t *indexU,
+                    const int32_t *itemU, double *D, double *AL, double *AU, double *B, int32_t inode,
+                    int32_t idof, double RHS) {
+  (void)NP;
+  const int NDOF = 3, ndof2 = 9;
+  if (NDOF < idof) return;
+  /* diagonal block */
+  F1(B, NDOF * inode - (NDOF - idof)) = RHS;
+  int ii = ndof2 - idof;
+  for (int i = NDOF - 1; i >= 0; i--) {
+    if (i != NDOF - idof) {
+      int32_t idx = NDOF * inode - i;
+      double val = F1(D, ndof2 * inode - ii) * RHS;
+      F1(B, idx) = F1(B, idx) - val;
+    }
+    ii = ii - NDOF;
+  }
+  ii = ndof2 - 1 - (idof - 1) * NDOF; /* row to zero */
+  for (int i = 0; i <= NDOF - 1; i++) F1(D, ndof2 * inode - ii + i) = 0.0;
+  ii = ndof2 - idof; /* column to zero, unit diagonal */
+  for (int i = 1; i <= NDOF; i++) {
+    F1(D, ndof2 * inode - ii) = (i != idof) ? 0.0 : 1.0;
+    ii = ii - NDOF;
+  }
+  /* off-diagonal blocks */
+  ii = ndof2 - 1 - (idof - 1) * NDOF;
+  for (int32_t k = indexL[inode - 1] + 1; k <= indexL[inode]; k++) {
+    for (int i = 0; i <= NDOF - 1; i++) F1(AL, ndof2 * k - ii + i) = 0.0; /* row (left) */
+    int32_t in = F1(itemL, k);                                            /* column (upper) */
+    for (int32_t ik = indexU[in - 1] + 1; ik <= indexU[in]; ik++) {
+      if (F1(itemU, ik) == inode) {
+        int iii = ndof2 - idof;
+        for (int i = NDOF - 1; i >= 0; i--) {
+          int32_t idx = NDOF * in - i;
+          double val = F1(AU, ndof2 * ik - iii) * RHS;
+          F1(B, idx) = F1(B, idx) - val;
+          F1(AU, ndof2 * ik - iii) = 0.0;
+          iii = iii - NDOF;
+        }
+        break;
+      }
+    }
+  }
+  ii = ndof2 - 1 - (idof - 1) * NDOF;
+  for (int32_t k = indexU[inode - 1] + 1; k <= indexU[inode]; k++) {
+    for (int i = 0; i <= NDOF - 1; i++) F1(AU, ndof2 * k - ii + i) = 0.0; /* row (right) */
+    int32_t in = F1(itemU, k);                                            /* column (lower) */
+    for (int32_t ik = indexL[in - 1] + 1; ik <= indexL[in]; ik++) {
+      if (F1(itemL, ik) == inode) {
+        int iii = ndof2 - idof;
+        for (int i = NDOF - 1; i >= 0; i--) {
+          int32_t idx = NDOF * in - i;
+          double val = F1(AL, ndof2 * ik - iii) * RHS;
+          F1(B, idx) = F1(B, idx) - val;
+          F1(AL, ndof2 * ik - iii) = 0.0;
+          iii = iii - NDOF;
+        }
+        break;
+      }
+    }
+  }
+}
+
+/* fstr_StiffMatrix element loop, fstr_StiffMatrix.f90:40 (clear) + :58-207 */
+void orc_assemble_c3d8(int elemopt, int32_t NP, int32_t n_elem, const double *coord,
+                       const int32_t *conn, double E, double nu, const int32_t *indexL,
+                       const int32_t *itemL, const int32_t *indexU, const int32_t *itemU, double *D,
+                       double *AL, double *AU) {
+  memset(D, 0, (size_t)9 * NP * sizeof(double));
+  memset(AL, 0, (size_t)9 * indexL[NP] * sizeof(double));
+  memset(AU, 0, (size_t)9 * indexU[NP] * sizeof(double));
+  for (int32_t e = 0; e < n_elem; e++) {
+    double ec[24], stiff[576];
+    const int32_t *nod = &conn[(size_t)8 * e];
+    for (int j = 0; j < 8; j++)
+      for (int d = 0; d < 3; d++) ec[3 * j + d] = coord[3 * (size_t)(nod[j] - 1) + d];
+    orc_stf_c3d8(elemopt, ec, E, nu, stiff);
+    orc_mat_ass_elem(NP, indexL, itemL, indexU, itemU, D, AL, AU, 8, nod, stiff);
+  }
+}

@@ -1,0 +1,88 @@
+"""The CPU restatement (oracle/hecmw_oracle.c) against the golden vectors the REAL
+reference produced (tests/golden/*.npz, made by tests/golden/make_golden.py from
+oracle/_ref = /root/reference compiled with flang), and against the reference's
+own known answer examples/static/exA/A361_correct.log."""
+import numpy as np
+import pytest
+
+from conftest import CONFIGS, golden_matrix, load_golden
+
+DECKS = ["cube4", "cube3s", "exA_A361"]
+
+
+@pytest.mark.parametrize("deck", DECKS)
+@pytest.mark.parametrize("eo,tag", [(1, "ic_"), (2, "bbar_"), (3, "fi_")])
+def test_assembly_bit_exact(oracle, deck, eo, tag):
+    g = load_golden(deck)
+    ke = oracle.stf_c3d8(eo, g["coord"][g["conn"][0] - 1], float(g["E"]), float(g["nu"]))
+    assert np.array_equal(ke, g[tag + "ke"])          # element stiffness: bit exact
+    A = oracle.assemble(eo, g["coord"], g["conn"], float(g["E"]), float(g["nu"]),
+                        bc=(g["bc_node"], g["bc_dof"], g["bc_val"]), load=g["load"])
+    for k in ("indexL", "itemL", "indexU", "itemU"):  # CRS profile: identical
+        assert np.array_equal(getattr(A, k), g[tag + k]), k
+    for k in ("D", "AL", "AU", "B"):                  # values after BC: bit exact
+        assert np.array_equal(getattr(A, k), g[tag + k]), k
+
+
+@pytest.mark.parametrize("deck", DECKS)
+@pytest.mark.parametrize("meth,pc,thr", CONFIGS)
+def test_solver_matches_reference(oracle, deck, meth, pc, thr):
+    from oracle.refrun import default_params
+    g = load_golden(deck)
+    A = golden_matrix(g)
+    I, R = default_params(method=meth, precond=pc)
+    o = oracle.solve_iterative(A, I, R, nthreads=thr)
+    tag = "sol_m%d_p%d_t%d_" % (meth, pc, thr)
+    assert o["code"] == 0
+    assert o["iter"] == int(g[tag + "iter"])
+    # the reference prints 7 significant digits (1pe16.6, hecmw_solver_CG.f90:245)
+    h = g[tag + "hist"]
+    assert len(o["history"]) == len(h)
+    assert np.all(np.abs(o["history"] - h) <= 6e-7 * h)
+    assert np.array_equal(o["X"], g[tag + "X"])       # solution: bit exact
+    assert o["Iarray"][80] == g[tag + "Iarray"][80] == 1
+
+
+def test_exA_known_answer(oracle):
+    """examples/static/exA/A361_correct.log extrema, the reference harness' own
+    tolerance (|d| <= 1e-4, examples/test_FrontISTR.rb:10)."""
+    from oracle.refrun import default_params
+    g = load_golden("exA_A361")
+    A = oracle.assemble(1, g["coord"], g["conn"], float(g["E"]), float(g["nu"]),
+                        bc=(g["bc_node"], g["bc_dof"], g["bc_val"]), load=g["load"])
+    I, R = default_params(method=1, precond=3)
+    o = oracle.solve_iterative(A, I, R)
+    U = o["X"].reshape(-1, 3)
+    for c, key in enumerate(("U1", "U2", "U3")):
+        mx, mn = g["expect_" + key]
+        assert abs(U[:, c].max() - mx) <= 1e-4 and abs(U[:, c].min() - mn) <= 1e-4
+    assert o["iter"] == 70                             # CG+DIAG 70 iterations
+
+
+def test_zero_rhs_and_zero_diag(oracle):
+    from oracle.refrun import default_params
+    g = load_golden("cube4")
+    A = golden_matrix(g)
+    I, R = default_params(method=1, precond=3)
+    A.B = np.zeros_like(A.B)
+    o = oracle.solve_iterative(A, I, R)
+    assert o["code"] == 2002 and not o["X"].any()       # HECMW_SOLVER_ERROR_ZERO_RHS (warning)
+    A = golden_matrix(g)
+    A.D = A.D.copy(); A.D[0] = 0.0
+    o = oracle.solve_iterative(A, I, R)
+    assert o["code"] == 2001                            # HECMW_SOLVER_ERROR_ZERO_DIAG
+
+
+def test_multicolor_ordering_properties(oracle):
+    g = load_golden("cube4")
+    A = golden_matrix(g)
+    P = oracle.Precond(A, 1, nthreads=4, ncolor_in=10)
+    perm, ci = P.perm, P.colorindex
+    assert sorted(perm.tolist()) == list(range(1, A.N + 1))
+    assert P.ncolor >= 10 and ci[-1] == A.N
+    color = np.zeros(A.N + 1, dtype=int)
+    for c in range(P.ncolor):
+        color[perm[ci[c]:ci[c + 1]]] = c + 1
+    for i in range(1, A.N + 1):                          # colours are independent sets
+        nb = np.concatenate([A.itemL[A.indexL[i - 1]:A.indexL[i]], A.itemU[A.indexU[i - 1]:A.indexU[i]]])
+        assert not np.any(color[nb] == color[i])
