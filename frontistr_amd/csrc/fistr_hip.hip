@@ -1,0 +1,986 @@
+// libfistr_hip: MI355X-native HEC-MW linear-solve hot path behind the C ABI of
+// include/fistr_hip.h.  Host orchestration; the kernels live in fx_kernels.h /
+// fx_assemble.h.  gfx950 only -- there is no CPU fallback anywhere in this library.
+#include <rccl/rccl.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <thread>
+
+#include "fx_assemble.h"
+#include "fx_kernels.h"
+
+namespace fxo {
+struct Graph {
+  int32_t n = 0;
+  std::vector<int64_t> ptr;
+  std::vector<int32_t> adj;
+};
+Graph build_graph(int32_t N, const int32_t *indexL, const int32_t *itemL, const int32_t *indexU,
+                  const int32_t *itemU);
+std::vector<int32_t> rcm_sequence(const Graph &g);
+void multicolor(const Graph &g, const std::vector<int32_t> &seq, int ncolor_in, std::vector<int32_t> &perm,
+                std::vector<int32_t> &colorindex);
+}  // namespace fxo
+
+thread_local std::string g_fx_error;
+
+int fx_fail(const char *what, const char *file, int line) {
+  char buf[64];
+  snprintf(buf, sizeof buf, " (%s:%d)", strrchr(file, '/') ? strrchr(file, '/') + 1 : file, line);
+  if (g_fx_error.empty()) g_fx_error = what;
+  g_fx_error += buf;
+  return FX_ERROR_RUNTIME;
+}
+
+#define NCCL_TRY(expr)                                                       \
+  do {                                                                       \
+    ncclResult_t _e = (expr);                                                \
+    if (_e != ncclSuccess) {                                                 \
+      g_fx_error = std::string(#expr) + ": " + ncclGetErrorString(_e);       \
+      return fx_fail(g_fx_error.c_str(), __FILE__, __LINE__);                \
+    }                                                                        \
+  } while (0)
+
+static double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static int nthreads_host() {
+  const char *e = getenv("FX_HOST_THREADS");
+  int n = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+  return std::max(1, std::min(n, 32));
+}
+
+template <class F>
+static void parallel_for(int64_t n, F f) {
+  const int nt = (int)std::min<int64_t>(nthreads_host(), std::max<int64_t>(1, n / 4096));
+  if (nt <= 1) { f(0, n); return; }
+  std::vector<std::thread> th;
+  for (int t = 0; t < nt; t++) {
+    const int64_t a = n * t / nt, b = n * (t + 1) / nt;
+    th.emplace_back([=] { f(a, b); });
+  }
+  for (auto &t : th) t.join();
+}
+
+template <class T>
+static int dev_alloc(T **p, size_t count) {
+  *p = nullptr;
+  if (count == 0) count = 1;
+  HIP_TRY(hipMalloc((void **)p, count * sizeof(T)));
+  return 0;
+}
+template <class T>
+static void dev_free(T *&p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+
+static inline int grid_for(int64_t n, int per_block = FX_BLOCK, int cap = 256 * 16) {
+  int64_t g = (n + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  return (int)std::min<int64_t>(g, cap);
+}
+
+// ---------------------------------------------------------------------------
+// life cycle
+// ---------------------------------------------------------------------------
+extern "C" const char *fx_last_error(void) { return g_fx_error.c_str(); }
+extern "C" const char *fx_version(void) { return "fistr_hip 0.1 (gfx950)"; }
+
+extern "C" int fx_create(int device, fx_context **out) {
+  *out = nullptr;
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) { g_fx_error = "no HIP device: libfistr_hip has no CPU path"; return FX_ERROR_RUNTIME; }
+  if (device < 0) {
+    const char *lr = getenv("LOCAL_RANK");
+    device = lr ? atoi(lr) % ndev : 0;
+  }
+  HIP_TRY(hipSetDevice(device));
+  fx_context *c = new fx_context();
+  c->device = device;
+  HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreate(&c->ev0));
+  HIP_TRY(hipEventCreate(&c->ev1));
+  if (dev_alloc(&c->st, 1)) return FX_ERROR_RUNTIME;
+  HIP_TRY(hipHostMalloc((void **)&c->st_host, sizeof(KrylovState) * 4, hipHostMallocDefault));
+  if (dev_alloc(&c->red_out, 16)) return FX_ERROR_RUNTIME;
+  *out = c;
+  return 0;
+}
+
+static void bell_free(Bell &b) {
+  dev_free(b.pair_ptr); dev_free(b.val2); dev_free(b.col2); dev_free(b.slot_row); dev_free(b.src2);
+  b = Bell();
+}
+
+static void free_matrix(fx_context *c) {
+  DevCSR &A = c->A;
+  dev_free(A.indexL); dev_free(A.itemL); dev_free(A.indexU); dev_free(A.itemU);
+  dev_free(A.D); dev_free(A.AL); dev_free(A.AU); dev_free(A.B); dev_free(A.X);
+  A = DevCSR();
+  bell_free(c->M);
+  for (auto &w : c->W) dev_free(w);
+  dev_free(c->partials);
+  c->wlen = 0;
+  c->max_partials = 0;
+  c->have_profile = c->have_values = c->bell_valid = false;
+}
+
+static void free_precond(fx_context *c) {
+  dev_free(c->diag.alu);
+  bell_free(c->ssor.L); bell_free(c->ssor.U);
+  dev_free(c->ssor.alu);
+  c->ssor = SsorDev();
+  c->precond_valid = false;
+  c->precond_kind = 0;
+}
+
+extern "C" void fx_destroy(fx_context *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  free_precond(c);
+  free_matrix(c);
+  dev_free(c->halo.export_item); dev_free(c->halo.import_item);
+  dev_free(c->halo.sendbuf); dev_free(c->halo.recvbuf);
+  dev_free(c->st); dev_free(c->red_out); dev_free(c->hist);
+  if (c->st_host) (void)hipHostFree(c->st_host);
+  if (c->nccl) ncclCommDestroy((ncclComm_t)c->nccl);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" int fx_device_synchronize(fx_context *c) {
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// BELL construction on the host (profile only; values are gathered on the device)
+// entries(slot, out): ordered list of (src code, 0-based column) of that slot's row.
+// ---------------------------------------------------------------------------
+struct BellEntry { int32_t src, col; };
+
+template <class CountFn, class FillFn>
+static int bell_build2(fx_context *c, Bell &b, int32_t nslots, const std::vector<int32_t> *slot_row,
+                       CountFn count, FillFn fill) {
+  bell_free(b);
+  b.nslots = nslots;
+  b.nslices = (nslots + 63) / 64;
+  std::vector<int32_t> pair_ptr((size_t)b.nslices + 1, 0);
+  std::vector<int64_t> blocks_per_slice((size_t)b.nslices, 0);
+  parallel_for(b.nslices, [&](int64_t s0, int64_t s1) {
+    for (int64_t s = s0; s < s1; s++) {
+      int32_t w = 0;
+      int64_t nb = 0;
+      for (int l = 0; l < 64; l++) {
+        const int64_t slot = s * 64 + l;
+        if (slot >= nslots) break;
+        const int32_t k = count((int32_t)slot);
+        w = std::max(w, k);
+        nb += k;
+      }
+      pair_ptr[s + 1] = (w + 1) / 2;
+      blocks_per_slice[s] = nb;
+    }
+  });
+  int64_t tot = 0;
+  b.nblocks = 0;
+  for (int32_t s = 0; s < b.nslices; s++) {
+    tot += pair_ptr[s + 1];
+    if (tot > INT32_MAX) { g_fx_error = "BELL: pair count overflows int32"; return FX_ERROR_RUNTIME; }
+    pair_ptr[s + 1] = (int32_t)tot;
+    b.nblocks += blocks_per_slice[s];
+  }
+  b.npairs = tot;
+  std::vector<int2> col2((size_t)tot * 64), src2((size_t)tot * 64);
+  parallel_for(b.nslices, [&](int64_t s0, int64_t s1) {
+    std::vector<BellEntry> ent;
+    for (int64_t s = s0; s < s1; s++) {
+      const int32_t p0 = pair_ptr[s], p1 = pair_ptr[s + 1];
+      for (int l = 0; l < 64; l++) {
+        const int64_t slot = s * 64 + l;
+        ent.clear();
+        int32_t self = 0;
+        if (slot < nslots) {
+          self = slot_row ? (*slot_row)[slot] : (int32_t)slot;
+          if (self >= 0) fill((int32_t)slot, ent);
+          else self = 0;
+        }
+        for (int32_t p = p0; p < p1; p++) {
+          const size_t k = (size_t)(p - p0) * 2;
+          int2 cc, ss;
+          cc.x = k < ent.size() ? ent[k].col : self;
+          ss.x = k < ent.size() ? ent[k].src : -1;
+          cc.y = k + 1 < ent.size() ? ent[k + 1].col : self;
+          ss.y = k + 1 < ent.size() ? ent[k + 1].src : -1;
+          col2[(size_t)p * 64 + l] = cc;
+          src2[(size_t)p * 64 + l] = ss;
+        }
+      }
+    }
+  });
+  if (dev_alloc(&b.pair_ptr, (size_t)b.nslices + 1)) return FX_ERROR_RUNTIME;
+  if (dev_alloc(&b.col2, (size_t)tot * 64)) return FX_ERROR_RUNTIME;
+  if (dev_alloc(&b.src2, (size_t)tot * 64)) return FX_ERROR_RUNTIME;
+  if (dev_alloc(&b.val2, (size_t)tot * 576)) return FX_ERROR_RUNTIME;
+  HIP_TRY(hipMemcpyAsync(b.pair_ptr, pair_ptr.data(), pair_ptr.size() * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(b.col2, col2.data(), col2.size() * sizeof(int2), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(b.src2, src2.data(), src2.size() * sizeof(int2), hipMemcpyHostToDevice, c->stream));
+  if (slot_row) {
+    if (dev_alloc(&b.slot_row, (size_t)b.nslices * 64)) return FX_ERROR_RUNTIME;
+    std::vector<int32_t> sr((size_t)b.nslices * 64, -1);
+    std::copy(slot_row->begin(), slot_row->end(), sr.begin());
+    HIP_TRY(hipMemcpyAsync(b.slot_row, sr.data(), sr.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));  // host staging vectors die here
+  return 0;
+}
+
+static int bell_fill_values(fx_context *c, Bell &b) {
+  if (b.nslices == 0) return 0;
+  hipLaunchKernelGGL(k_bell_fill, dim3((b.nslices + 3) / 4), dim3(FX_BLOCK), 0, c->stream, b.nslices, b.pair_ptr,
+                     b.src2, c->A.D, c->A.AL, c->A.AU, b.val2);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// full matrix M = [D | AL | AU] per row, in the reference's summation order
+static int build_full_bell(fx_context *c) {
+  const int32_t N = c->A.N;
+  const int32_t *iL = c->h_indexL.data(), *jL = c->h_itemL.data(), *iU = c->h_indexU.data(), *jU = c->h_itemU.data();
+  auto count = [=](int32_t row) { return 1 + (iL[row + 1] - iL[row]) + (iU[row + 1] - iU[row]); };
+  auto fill = [=](int32_t row, std::vector<BellEntry> &e) {
+    e.push_back({3 * row + 0, row});
+    for (int32_t j = iL[row]; j < iL[row + 1]; j++) e.push_back({3 * j + 1, jL[j] - 1});
+    for (int32_t j = iU[row]; j < iU[row + 1]; j++) e.push_back({3 * j + 2, jU[j] - 1});
+  };
+  if ((int64_t)3 * std::max(c->A.NPL, c->A.NPU) + 2 > INT32_MAX) {
+    g_fx_error = "matrix too large for int32 block codes";
+    return FX_ERROR_UNSUPPORTED;
+  }
+  return bell_build2(c, c->M, N, nullptr, count, fill);
+}
+
+// ---------------------------------------------------------------------------
+// upload
+// ---------------------------------------------------------------------------
+static int ensure_work(fx_context *c) {
+  const int32_t len = 3 * c->A.NP;
+  if (c->wlen != len) {
+    for (auto &w : c->W) dev_free(w);
+    for (auto &w : c->W) {
+      if (dev_alloc(&w, (size_t)len)) return FX_ERROR_RUNTIME;
+      HIP_TRY(hipMemsetAsync(w, 0, (size_t)len * 8, c->stream));
+    }
+    c->wlen = len;
+  }
+  const int32_t need = std::max((c->A.N + FX_BLOCK - 1) / FX_BLOCK + 8, 4096 + 8);
+  if (c->max_partials < need) {
+    dev_free(c->partials);
+    if (dev_alloc(&c->partials, (size_t)need * 3)) return FX_ERROR_RUNTIME;
+    c->max_partials = need;
+  }
+  return 0;
+}
+
+static int setup_halo(fx_context *c, const fx_comm_view *cm) {
+  HaloDev &h = c->halo;
+  dev_free(h.export_item); dev_free(h.import_item); dev_free(h.sendbuf); dev_free(h.recvbuf);
+  h = HaloDev();
+  c->nn_internal = c->A.N;
+  if (!cm) return 0;
+  c->nn_internal = cm->nn_internal > 0 ? cm->nn_internal : c->A.N;
+  h.n_neighbor = cm->n_neighbor_pe;
+  if (h.n_neighbor <= 0) return 0;
+  h.neighbor.assign(cm->neighbor_pe, cm->neighbor_pe + h.n_neighbor);
+  h.import_index.assign(cm->import_index, cm->import_index + h.n_neighbor + 1);
+  h.export_index.assign(cm->export_index, cm->export_index + h.n_neighbor + 1);
+  h.n_import = h.import_index.back();
+  h.n_export = h.export_index.back();
+  std::vector<int32_t> ei(cm->export_item, cm->export_item + h.n_export), ii(cm->import_item, cm->import_item + h.n_import);
+  for (auto &v : ei) v -= 1;
+  for (auto &v : ii) v -= 1;
+  if (dev_alloc(&h.export_item, ei.size()) || dev_alloc(&h.import_item, ii.size())) return FX_ERROR_RUNTIME;
+  if (dev_alloc(&h.sendbuf, (size_t)3 * h.n_export) || dev_alloc(&h.recvbuf, (size_t)3 * h.n_import)) return FX_ERROR_RUNTIME;
+  HIP_TRY(hipMemcpy(h.export_item, ei.data(), ei.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h.import_item, ii.data(), ii.size() * 4, hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int fx_upload(fx_context *c, const fx_matrix_view *m, const fx_comm_view *cm, int what) {
+  HIP_TRY(hipSetDevice(c->device));
+  if (m->NDOF != 3) { g_fx_error = "only NDOF=3 (3x3 blocks) is on the hot path"; return FX_ERROR_UNSUPPORTED; }
+  DevCSR &A = c->A;
+  const bool shape_changed = (A.N != m->N || A.NP != m->NP || A.NPL != m->NPL || A.NPU != m->NPU);
+  if (shape_changed || !c->have_profile) what |= FX_UP_PROFILE;
+  if (what & FX_UP_PROFILE) {
+    free_precond(c);
+    free_matrix(c);
+    A.N = m->N; A.NP = m->NP; A.NPL = m->NPL; A.NPU = m->NPU;
+    if (dev_alloc(&A.indexL, (size_t)A.NP + 1) || dev_alloc(&A.indexU, (size_t)A.NP + 1) ||
+        dev_alloc(&A.itemL, (size_t)A.NPL) || dev_alloc(&A.itemU, (size_t)A.NPU) ||
+        dev_alloc(&A.D, (size_t)9 * A.NP) || dev_alloc(&A.AL, (size_t)9 * A.NPL) ||
+        dev_alloc(&A.AU, (size_t)9 * A.NPU) || dev_alloc(&A.B, (size_t)3 * A.NP) || dev_alloc(&A.X, (size_t)3 * A.NP))
+      return FX_ERROR_RUNTIME;
+    HIP_TRY(hipMemcpyAsync(A.indexL, m->indexL, ((size_t)A.NP + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(A.indexU, m->indexU, ((size_t)A.NP + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(A.itemL, m->itemL, (size_t)A.NPL * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(A.itemU, m->itemU, (size_t)A.NPU * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(A.B, 0, (size_t)3 * A.NP * 8, c->stream));
+    HIP_TRY(hipMemsetAsync(A.X, 0, (size_t)3 * A.NP * 8, c->stream));
+    c->h_indexL.assign(m->indexL, m->indexL + A.NP + 1);
+    c->h_indexU.assign(m->indexU, m->indexU + A.NP + 1);
+    c->h_itemL.assign(m->itemL, m->itemL + A.NPL);
+    c->h_itemU.assign(m->itemU, m->itemU + A.NPU);
+    if (setup_halo(c, cm)) return FX_ERROR_RUNTIME;
+    if (ensure_work(c)) return FX_ERROR_RUNTIME;
+    if (build_full_bell(c)) return FX_ERROR_RUNTIME;
+    c->have_profile = true;
+    what |= FX_UP_VALUES;
+    if (!m->D) what &= ~FX_UP_VALUES;  // profile-only upload (device assembly follows)
+  }
+  if ((what & FX_UP_VALUES) && m->D) {
+    HIP_TRY(hipMemcpyAsync(A.D, m->D, (size_t)9 * A.NP * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(A.AL, m->AL, (size_t)9 * A.NPL * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(A.AU, m->AU, (size_t)9 * A.NPU * 8, hipMemcpyHostToDevice, c->stream));
+    if (bell_fill_values(c, c->M)) return FX_ERROR_RUNTIME;
+    c->have_values = true;
+    c->bell_valid = true;
+    c->precond_valid = false;
+  }
+  if ((what & FX_UP_RHS) && m->B)
+    HIP_TRY(hipMemcpyAsync(A.B, m->B, (size_t)3 * A.NP * 8, hipMemcpyHostToDevice, c->stream));
+  if ((what & FX_UP_X) && m->X)
+    HIP_TRY(hipMemcpyAsync(A.X, m->X, (size_t)3 * A.NP * 8, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int fx_download_x(fx_context *c, double *X, int32_t n) {
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpyAsync(X, c->A.X, (size_t)std::min(n, 3 * c->A.NP) * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int fx_download_matrix(fx_context *c, double *D, double *AL, double *AU, double *B) {
+  HIP_TRY(hipSetDevice(c->device));
+  if (D) HIP_TRY(hipMemcpyAsync(D, c->A.D, (size_t)9 * c->A.NP * 8, hipMemcpyDeviceToHost, c->stream));
+  if (AL) HIP_TRY(hipMemcpyAsync(AL, c->A.AL, (size_t)9 * c->A.NPL * 8, hipMemcpyDeviceToHost, c->stream));
+  if (AU) HIP_TRY(hipMemcpyAsync(AU, c->A.AU, (size_t)9 * c->A.NPU * 8, hipMemcpyDeviceToHost, c->stream));
+  if (B) HIP_TRY(hipMemcpyAsync(B, c->A.B, (size_t)3 * c->A.NP * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// communication: halo exchange (C1) and scalar all-reduce (C2) over RCCL
+// ---------------------------------------------------------------------------
+extern "C" int fx_comm_unique_id(unsigned char id[128]) {
+  ncclUniqueId u;
+  NCCL_TRY(ncclGetUniqueId(&u));
+  static_assert(sizeof(ncclUniqueId) <= 128, "ncclUniqueId larger than the ABI slot");
+  memset(id, 0, 128);
+  memcpy(id, &u, sizeof u);
+  return 0;
+}
+
+extern "C" int fx_comm_init(fx_context *c, const unsigned char id[128], int rank, int nranks) {
+  HIP_TRY(hipSetDevice(c->device));
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof u);
+  ncclComm_t comm;
+  NCCL_TRY(ncclCommInitRank(&comm, nranks, u, rank));
+  c->nccl = comm;
+  c->rank = rank;
+  c->nranks = nranks;
+  return 0;
+}
+
+// hecmw_update_3_R (hecmw_comm_f.F90:669-694): persistent device buffers, one grouped
+// send/recv per neighbour, all on the solver stream (no host synchronisation).
+static int halo_update(fx_context *c, double *x) {
+  HaloDev &h = c->halo;
+  if (h.n_neighbor <= 0 || c->nranks <= 1) return 0;
+  if (!c->nccl) { g_fx_error = "halo exchange requested but fx_comm_init was not called"; return FX_ERROR_RUNTIME; }
+  if (h.n_export > 0)
+    hipLaunchKernelGGL(k_halo_pack, dim3((h.n_export + 255) / 256), dim3(256), 0, c->stream, h.n_export, h.export_item, x,
+                       h.sendbuf);
+  NCCL_TRY(ncclGroupStart());
+  for (int k = 0; k < h.n_neighbor; k++) {
+    const int32_t ns = h.export_index[k + 1] - h.export_index[k], nr = h.import_index[k + 1] - h.import_index[k];
+    if (ns > 0)
+      NCCL_TRY(ncclSend(h.sendbuf + (size_t)3 * h.export_index[k], (size_t)3 * ns, ncclDouble, h.neighbor[k], (ncclComm_t)c->nccl,
+                        c->stream));
+    if (nr > 0)
+      NCCL_TRY(ncclRecv(h.recvbuf + (size_t)3 * h.import_index[k], (size_t)3 * nr, ncclDouble, h.neighbor[k], (ncclComm_t)c->nccl,
+                        c->stream));
+  }
+  NCCL_TRY(ncclGroupEnd());
+  if (h.n_import > 0)
+    hipLaunchKernelGGL(k_halo_unpack, dim3((h.n_import + 255) / 256), dim3(256), 0, c->stream, h.n_import, h.import_item,
+                       h.recvbuf, x);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// building blocks on the solver stream
+// ---------------------------------------------------------------------------
+static inline const int32_t *gate_status(fx_context *c) { return &c->st->status; }
+static inline const int32_t *gate_verify(fx_context *c) { return &c->st->need_verify; }
+
+// y = A x (mode 0) or y = b - A x (mode 1), optional fused dot partial (dot 1: x.y, 2: y.y)
+static int spmv(fx_context *c, int mode, int dot, double *x, const double *b, double *y, const int32_t *gate,
+                int32_t gate_val) {
+  if (halo_update(c, x)) return FX_ERROR_RUNTIME;
+  const Bell &M = c->M;
+  const dim3 g((M.nslices + 3) / 4), blk(FX_BLOCK);
+  double *part = c->partials;
+#define SPMV_LAUNCH(MODE, DOT)                                                                                   \
+  hipLaunchKernelGGL((k_spmv<MODE, DOT>), g, blk, 0, c->stream, M.nslices, c->A.N, M.pair_ptr, M.val2, M.col2, x, b, \
+                     y, part, gate, gate_val)
+  if (mode == 0 && dot == 0) SPMV_LAUNCH(0, 0);
+  else if (mode == 0 && dot == 1) SPMV_LAUNCH(0, 1);
+  else if (mode == 1 && dot == 0) SPMV_LAUNCH(1, 0);
+  else if (mode == 1 && dot == 2) SPMV_LAUNCH(1, 2);
+  else { g_fx_error = "spmv: bad mode"; return FX_ERROR_RUNTIME; }
+#undef SPMV_LAUNCH
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+static inline int spmv_nparts(fx_context *c) { return (c->M.nslices + 3) / 4; }
+
+template <int OP>
+static int scalar_stage(fx_context *c, int nparts, int stride, int recompute_every) {
+  if (c->nranks > 1 && c->nccl) {
+    hipLaunchKernelGGL((k_scalar<OP>), dim3(1), dim3(1024), 0, c->stream, c->partials, nparts, stride, c->st, c->hist,
+                       c->red_out, 1, recompute_every);
+    NCCL_TRY(ncclAllReduce(c->red_out, c->red_out, 2, ncclDouble, ncclSum, (ncclComm_t)c->nccl, c->stream));
+    hipLaunchKernelGGL((k_scalar<OP>), dim3(1), dim3(64), 0, c->stream, c->partials, nparts, stride, c->st, c->hist,
+                       c->red_out, 2, recompute_every);
+  } else {
+    hipLaunchKernelGGL((k_scalar<OP>), dim3(1), dim3(1024), 0, c->stream, c->partials, nparts, stride, c->st, c->hist,
+                       c->red_out, 0, recompute_every);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// preconditioner setup (hecmw_precond_33_setup, 33/hecmw_precond_33.f90:27-50)
+// ---------------------------------------------------------------------------
+static int diag_setup(fx_context *c, double sigma_diag) {
+  const int32_t N = c->A.N;
+  c->diag.nslices = (N + 63) / 64;
+  dev_free(c->diag.alu);
+  if (dev_alloc(&c->diag.alu, (size_t)c->diag.nslices * 576)) return FX_ERROR_RUNTIME;
+  const int nslots = c->diag.nslices * 64;
+  hipLaunchKernelGGL(k_alu_setup, dim3((nslots + 255) / 256), dim3(256), 0, c->stream, nslots, N, (const int32_t *)nullptr,
+                     c->A.D, sigma_diag, c->diag.alu);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// hecmw_precond_SSOR_33_setup (hecmw_precond_SSOR_33.f90:55-223), always on the
+// multicolour path (the reference's nthreads > 1 branch :102-111): ordering on the
+// host, values gathered on the device.  Within a colour the slots are sorted by the
+// number of lower blocks (rows of one colour are independent, so the order inside a
+// colour does not change the result) which keeps the BELL padding of L and U small.
+static int ssor_setup_symbolic(fx_context *c, int ncolor_in) {
+  const int32_t N = c->A.N;
+  SsorDev &S = c->ssor;
+  const int32_t *iL = c->h_indexL.data(), *jL = c->h_itemL.data(), *iU = c->h_indexU.data(), *jU = c->h_itemU.data();
+  fxo::Graph g = fxo::build_graph(N, iL, jL, iU, jU);
+  std::vector<int32_t> seq = fxo::rcm_sequence(g);
+  std::vector<int32_t> perm0, cidx;
+  fxo::multicolor(g, seq, ncolor_in, perm0, cidx);
+  S.ncolor = (int32_t)cidx.size() - 1;
+  S.colorindex = cidx;
+  S.perm.resize(N);
+  std::vector<int32_t> newpos((size_t)N);  // old -> new (0-based), the reference's iperm
+  for (int32_t i = 0; i < N; i++) { S.perm[i] = perm0[i] + 1; newpos[perm0[i]] = i; }
+  // number of lower blocks per old row under the new numbering
+  std::vector<int32_t> nlow((size_t)N);
+  parallel_for(N, [&](int64_t a, int64_t b) {
+    for (int64_t r = a; r < b; r++) {
+      int32_t k = 0;
+      for (int64_t e = g.ptr[r]; e < g.ptr[r + 1]; e++) k += (newpos[g.adj[e]] < newpos[r]);
+      nlow[r] = k;
+    }
+  });
+  // slot order: colour by colour (each colour starts a new slice), inside a colour by nlow
+  std::vector<int32_t> slot_row;
+  slot_row.reserve((size_t)N + 64 * S.ncolor);
+  S.color_slice.assign(1, 0);
+  for (int32_t col = 0; col < S.ncolor; col++) {
+    std::vector<int32_t> rows(perm0.begin() + cidx[col], perm0.begin() + cidx[col + 1]);
+    std::stable_sort(rows.begin(), rows.end(), [&](int32_t a, int32_t b) { return nlow[a] < nlow[b]; });
+    slot_row.insert(slot_row.end(), rows.begin(), rows.end());
+    while (slot_row.size() % 64) slot_row.push_back(-1);
+    S.color_slice.push_back((int32_t)(slot_row.size() / 64));
+  }
+  const int32_t nslots = (int32_t)slot_row.size();
+  // map old row -> (is block j of AL / AU) lists, ordered by new index as the reference does
+  auto collect = [&](int32_t slot, std::vector<BellEntry> &e, bool lower) {
+    const int32_t r = slot_row[slot];
+    const int32_t me = newpos[r];
+    const size_t first = e.size();
+    for (int32_t j = iL[r]; j < iL[r + 1]; j++) {
+      const int32_t co = jL[j] - 1;
+      if ((newpos[co] < me) == lower) e.push_back({3 * j + 1, co});
+    }
+    for (int32_t j = iU[r]; j < iU[r + 1]; j++) {
+      const int32_t co = jU[j] - 1;
+      if (co >= N) continue;  // halo columns are dropped (hecmw_matrix_reorder.f90:50)
+      if ((newpos[co] < me) == lower) e.push_back({3 * j + 2, co});
+    }
+    if (lower) std::sort(e.begin() + first, e.end(), [&](const BellEntry &a, const BellEntry &b) { return newpos[a.col] < newpos[b.col]; });
+    else std::sort(e.begin() + first, e.end(), [&](const BellEntry &a, const BellEntry &b) { return newpos[a.col] > newpos[b.col]; });
+  };
+  auto countL = [&](int32_t slot) { const int32_t r = slot_row[slot]; return r < 0 ? 0 : nlow[r]; };
+  auto countU = [&](int32_t slot) {
+    const int32_t r = slot_row[slot];
+    return r < 0 ? 0 : (int32_t)(g.ptr[r + 1] - g.ptr[r]) - nlow[r];
+  };
+  auto fillL = [&](int32_t slot, std::vector<BellEntry> &e) { collect(slot, e, true); };
+  auto fillU = [&](int32_t slot, std::vector<BellEntry> &e) { collect(slot, e, false); };
+  if (bell_build2(c, S.L, nslots, &slot_row, countL, fillL)) return FX_ERROR_RUNTIME;
+  if (bell_build2(c, S.U, nslots, &slot_row, countU, fillU)) return FX_ERROR_RUNTIME;
+  dev_free(S.alu);
+  if (dev_alloc(&S.alu, (size_t)(nslots / 64) * 576)) return FX_ERROR_RUNTIME;
+  return 0;
+}
+
+static int ssor_setup_numeric(fx_context *c, double sigma_diag) {
+  SsorDev &S = c->ssor;
+  if (bell_fill_values(c, S.L) || bell_fill_values(c, S.U)) return FX_ERROR_RUNTIME;
+  const int nslots = S.L.nslices * 64;
+  hipLaunchKernelGGL(k_alu_setup, dim3((nslots + 255) / 256), dim3(256), 0, c->stream, nslots, c->A.N, S.L.slot_row, c->A.D,
+                     sigma_diag, S.alu);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int fx_precond_setup(fx_context *c, const int32_t *Iarray, const double *Rarray) {
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->have_values) { g_fx_error = "fx_precond_setup: no matrix values resident"; return FX_ERROR_RUNTIME; }
+  const int precond = Iarray[2], iterpremax = Iarray[4], ncolor_in = Iarray[33] > 0 ? Iarray[33] : 10;
+  double sigma_diag = Rarray[1];
+  if (sigma_diag < 0.0) sigma_diag = 1.0;  // auto mode starts from 1 (hecmw_solver_Iterative.f90:68-73)
+  if (iterpremax <= 0) { free_precond(c); c->precond_valid = true; return 0; }
+  int kind;
+  switch (precond) {
+    case 1: case 2: kind = 1; break;
+    case 3: kind = 3; break;
+    default:
+      g_fx_error = "PRECOND=" + std::to_string(precond) + " is not on the GPU hot path yet (1,2 SSOR and 3 DIAG are)";
+      return FX_ERROR_INCONS_PC;
+  }
+  const bool symbolic = (kind != c->precond_kind) || (kind == 1 && (c->ssor.ncolor == 0 || c->ssor_ncolor_in != ncolor_in));
+  if (symbolic) { free_precond(c); c->precond_kind = kind; }
+  if (kind == 3) {
+    if (diag_setup(c, sigma_diag)) return FX_ERROR_RUNTIME;
+  } else {
+    if (symbolic) {
+      c->ssor_ncolor_in = ncolor_in;
+      if (ssor_setup_symbolic(c, ncolor_in)) return FX_ERROR_RUNTIME;
+    }
+    if (ssor_setup_numeric(c, sigma_diag)) return FX_ERROR_RUNTIME;
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->precond_valid = true;
+  return 0;
+}
+
+// z = M^-1 r  (hecmw_precond_apply hecmw_precond.f90:75-123 with iterPREmax = 1; the
+// ZP/Z prologue is folded into the kernels).  want_dot: leave partials of r.z.
+// Returns the number of partials written (0 if none).
+static int precond_apply(fx_context *c, const double *r, double *z, bool want_dot, int *nparts) {
+  const int32_t N = c->A.N;
+  *nparts = 0;
+  if (c->precond_kind == 3) {
+    const int g = (N + FX_BLOCK - 1) / FX_BLOCK;
+    hipLaunchKernelGGL(k_diag_apply, dim3(g), dim3(FX_BLOCK), 0, c->stream, N, c->diag.alu, r, z,
+                       want_dot ? c->partials : (double *)nullptr, gate_status(c));
+    if (want_dot) *nparts = g;
+  } else if (c->precond_kind == 1) {
+    SsorDev &S = c->ssor;
+    for (int col = 0; col < S.ncolor; col++) {
+      const int s0 = S.color_slice[col], s1 = S.color_slice[col + 1];
+      if (s1 <= s0) continue;
+      hipLaunchKernelGGL((k_ssor_color<true>), dim3((s1 - s0 + 3) / 4), dim3(FX_BLOCK), 0, c->stream, s0, s1, S.L.pair_ptr,
+                         S.L.val2, S.L.col2, S.L.slot_row, S.alu, r, z, (double *)nullptr, gate_status(c));
+    }
+    int off = 0;
+    for (int col = S.ncolor - 1; col >= 0; col--) {
+      const int s0 = S.color_slice[col], s1 = S.color_slice[col + 1];
+      if (s1 <= s0) continue;
+      const int g = (s1 - s0 + 3) / 4;
+      hipLaunchKernelGGL((k_ssor_color<false>), dim3(g), dim3(FX_BLOCK), 0, c->stream, s0, s1, S.U.pair_ptr, S.U.val2,
+                         S.U.col2, S.U.slot_row, S.alu, r, z, want_dot ? c->partials + off : (double *)nullptr,
+                         gate_status(c));
+      if (want_dot) off += g;
+    }
+    *nparts = off;
+  } else {  // iterPREmax <= 0: Z = R (hecmw_precond.f90:89-94)
+    hipLaunchKernelGGL(k_copy, dim3(grid_for(3 * (int64_t)N)), dim3(256), 0, c->stream, (int64_t)3 * N, r, z);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+static int dot_into_partials(fx_context *c, const double *x, const double *y, const int32_t *gate, int32_t gate_val,
+                             int *nparts) {
+  const int64_t n = (int64_t)3 * c->nn_internal;
+  const int g = grid_for(n, FX_BLOCK, 2048);
+  hipLaunchKernelGGL(k_dot, dim3(g), dim3(FX_BLOCK), 0, c->stream, n, x, y, c->partials, gate, gate_val);
+  HIP_TRY(hipGetLastError());
+  *nparts = g;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Krylov drivers.  Device-resident state machine; the host enqueues whole
+// iterations and only polls the status word every `chunk` iterations.
+// ---------------------------------------------------------------------------
+static int krylov_init_state(fx_context *c, int maxit, double tol) {
+  KrylovState s;
+  memset(&s, 0, sizeof s);
+  s.iter = 1;
+  s.maxit = maxit;
+  s.tol = tol;
+  HIP_TRY(hipMemcpyAsync(c->st, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
+  if (c->hist_cap < maxit + 1) {
+    dev_free(c->hist);
+    if (dev_alloc(&c->hist, (size_t)maxit + 1)) return FX_ERROR_RUNTIME;
+    c->hist_cap = maxit + 1;
+  }
+  return 0;
+}
+
+static int poll_state(fx_context *c, KrylovState *out) {
+  HIP_TRY(hipMemcpyAsync(c->st_host, c->st, sizeof(KrylovState), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  *out = *c->st_host;
+  return 0;
+}
+
+// hecmw_solve_CG, hecmw_solver_CG.f90:19-312
+static int run_cg(fx_context *c, int maxit, double tol, KrylovState *fin) {
+  const int64_t n3 = (int64_t)3 * c->nn_internal;
+  double *R = c->W[0], *Z = c->W[1], *Q = c->W[1], *P = c->W[2];
+  double *X = c->A.X, *B = c->A.B;
+  const int RECOMPUTE = 50;
+  int np;
+  if (krylov_init_state(c, maxit, tol)) return FX_ERROR_RUNTIME;
+  HIP_TRY(hipMemsetAsync(P, 0, (size_t)c->wlen * 8, c->stream));
+  // r0 = b - A x0 (:120) ; ||b||^2 (:123-129)
+  if (spmv(c, 1, 0, X, B, R, nullptr, 0)) return FX_ERROR_RUNTIME;
+  if (dot_into_partials(c, B, B, nullptr, 0, &np)) return FX_ERROR_RUNTIME;
+  if (scalar_stage<OP_BNRM2>(c, np, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
+  const int vgrid = grid_for(n3, FX_BLOCK, 2048);
+  const int chunk = 16;
+  KrylovState s;
+  for (int it = 1; it <= maxit; it++) {
+    // z = M^-1 r (:160) with the partial of rho = r.z (:168) fused in
+    if (precond_apply(c, R, Z, true, &np)) return FX_ERROR_RUNTIME;
+    if (np == 0 && dot_into_partials(c, R, Z, gate_status(c), 0, &np)) return FX_ERROR_RUNTIME;
+    if (scalar_stage<OP_CG_RHO>(c, np, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
+    // p = z + beta p (:188-197)
+    hipLaunchKernelGGL(k_cg_update_p, dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, n3, c->st, Z, P);
+    // q = A p (:204) + partial of p.q (:211)
+    if (spmv(c, 0, 1, P, nullptr, Q, gate_status(c), 0)) return FX_ERROR_RUNTIME;
+    if (scalar_stage<OP_CG_C1>(c, spmv_nparts(c), 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
+    // x += alpha p ; r -= alpha q | r = b - A x every 50 iterations (:227-238) ; ||r||^2 (:240)
+    if (it % RECOMPUTE == 0) {
+      hipLaunchKernelGGL((k_cg_update_xr<false>), dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, n3, c->st, P, Q, X, R, c->partials);
+      if (spmv(c, 1, 2, X, B, R, gate_status(c), 0)) return FX_ERROR_RUNTIME;
+      np = spmv_nparts(c);
+    } else {
+      hipLaunchKernelGGL((k_cg_update_xr<true>), dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, n3, c->st, P, Q, X, R, c->partials);
+      np = vgrid;
+    }
+    if (scalar_stage<OP_RESID>(c, np, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
+    // converged by the recurrence: recompute the true residual and re-test (:259-266)
+    if (it % RECOMPUTE != 0) {
+      if (spmv(c, 1, 2, X, B, R, gate_verify(c), 1)) return FX_ERROR_RUNTIME;
+      if (scalar_stage<OP_VERIFY>(c, spmv_nparts(c), 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
+    }
+    HIP_TRY(hipGetLastError());
+    if (it % chunk == 0 || it == maxit) {
+      if (poll_state(c, &s)) return FX_ERROR_RUNTIME;
+      if (s.status != 0) break;
+    }
+  }
+  if (poll_state(c, &s)) return FX_ERROR_RUNTIME;
+  *fin = s;
+  return 0;
+}
+
+// hecmw_solve_BiCGSTAB, hecmw_solver_BiCGSTAB.f90:16-297
+static int run_bicgstab(fx_context *c, int maxit, double tol, KrylovState *fin) {
+  const int64_t n3 = (int64_t)3 * c->nn_internal;
+  // R=1 RT=2 P=3 PT=4 S=5 ST=1 T=6 V=7 (:45-53); ST aliases R as in the reference
+  double *R = c->W[0], *RT = c->W[1], *P = c->W[2], *PT = c->W[3], *S = c->W[4], *ST = c->W[0], *T = c->W[5], *V = c->W[6];
+  double *X = c->A.X, *B = c->A.B;
+  const int RECOMPUTE = 100;
+  int np;
+  if (krylov_init_state(c, maxit, tol)) return FX_ERROR_RUNTIME;
+  HIP_TRY(hipMemsetAsync(P, 0, (size_t)c->wlen * 8, c->stream));
+  HIP_TRY(hipMemsetAsync(V, 0, (size_t)c->wlen * 8, c->stream));
+  if (spmv(c, 1, 0, X, B, R, nullptr, 0)) return FX_ERROR_RUNTIME;
+  const int vgrid = grid_for(n3, FX_BLOCK, 2048);
+  hipLaunchKernelGGL(k_copy, dim3(vgrid), dim3(256), 0, c->stream, n3, R, RT);
+  if (dot_into_partials(c, B, B, nullptr, 0, &np)) return FX_ERROR_RUNTIME;
+  if (scalar_stage<OP_BNRM2>(c, np, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
+  const int chunk = 8;
+  KrylovState s;
+  for (int it = 1; it <= maxit; it++) {
+    if (dot_into_partials(c, R, RT, gate_status(c), 0, &np)) return FX_ERROR_RUNTIME;           // :152
+    if (scalar_stage<OP_BI_RHO>(c, np, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
+    hipLaunchKernelGGL(k_bi_update_p, dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, n3, c->st, R, V, P);  // :160-170
+    if (precond_apply(c, P, PT, false, &np)) return FX_ERROR_RUNTIME;                            // :177
+    if (spmv(c, 0, 0, PT, nullptr, V, gate_status(c), 0)) return FX_ERROR_RUNTIME;               // :184
+    if (dot_into_partials(c, RT, V, gate_status(c), 0, &np)) return FX_ERROR_RUNTIME;            // :188
+    if (scalar_stage<OP_BI_C2>(c, np, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
+    hipLaunchKernelGGL(k_bi_update_s, dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, n3, c->st, R, V, S);  // :194-196
+    if (precond_apply(c, S, ST, false, &np)) return FX_ERROR_RUNTIME;                            // :203
+    if (spmv(c, 0, 0, ST, nullptr, T, gate_status(c), 0)) return FX_ERROR_RUNTIME;               // :210
+    hipLaunchKernelGGL(k_dot2, dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, n3, T, S, c->partials, c->max_partials,
+                       gate_status(c));                                                          // :217-218
+    if (scalar_stage<OP_BI_OMEGA>(c, vgrid, c->max_partials, RECOMPUTE)) return FX_ERROR_RUNTIME;
+    if (it % RECOMPUTE == 0) {                                                                   // :231-241
+      hipLaunchKernelGGL((k_bi_update_xr<false>), dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, n3, c->st, PT, ST, S, T, X, R,
+                         c->partials);
+      if (spmv(c, 1, 2, X, B, R, gate_status(c), 0)) return FX_ERROR_RUNTIME;
+      np = spmv_nparts(c);
+    } else {
+      hipLaunchKernelGGL((k_bi_update_xr<true>), dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, n3, c->st, PT, ST, S, T, X, R,
+                         c->partials);
+      np = vgrid;
+    }
+    if (scalar_stage<OP_RESID>(c, np, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
+    if (it % RECOMPUTE != 0) {
+      if (spmv(c, 1, 2, X, B, R, gate_verify(c), 1)) return FX_ERROR_RUNTIME;
+      if (scalar_stage<OP_VERIFY>(c, spmv_nparts(c), 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
+    }
+    HIP_TRY(hipGetLastError());
+    if (it % chunk == 0 || it == maxit) {
+      if (poll_state(c, &s)) return FX_ERROR_RUNTIME;
+      if (s.status != 0) break;
+    }
+  }
+  if (poll_state(c, &s)) return FX_ERROR_RUNTIME;
+  *fin = s;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// hecmw_solve_iterative on the resident system (hecmw_solver_Iterative.f90:13-210)
+// ---------------------------------------------------------------------------
+static int host_sum(fx_context *c, int nparts, int stride, double *v0, double *v1) {
+  hipLaunchKernelGGL((k_scalar<OP_PLAIN>), dim3(1), dim3(1024), 0, c->stream, c->partials, nparts, stride, c->st,
+                     (double *)nullptr, c->red_out, 1, 1);
+  if (c->nranks > 1 && c->nccl)
+    NCCL_TRY(ncclAllReduce(c->red_out, c->red_out, 2, ncclDouble, ncclSum, (ncclComm_t)c->nccl, c->stream));
+  double h[2];
+  HIP_TRY(hipMemcpyAsync(h, c->red_out, 16, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  *v0 = h[0];
+  if (v1) *v1 = h[1];
+  return 0;
+}
+
+extern "C" int fx_solve_resident(fx_context *c, int32_t *Iarray, double *Rarray, fx_solve_info *info, double *hist,
+                                 int32_t hist_len) {
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->have_values) { g_fx_error = "fx_solve_resident: no matrix resident"; return FX_ERROR_RUNTIME; }
+  const int maxit = Iarray[0], precond = Iarray[2], method2 = Iarray[7], iterpremax = Iarray[4];
+  int method = Iarray[1];
+  const double tol = Rarray[0];
+  if (iterpremax > 1) { g_fx_error = "iterPREmax > 1 (additive Schwarz sweeps) is not on the GPU hot path yet"; return FX_ERROR_UNSUPPORTED; }
+  int ret = 0, np;
+  double t0 = now_s();
+  // hecmw_solve_check_zerorhs (:242-278): warning 2002, X = 0, the solve continues
+  double rhs2 = 0.0, tmp;
+  if (dot_into_partials(c, c->A.B, c->A.B, nullptr, 0, &np)) return FX_ERROR_RUNTIME;
+  if (host_sum(c, np, 0, &rhs2, &tmp)) return FX_ERROR_RUNTIME;
+  if (rhs2 == 0.0) {
+    ret = FX_ERROR_ZERO_RHS;
+    HIP_TRY(hipMemsetAsync(c->A.X, 0, (size_t)3 * c->A.NP * 8, c->stream));
+  }
+  // hecmw_solve_check_zerodiag (:212-240)
+  {
+    int32_t *flag = (int32_t *)(c->red_out + 8);
+    HIP_TRY(hipMemsetAsync(flag, 0, 4, c->stream));
+    hipLaunchKernelGGL(k_check_zero_diag, dim3(grid_for(c->A.N)), dim3(256), 0, c->stream, c->A.N, c->A.D, flag);
+    int32_t hflag = 0;
+    HIP_TRY(hipMemcpyAsync(&hflag, flag, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->nranks > 1 && c->nccl) {
+      NCCL_TRY(ncclAllReduce(flag, flag, 1, ncclInt32, ncclMax, (ncclComm_t)c->nccl, c->stream));
+      HIP_TRY(hipMemcpyAsync(&hflag, flag, 4, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    if (hflag && precond < 10 && iterpremax > 0) return FX_ERROR_ZERO_DIAG;
+  }
+  // hecmw_mat_recycle_precond_setting (hecmw_matrix_misc.f90:678-697)
+  if (Iarray[97] >= 1) { Iarray[96] = 1; Iarray[95] = 0; }
+  else if (Iarray[96] > 1) { Iarray[95] = 0; Iarray[96] = 1; }
+  else if (Iarray[96] == 1) {
+    if (Iarray[95] < Iarray[34]) { Iarray[96] = 0; Iarray[95]++; }
+    else Iarray[95] = 0;
+  }
+  // preconditioner: rebuild when the flags ask for it, reuse otherwise (SSOR_33.f90:71-79)
+  if (!c->precond_valid || Iarray[97] == 1 || Iarray[96] == 1) {
+    int e = fx_precond_setup(c, Iarray, Rarray);
+    if (e) return e;
+  }
+  Iarray[97] = 0; Iarray[96] = 0;
+  const double t_setup = now_s() - t0;
+  KrylovState s;
+  memset(&s, 0, sizeof s);
+  double t1 = now_s();
+  for (;;) {
+    Iarray[80] = 0; Iarray[81] = 0;
+    int e;
+    if (method == 1) e = run_cg(c, maxit, tol, &s);
+    else if (method == 2) e = run_bicgstab(c, maxit, tol, &s);
+    else { g_fx_error = "METHOD must be 1 (CG) or 2 (BiCGSTAB) on the GPU hot path"; return FX_ERROR_INCONS_PC; }
+    if (e) return e;
+    if (s.status == FX_ERROR_DIVERGE_PC || s.status == FX_ERROR_DIVERGE_MAT) {  // :145-156
+      Iarray[81] = 1;
+      if (method == 1 && method2 > 1) { method = method2; continue; }
+    }
+    break;
+  }
+  // X halo (hecmw_update_m_R, hecmw_solver_CG.f90:280)
+  if (halo_update(c, c->A.X)) return FX_ERROR_RUNTIME;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const double t_sol = now_s() - t1;
+  if (s.status > 1) ret = s.status;
+  // final true residual (hecmw_rel_resid_L2, hecmw_solver_las.f90:129-158) -> Iarray(81)
+  double r2 = 0.0, b2 = rhs2;
+  if (b2 == 0.0) b2 = 1.0;
+  if (spmv(c, 1, 2, c->A.X, c->A.B, c->W[7], nullptr, 0)) return FX_ERROR_RUNTIME;
+  if (host_sum(c, spmv_nparts(c), 0, &r2, &tmp)) return FX_ERROR_RUNTIME;
+  const double resid2 = sqrt(r2 / b2);
+  if (resid2 < Rarray[0]) Iarray[80] = 1;
+  if (info) {
+    memset(info, 0, sizeof *info);
+    info->iterations = s.iter;
+    info->method = method; info->precond = precond;
+    info->ncolor = (c->precond_kind == 1) ? c->ssor.ncolor : 0;
+    info->resid = s.resid;
+    info->rel_resid = resid2;
+    info->time_setup = t_setup; info->time_sol = t_sol;
+    const int nh = std::max(0, std::min({(int)hist_len, s.iter, maxit}));
+    info->n_hist = hist ? nh : 0;
+  }
+  if (hist && hist_len > 0) {
+    const int nh = std::max(0, std::min({(int)hist_len, s.iter, maxit}));
+    if (nh > 0) HIP_TRY(hipMemcpy(hist, c->hist, (size_t)nh * 8, hipMemcpyDeviceToHost));
+  }
+  return ret;
+}
+
+// hecmw_solve (hecmw_solver.f90:9): host arrays in, host X out.
+extern "C" int fx_solve(fx_context *c, const fx_matrix_view *m, const fx_comm_view *cm, int32_t *Iarray, double *Rarray,
+                        fx_solve_info *info, double *hist, int32_t hist_len) {
+  if (Iarray[98] != 1) { g_fx_error = "Iarray(99) selects a direct solver: outside the GPU hot path"; return FX_ERROR_UNSUPPORTED; }
+  int what = FX_UP_RHS | FX_UP_X;
+  if (Iarray[97] >= 1 || !c->have_profile) what |= FX_UP_PROFILE;  // symbolic: profile changed
+  if (Iarray[96] >= 1 || !c->have_values) what |= FX_UP_VALUES;    // numeric: values changed
+  int e = fx_upload(c, m, cm, what);
+  if (e) return e;
+  const int ret = fx_solve_resident(c, Iarray, Rarray, info, hist, hist_len);
+  if (ret < 0 || ret == FX_ERROR_ZERO_DIAG || ret == FX_ERROR_INCONS_PC) return ret;
+  e = fx_download_x(c, m->X, 3 * m->NP);
+  return e ? e : ret;
+}
+
+extern "C" int fx_matvec(fx_context *c, const fx_matrix_view *m, const fx_comm_view *cm, double *x, double *y,
+                         double *commtime) {
+  int what = 0;
+  if (!c->have_profile) what |= FX_UP_PROFILE;
+  if (!c->have_values) what |= FX_UP_VALUES;
+  if (what || c->A.N != m->N || c->A.NPL != m->NPL) {
+    int e = fx_upload(c, m, cm, what ? what : FX_UP_PROFILE);
+    if (e) return e;
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t len = (size_t)3 * c->A.NP * 8;
+  HIP_TRY(hipMemcpyAsync(c->W[6], x, len, hipMemcpyHostToDevice, c->stream));
+  const double t0 = now_s();
+  if (halo_update(c, c->W[6])) return FX_ERROR_RUNTIME;
+  if (commtime) { HIP_TRY(hipStreamSynchronize(c->stream)); *commtime += now_s() - t0; }
+  HIP_TRY(hipMemsetAsync(c->W[7], 0, len, c->stream));
+  {
+    const Bell &M = c->M;
+    hipLaunchKernelGGL((k_spmv<0, 0>), dim3((M.nslices + 3) / 4), dim3(FX_BLOCK), 0, c->stream, M.nslices, c->A.N, M.pair_ptr,
+                       M.val2, M.col2, c->W[6], (const double *)nullptr, c->W[7], c->partials, (const int32_t *)nullptr, 0);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipMemcpyAsync(y, c->W[7], (size_t)3 * c->A.N * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(x, c->W[6], len, hipMemcpyDeviceToHost, c->stream));  // halo part of X is updated
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// y = A x on resident work vectors, timed with HIP events on the solver stream.
+extern "C" int fx_matvec_resident(fx_context *c, int nrepeat, float *ms_per_call) {
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->bell_valid) { g_fx_error = "fx_matvec_resident: no matrix resident"; return FX_ERROR_RUNTIME; }
+  const Bell &M = c->M;
+  HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  for (int i = 0; i < nrepeat; i++)
+    hipLaunchKernelGGL((k_spmv<0, 0>), dim3((M.nslices + 3) / 4), dim3(FX_BLOCK), 0, c->stream, M.nslices, c->A.N, M.pair_ptr,
+                       M.val2, M.col2, c->A.B, (const double *)nullptr, c->W[7], c->partials, (const int32_t *)nullptr, 0);
+  HIP_TRY(hipEventRecord(c->ev1, c->stream));
+  HIP_TRY(hipEventSynchronize(c->ev1));
+  HIP_TRY(hipGetLastError());
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  if (ms_per_call) *ms_per_call = ms / std::max(nrepeat, 1);
+  return 0;
+}
+
+extern "C" int fx_precond_apply_host(fx_context *c, const double *r, double *z) {
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->precond_valid) { g_fx_error = "fx_precond_apply_host: preconditioner not set up"; return FX_ERROR_RUNTIME; }
+  const size_t len = (size_t)3 * c->A.NP * 8;
+  KrylovState s;
+  memset(&s, 0, sizeof s);
+  HIP_TRY(hipMemcpyAsync(c->st, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->W[6], r, len, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemsetAsync(c->W[7], 0, len, c->stream));
+  int np;
+  if (precond_apply(c, c->W[6], c->W[7], false, &np)) return FX_ERROR_RUNTIME;
+  HIP_TRY(hipMemcpyAsync(z, c->W[7], len, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int fx_dot_host(fx_context *c, const double *x, const double *y, double *result) {
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t len = (size_t)3 * c->A.NP * 8;
+  HIP_TRY(hipMemcpyAsync(c->W[6], x, len, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->W[7], y, len, hipMemcpyHostToDevice, c->stream));
+  int np;
+  double tmp;
+  if (dot_into_partials(c, c->W[6], c->W[7], nullptr, 0, &np)) return FX_ERROR_RUNTIME;
+  return host_sum(c, np, 0, result, &tmp);
+}
+
+#include "fx_assemble_host.h"

@@ -1,0 +1,365 @@
+// Device assembly kernels of libfistr_hip: C3D8 element stiffness (K10), scatter-add
+// into the block CRS arrays (K11) and Dirichlet elimination (K12).
+//
+// Reference: fstr_StiffMatrix.f90:58-207 (element loop), static_LIB_3dIC.f90:21-215
+// (STF_C3D8IC), static_LIB_C3D8.f90:23-200 (STF_C3D8Bbar), static_LIB_3d.f90:47-205
+// (STF_C3), hecmw_mat_ass.f90:31-134 (scatter), :292-429 (BC).
+//
+// Work decomposition: 16 lanes per element (4 elements per wave64).  Lane a owns the
+// 3-row block of "node" a of the element matrix: a = 0..7 are the corner nodes,
+// a = 8..10 the three incompatible modes of the IC element.  Each lane accumulates its
+// row block over the 2x2x2 Gauss points in registers (<= 11 blocks x 9 doubles); the
+// Jacobian is recomputed per lane (72 FMAs) rather than exchanged.  The IC element's
+// static condensation goes through LDS: rows 24..32 are published by lanes 8..10, one
+// lane inverts the 9x9 mode block (Gauss-Jordan with partial pivoting, as calInverse
+// utilities.f90:247-316), lanes 0..7 then condense their own rows.  The scatter is a
+// binary search in the row's item list + hardware fp64 atomic adds (the reference uses
+// `!$omp atomic` for the same purpose).
+#pragma once
+#include "fx_internal.h"
+
+#define FXA_BLOCK 256
+#define FXA_EPB (FXA_BLOCK / 16)  // elements per block
+
+__device__ __forceinline__ void hex8_shape_deriv(double xi, double et, double ze, double (&dN)[8][3]) {
+  // hex8n.f90:24-53
+  const double sx[8] = {-1, 1, 1, -1, -1, 1, 1, -1};
+  const double sy[8] = {-1, -1, 1, 1, -1, -1, 1, 1};
+  const double sz[8] = {-1, -1, -1, -1, 1, 1, 1, 1};
+#pragma unroll
+  for (int a = 0; a < 8; a++) {
+    const double fx = 1.0 + sx[a] * xi, fy = 1.0 + sy[a] * et, fz = 1.0 + sz[a] * ze;
+    dN[a][0] = sx[a] * 0.125 * fy * fz;
+    dN[a][1] = sy[a] * 0.125 * fx * fz;
+    dN[a][2] = sz[a] * 0.125 * fx * fy;
+  }
+}
+
+// Jacobian, determinant, inverse (element.f90:772-818) and global derivatives (:693-744)
+__device__ __forceinline__ void hex8_global_deriv(const double (&ec)[8][3], double xi, double et, double ze, double &det,
+                                                  double (&inv)[3][3], double (&gd)[11][3]) {
+  double dN[8][3];
+  hex8_shape_deriv(xi, et, ze, dN);
+  double J[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      double s = 0.0;
+#pragma unroll
+      for (int a = 0; a < 8; a++) s += ec[a][i] * dN[a][j];
+      J[i][j] = s;
+    }
+  det = J[0][0] * J[1][1] * J[2][2] + J[1][0] * J[2][1] * J[0][2] + J[2][0] * J[0][1] * J[1][2] -
+        J[2][0] * J[1][1] * J[0][2] - J[1][0] * J[0][1] * J[2][2] - J[0][0] * J[2][1] * J[1][2];
+  const double dum = 1.0 / det;
+  inv[0][0] = dum * (J[1][1] * J[2][2] - J[2][1] * J[1][2]);
+  inv[0][1] = dum * (-J[0][1] * J[2][2] + J[2][1] * J[0][2]);
+  inv[0][2] = dum * (J[0][1] * J[1][2] - J[1][1] * J[0][2]);
+  inv[1][0] = dum * (-J[1][0] * J[2][2] + J[2][0] * J[1][2]);
+  inv[1][1] = dum * (J[0][0] * J[2][2] - J[2][0] * J[0][2]);
+  inv[1][2] = dum * (-J[0][0] * J[1][2] + J[1][0] * J[0][2]);
+  inv[2][0] = dum * (J[1][0] * J[2][1] - J[2][0] * J[1][1]);
+  inv[2][1] = dum * (-J[0][0] * J[2][1] + J[2][0] * J[0][1]);
+  inv[2][2] = dum * (J[0][0] * J[1][1] - J[1][0] * J[0][1]);
+#pragma unroll
+  for (int a = 0; a < 8; a++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) gd[a][j] = dN[a][0] * inv[0][j] + dN[a][1] * inv[1][j] + dN[a][2] * inv[2][j];
+}
+
+// strain-displacement block of one node: rows xx,yy,zz,xy,yz,zx (static_LIB_3d.f90:126-136);
+// h = (Bbar - g)/3 adds the B-bar dilatational correction (static_LIB_C3D8.f90:103-126).
+__device__ __forceinline__ void node_B(const double *g, const double *h, double (&B)[6][3]) {
+  B[0][0] = g[0] + h[0]; B[0][1] = h[1];        B[0][2] = h[2];
+  B[1][0] = h[0];        B[1][1] = g[1] + h[1]; B[1][2] = h[2];
+  B[2][0] = h[0];        B[2][1] = h[1];        B[2][2] = g[2] + h[2];
+  B[3][0] = g[1]; B[3][1] = g[0]; B[3][2] = 0.0;
+  B[4][0] = 0.0;  B[4][1] = g[2]; B[4][2] = g[1];
+  B[5][0] = g[2]; B[5][1] = 0.0;  B[5][2] = g[0];
+}
+
+// 1-based binary search as hecmw_array_search_i (hecmw_mat_ass.f90:137-166); returns 0-based
+// position or -1.
+__device__ __forceinline__ int32_t item_search(const int32_t *item, int32_t lo, int32_t hi, int32_t val) {
+  while (lo < hi) {
+    const int32_t mid = (lo + hi) >> 1;
+    const int32_t v = item[mid];
+    if (v < val) lo = mid + 1;
+    else if (v > val) hi = mid;
+    else return mid;
+  }
+  return -1;
+}
+
+template <int ELEMOPT>
+__global__ __launch_bounds__(FXA_BLOCK) void k_assemble_c3d8(int32_t n_elem, const double *__restrict__ coord,
+                                                             const int32_t *__restrict__ conn, double D11, double D12,
+                                                             double D44, const int32_t *__restrict__ indexL,
+                                                             const int32_t *__restrict__ itemL,
+                                                             const int32_t *__restrict__ indexU,
+                                                             const int32_t *__restrict__ itemU, double *__restrict__ D,
+                                                             double *__restrict__ AL, double *__restrict__ AU,
+                                                             double *__restrict__ Kout, int32_t *__restrict__ err) {
+  constexpr int NJ = (ELEMOPT == 1) ? 11 : 8;
+  __shared__ double Ksh[(ELEMOPT == 1) ? FXA_EPB : 1][9][34];
+  __shared__ double Xinv[(ELEMOPT == 1) ? FXA_EPB : 1][9][10];
+  const int el = threadIdx.x >> 4, a = threadIdx.x & 15;
+  const int32_t elem = blockIdx.x * FXA_EPB + el;
+  const bool active = (elem < n_elem) && (a < NJ);
+  double K[NJ][9];
+#pragma unroll
+  for (int b = 0; b < NJ; b++)
+#pragma unroll
+    for (int e = 0; e < 9; e++) K[b][e] = 0.0;
+  int32_t nod[8];
+  if (active) {
+    double ec[8][3];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      nod[j] = conn[(size_t)8 * elem + j];
+#pragma unroll
+      for (int d = 0; d < 3; d++) ec[j][d] = coord[(size_t)3 * (nod[j] - 1) + d];
+    }
+    double det, inv[3][3], gd[11][3];
+    double inv0[3][3], det0 = 0.0, bbar[8][3];
+    if (ELEMOPT == 1) {  // Jacobian at the element centre, scaled by its determinant (3dIC.f90:79-81)
+      hex8_global_deriv(ec, 0.0, 0.0, 0.0, det0, inv0, gd);
+    } else if (ELEMOPT == 2) {  // dilatation at the centroid (C3D8.f90:72-73)
+      hex8_global_deriv(ec, 0.0, 0.0, 0.0, det, inv, gd);
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+#pragma unroll
+        for (int d = 0; d < 3; d++) bbar[j][d] = gd[j][d];
+    }
+    const double GP = 0.577350269189626;  // quadrature.f90:83-91, unit weights (:221)
+    for (int LX = 0; LX < 8; LX++) {
+      const double xi = (LX & 1) ? GP : -GP, et = (LX & 2) ? GP : -GP, ze = (LX & 4) ? GP : -GP;
+      hex8_global_deriv(ec, xi, et, ze, det, inv, gd);
+      if (ELEMOPT == 1) {  // incompatible-mode derivatives (3dIC.f90:120-122)
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          gd[8][d] = -2.0 * xi * (inv0[0][d] * det0) / det;
+          gd[9][d] = -2.0 * et * (inv0[1][d] * det0) / det;
+          gd[10][d] = -2.0 * ze * (inv0[2][d] * det0) / det;
+        }
+      }
+      const double wg = det;
+      double Ba[6][3], h[3] = {0.0, 0.0, 0.0};
+      // own row block: B_a
+      {
+        double ga[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int b = 0; b < NJ; b++)
+          if (b == a) { ga[0] = gd[b][0]; ga[1] = gd[b][1]; ga[2] = gd[b][2]; }
+        if (ELEMOPT == 2) {
+#pragma unroll
+          for (int b = 0; b < 8; b++)
+            if (b == a) { h[0] = (bbar[b][0] - ga[0]) / 3.0; h[1] = (bbar[b][1] - ga[1]) / 3.0; h[2] = (bbar[b][2] - ga[2]) / 3.0; }
+        }
+        node_B(ga, h, Ba);
+      }
+#pragma unroll
+      for (int b = 0; b < NJ; b++) {
+        double Bb[6][3], hb[3] = {0.0, 0.0, 0.0};
+        if (ELEMOPT == 2) {
+          hb[0] = (bbar[b][0] - gd[b][0]) / 3.0; hb[1] = (bbar[b][1] - gd[b][1]) / 3.0; hb[2] = (bbar[b][2] - gd[b][2]) / 3.0;
+        }
+        node_B(gd[b], hb, Bb);
+        // DB = D * B_b with the isotropic D of calElasticMatrix (ElasticLinear.f90:43-55)
+        double DB[6][3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          DB[0][j] = D11 * Bb[0][j] + D12 * Bb[1][j] + D12 * Bb[2][j];
+          DB[1][j] = D12 * Bb[0][j] + D11 * Bb[1][j] + D12 * Bb[2][j];
+          DB[2][j] = D12 * Bb[0][j] + D12 * Bb[1][j] + D11 * Bb[2][j];
+          DB[3][j] = D44 * Bb[3][j]; DB[4][j] = D44 * Bb[4][j]; DB[5][j] = D44 * Bb[5][j];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+          for (int j = 0; j < 3; j++) {
+            double s = 0.0;
+#pragma unroll
+            for (int q = 0; q < 6; q++) s += Ba[q][i] * DB[q][j];
+            K[b][3 * i + j] += s * wg;
+          }
+      }
+    }
+  }
+  if (ELEMOPT == 1) {
+    // publish rows 24..32 (lanes 8..10), invert the 9x9 mode block, condense (3dIC.f90:206-209)
+    if (active && a >= 8) {
+#pragma unroll
+      for (int b = 0; b < 11; b++)
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+          for (int j = 0; j < 3; j++) Ksh[el][3 * (a - 8) + i][3 * b + j] = K[b][3 * i + j];
+    }
+    __syncthreads();
+    if (active && a == 0) {
+      double (*X)[10] = Xinv[el];
+      for (int i = 0; i < 9; i++)
+        for (int j = 0; j < 9; j++) X[i][j] = Ksh[el][i][24 + j];
+      int ip[9];
+      for (int i = 0; i < 9; i++) ip[i] = i;
+      for (int k = 0; k < 9; k++) {
+        double wmax = 0.0;
+        int lr = k;
+        for (int i = k; i < 9; i++) {
+          const double w = fabs(X[i][k]);
+          if (w > wmax) { wmax = w; lr = i; }
+        }
+        const double pivot = X[lr][k];
+        if (fabs(pivot) <= 1.0e-35) { if (err) atomicExch(err, 1); }
+        if (lr != k) {
+          const int iw = ip[k]; ip[k] = ip[lr]; ip[lr] = iw;
+          for (int j = 0; j < 9; j++) { const double w = X[k][j]; X[k][j] = X[lr][j]; X[lr][j] = w; }
+        }
+        for (int i = 0; i < 9; i++) X[k][i] = X[k][i] / pivot;
+        for (int i = 0; i < 9; i++) {
+          if (i != k) {
+            const double w = X[i][k];
+            if (w != 0.0) {
+              for (int j = 0; j < 9; j++)
+                if (j != k) X[i][j] = X[i][j] - w * X[k][j];
+              X[i][k] = -w / pivot;
+            }
+          }
+        }
+        X[k][k] = 1.0 / pivot;
+      }
+      for (int i = 0; i < 9; i++) {
+        const int k = ip[i];
+        if (k != i) {
+          const int iw = ip[k]; ip[k] = ip[i]; ip[i] = iw;
+          for (int j = 0; j < 9; j++) { const double w = X[j][i]; X[j][i] = X[j][k]; X[j][k] = w; }
+        }
+      }
+    }
+    __syncthreads();
+    if (active && a < 8) {
+      double tk[3][9];  // K_a,alpha * Xinv
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+          double s = 0.0;
+#pragma unroll
+          for (int q = 0; q < 9; q++) s += K[8 + q / 3][3 * i + (q % 3)] * Xinv[el][q][j];
+          tk[i][j] = s;
+        }
+#pragma unroll
+      for (int b = 0; b < 8; b++)
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+          for (int j = 0; j < 3; j++) {
+            double s = 0.0;
+#pragma unroll
+            for (int q = 0; q < 9; q++) s += tk[i][q] * Ksh[el][q][3 * b + j];
+            K[b][3 * i + j] -= s;
+          }
+    }
+  }
+  if (!active || a >= 8) return;
+  if (Kout) {
+#pragma unroll
+    for (int b = 0; b < 8; b++)
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) Kout[(size_t)elem * 576 + (size_t)(3 * a + i) * 24 + 3 * b + j] = K[b][3 * i + j];
+    return;
+  }
+  // scatter (hecmw_mat_add_node, hecmw_mat_ass.f90:72-134)
+  int32_t inod = 0;
+#pragma unroll
+  for (int b = 0; b < 8; b++)
+    if (b == a) inod = nod[b];
+#pragma unroll
+  for (int b = 0; b < 8; b++) {
+    const int32_t jnod = nod[b];
+    double *dst;
+    if (inod == jnod) dst = D + (size_t)9 * (inod - 1);
+    else if (jnod < inod) {
+      const int32_t k = item_search(itemL, indexL[inod - 1], indexL[inod], jnod);
+      if (k < 0) { if (err) atomicExch(err, 2); continue; }
+      dst = AL + (size_t)9 * k;
+    } else {
+      const int32_t k = item_search(itemU, indexU[inod - 1], indexU[inod], jnod);
+      if (k < 0) { if (err) atomicExch(err, 2); continue; }
+      dst = AU + (size_t)9 * k;
+    }
+#pragma unroll
+    for (int e = 0; e < 9; e++) unsafeAtomicAdd(dst + e, K[b][e]);
+  }
+}
+
+// ---- Dirichlet elimination (hecmw_mat_ass_bc, hecmw_mat_ass.f90:292-429) ----------------
+// The reference eliminates one dof at a time; the device does the same algebra in two
+// passes over the rows: (1) RHS fix-up of the free rows with the original columns,
+// (2) zero prescribed rows/columns, unit diagonal, B = prescribed value.
+__global__ void k_bc_mark(int32_t n_bc, const int32_t *__restrict__ node, const int32_t *__restrict__ dof,
+                          const double *__restrict__ val, uint8_t *__restrict__ flag, double *__restrict__ bcv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_bc) return;
+  if (dof[i] < 1 || dof[i] > 3) return;
+  const size_t k = (size_t)3 * (node[i] - 1) + (dof[i] - 1);
+  flag[k] = 1;
+  bcv[k] = val[i];
+}
+
+template <int PASS>
+__global__ void k_bc_apply(int32_t NP, const int32_t *__restrict__ indexL, const int32_t *__restrict__ itemL,
+                           const int32_t *__restrict__ indexU, const int32_t *__restrict__ itemU, double *__restrict__ D,
+                           double *__restrict__ AL, double *__restrict__ AU, double *__restrict__ B,
+                           const uint8_t *__restrict__ flag, const double *__restrict__ bcv) {
+  const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NP) return;
+  const bool fr[3] = {flag[(size_t)3 * i] != 0, flag[(size_t)3 * i + 1] != 0, flag[(size_t)3 * i + 2] != 0};
+  double acc[3] = {0.0, 0.0, 0.0};
+  auto visit = [&](double *blk, int32_t col, bool diag) {
+    const bool fc[3] = {flag[(size_t)3 * col] != 0, flag[(size_t)3 * col + 1] != 0, flag[(size_t)3 * col + 2] != 0};
+    const bool anyc = fc[0] | fc[1] | fc[2], anyr = fr[0] | fr[1] | fr[2];
+    if (!anyc && !anyr) return;
+    if (PASS == 1) {
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+        if (fc[c]) {
+          const double v = bcv[(size_t)3 * col + c];
+          if (v != 0.0) {
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+              if (!fr[r]) acc[r] += blk[3 * r + c] * v;
+          }
+        }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+          if (fr[r] || fc[c]) blk[3 * r + c] = (diag && r == c && fr[r]) ? 1.0 : 0.0;
+    }
+  };
+  visit(D + (size_t)9 * i, i, true);
+  for (int32_t j = indexL[i]; j < indexL[i + 1]; j++) visit(AL + (size_t)9 * j, itemL[j] - 1, false);
+  for (int32_t j = indexU[i]; j < indexU[i + 1]; j++) visit(AU + (size_t)9 * j, itemU[j] - 1, false);
+  if (PASS == 1) {
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+      if (!fr[r] && acc[r] != 0.0) B[(size_t)3 * i + r] -= acc[r];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+      if (fr[r]) B[(size_t)3 * i + r] = bcv[(size_t)3 * i + r];
+  }
+}
+
+__global__ void k_check_zero_diag(int32_t N, const double *__restrict__ D, int32_t *__restrict__ flag) {
+  for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+    const double *d = D + (size_t)9 * i;
+    if (fabs(d[0]) == 0.0 || fabs(d[4]) == 0.0 || fabs(d[8]) == 0.0) atomicExch(flag, 1);
+  }
+}

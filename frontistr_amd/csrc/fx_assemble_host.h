@@ -1,0 +1,174 @@
+// Host entry points of the assembly side (included at the end of fistr_hip.hip).
+#pragma once
+
+// hecmw_mat_con (hecmw_mat_con.f90:23-268): CRS block profile from element connectivity.
+// Node -> element incidence by counting sort, then per node the sorted unique set of the
+// nodes of its elements, split into lower / upper; rows are independent => host threads.
+extern "C" int fx_mat_con(int32_t NP, int32_t n_elem, int32_t nn, const int32_t *conn, int32_t *indexL, int32_t *indexU,
+                          int32_t *itemL, int32_t *itemU) {
+  std::vector<int64_t> ptr((size_t)NP + 2, 0);
+  const int64_t tot = (int64_t)n_elem * nn;
+  for (int64_t k = 0; k < tot; k++) {
+    const int32_t v = conn[k];
+    if (v < 1 || v > NP) { g_fx_error = "fx_mat_con: node id out of range"; return FX_ERROR_RUNTIME; }
+    ptr[v + 1]++;
+  }
+  for (int32_t i = 1; i <= NP + 1; i++) ptr[i] += ptr[i - 1];
+  std::vector<int32_t> inc((size_t)tot);
+  {
+    std::vector<int64_t> pos(ptr.begin(), ptr.end());
+    for (int32_t e = 0; e < n_elem; e++)
+      for (int j = 0; j < nn; j++) inc[pos[conn[(size_t)e * nn + j]]++] = e;
+  }
+  std::vector<int32_t> nl((size_t)NP + 1, 0), nu((size_t)NP + 1, 0);
+  auto row_nodes = [&](int32_t i, std::vector<int32_t> &buf) {
+    buf.clear();
+    for (int64_t a = ptr[i]; a < ptr[i + 1]; a++) {
+      const int32_t *en = conn + (size_t)inc[a] * nn;
+      buf.insert(buf.end(), en, en + nn);
+    }
+    std::sort(buf.begin(), buf.end());
+    buf.erase(std::unique(buf.begin(), buf.end()), buf.end());
+  };
+  if (!itemL || !itemU) {
+    parallel_for(NP, [&](int64_t a, int64_t b) {
+      std::vector<int32_t> buf;
+      for (int64_t i = a + 1; i <= b; i++) {
+        row_nodes((int32_t)i, buf);
+        int32_t l = 0, u = 0;
+        for (int32_t v : buf) { l += (v < i); u += (v > i); }
+        nl[i] = l; nu[i] = u;
+      }
+    });
+    indexL[0] = 0; indexU[0] = 0;
+    int64_t cl = 0, cu = 0;
+    for (int32_t i = 1; i <= NP; i++) {
+      cl += nl[i]; cu += nu[i];
+      if (cl > INT32_MAX || cu > INT32_MAX) { g_fx_error = "fx_mat_con: profile exceeds int32 (kint=4)"; return FX_ERROR_RUNTIME; }
+      indexL[i] = (int32_t)cl; indexU[i] = (int32_t)cu;
+    }
+    return 0;
+  }
+  parallel_for(NP, [&](int64_t a, int64_t b) {
+    std::vector<int32_t> buf;
+    for (int64_t i = a + 1; i <= b; i++) {
+      row_nodes((int32_t)i, buf);
+      int32_t *pl = itemL + indexL[i - 1], *pu = itemU + indexU[i - 1];
+      for (int32_t v : buf) {
+        if (v < i) *pl++ = v;
+        else if (v > i) *pu++ = v;
+      }
+    }
+  });
+  return 0;
+}
+
+static void elastic_constants(double E, double nu, double &D11, double &D12, double &D44) {
+  // calElasticMatrix, 3-D case (ElasticLinear.f90:43-55)
+  D11 = E * (1.0 - nu) / (1.0 - 2.0 * nu) / (1.0 + nu);
+  D12 = E * nu / (1.0 - 2.0 * nu) / (1.0 + nu);
+  D44 = E / (1.0 + nu) * 0.5;
+}
+
+template <int EO>
+static void launch_assemble(fx_context *c, int32_t n_elem, const double *coord, const int32_t *conn, double D11, double D12,
+                            double D44, double *Kout, int32_t *err) {
+  const DevCSR &A = c->A;
+  hipLaunchKernelGGL((k_assemble_c3d8<EO>), dim3((n_elem + FXA_EPB - 1) / FXA_EPB), dim3(FXA_BLOCK), 0, c->stream, n_elem,
+                     coord, conn, D11, D12, D44, A.indexL, A.itemL, A.indexU, A.itemU, A.D, A.AL, A.AU, Kout, err);
+}
+
+extern "C" int fx_assemble_c3d8(fx_context *c, const fx_mesh_view *mesh, double E, double nu, int elemopt, const double *load,
+                                int32_t n_bc, const int32_t *bc_node, const int32_t *bc_dof, const double *bc_val,
+                                float *ms_assemble) {
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->have_profile) { g_fx_error = "fx_assemble_c3d8: upload the profile first (fx_upload FX_UP_PROFILE)"; return FX_ERROR_RUNTIME; }
+  if (mesh->n_node != c->A.NP) { g_fx_error = "fx_assemble_c3d8: mesh/profile size mismatch"; return FX_ERROR_RUNTIME; }
+  if (elemopt < 1 || elemopt > 3) { g_fx_error = "fx_assemble_c3d8: elemopt must be 1 (IC), 2 (B-bar) or 3 (FI)"; return FX_ERROR_UNSUPPORTED; }
+  DevCSR &A = c->A;
+  double *d_coord = nullptr, *d_bcv = nullptr, *d_val = nullptr;
+  int32_t *d_conn = nullptr, *d_err = nullptr, *d_node = nullptr, *d_dof = nullptr;
+  uint8_t *d_flag = nullptr;
+  if (dev_alloc(&d_coord, (size_t)3 * mesh->n_node) || dev_alloc(&d_conn, (size_t)8 * mesh->n_elem) || dev_alloc(&d_err, 1))
+    return FX_ERROR_RUNTIME;
+  HIP_TRY(hipMemcpyAsync(d_coord, mesh->coord, (size_t)3 * mesh->n_node * 8, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(d_conn, mesh->conn, (size_t)8 * mesh->n_elem * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemsetAsync(d_err, 0, 4, c->stream));
+  double D11, D12, D44;
+  elastic_constants(E, nu, D11, D12, D44);
+  HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  // hecmw_mat_clear (fstr_StiffMatrix.f90:40)
+  HIP_TRY(hipMemsetAsync(A.D, 0, (size_t)9 * A.NP * 8, c->stream));
+  HIP_TRY(hipMemsetAsync(A.AL, 0, (size_t)9 * A.NPL * 8, c->stream));
+  HIP_TRY(hipMemsetAsync(A.AU, 0, (size_t)9 * A.NPU * 8, c->stream));
+  if (elemopt == 1) launch_assemble<1>(c, mesh->n_elem, d_coord, d_conn, D11, D12, D44, nullptr, d_err);
+  else if (elemopt == 2) launch_assemble<2>(c, mesh->n_elem, d_coord, d_conn, D11, D12, D44, nullptr, d_err);
+  else launch_assemble<3>(c, mesh->n_elem, d_coord, d_conn, D11, D12, D44, nullptr, d_err);
+  HIP_TRY(hipGetLastError());
+  if (load) HIP_TRY(hipMemcpyAsync(A.B, load, (size_t)3 * A.NP * 8, hipMemcpyHostToDevice, c->stream));
+  else HIP_TRY(hipMemsetAsync(A.B, 0, (size_t)3 * A.NP * 8, c->stream));
+  if (n_bc > 0) {
+    if (dev_alloc(&d_flag, (size_t)3 * A.NP) || dev_alloc(&d_bcv, (size_t)3 * A.NP) || dev_alloc(&d_node, (size_t)n_bc) ||
+        dev_alloc(&d_dof, (size_t)n_bc) || dev_alloc(&d_val, (size_t)n_bc))
+      return FX_ERROR_RUNTIME;
+    for (int32_t k = 0; k < n_bc; k++)
+      if (bc_node[k] < 1 || bc_node[k] > A.NP) { g_fx_error = "fx_assemble_c3d8: BC node id out of range"; return FX_ERROR_RUNTIME; }
+    HIP_TRY(hipMemsetAsync(d_flag, 0, (size_t)3 * A.NP, c->stream));
+    HIP_TRY(hipMemsetAsync(d_bcv, 0, (size_t)3 * A.NP * 8, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_node, bc_node, (size_t)n_bc * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_dof, bc_dof, (size_t)n_bc * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_val, bc_val, (size_t)n_bc * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_bc_mark, dim3((n_bc + 255) / 256), dim3(256), 0, c->stream, n_bc, d_node, d_dof, d_val, d_flag, d_bcv);
+    const dim3 g((A.NP + 255) / 256);
+    hipLaunchKernelGGL((k_bc_apply<1>), g, dim3(256), 0, c->stream, A.NP, A.indexL, A.itemL, A.indexU, A.itemU, A.D, A.AL, A.AU,
+                       A.B, d_flag, d_bcv);
+    hipLaunchKernelGGL((k_bc_apply<2>), g, dim3(256), 0, c->stream, A.NP, A.indexL, A.itemL, A.indexU, A.itemU, A.D, A.AL, A.AU,
+                       A.B, d_flag, d_bcv);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipEventRecord(c->ev1, c->stream));
+  // refresh the streaming layout from the freshly assembled values
+  if (bell_fill_values(c, c->M)) return FX_ERROR_RUNTIME;
+  int32_t herr = 0;
+  HIP_TRY(hipMemcpyAsync(&herr, d_err, 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  if (ms_assemble) *ms_assemble = ms;
+  dev_free(d_coord); dev_free(d_conn); dev_free(d_err); dev_free(d_flag); dev_free(d_bcv);
+  dev_free(d_node); dev_free(d_dof); dev_free(d_val);
+  if (herr == 1) { g_fx_error = "PIVOT ERROR in the incompatible-mode condensation (calInverse)"; return FX_ERROR_RUNTIME; }
+  if (herr == 2) { g_fx_error = "###ERROR### : cannot find connectivity (element not covered by the profile)"; return FX_ERROR_RUNTIME; }
+  c->have_values = true;
+  c->bell_valid = true;
+  c->precond_valid = false;
+  return 0;
+}
+
+extern "C" int fx_element_stiffness_c3d8(fx_context *c, int elemopt, const double *ecoord, double E, double nu, double *stiff) {
+  HIP_TRY(hipSetDevice(c->device));
+  double *d_coord = nullptr, *d_k = nullptr;
+  int32_t *d_conn = nullptr, *d_err = nullptr;
+  if (dev_alloc(&d_coord, 24) || dev_alloc(&d_conn, 8) || dev_alloc(&d_k, 576) || dev_alloc(&d_err, 1)) return FX_ERROR_RUNTIME;
+  const int32_t conn[8] = {1, 2, 3, 4, 5, 6, 7, 8};
+  HIP_TRY(hipMemcpy(d_coord, ecoord, 24 * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_conn, conn, 32, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(d_err, 0, 4));
+  double D11, D12, D44;
+  elastic_constants(E, nu, D11, D12, D44);
+  const int32_t *nul = nullptr;
+  double *nud = nullptr;
+#define ONE(EO)                                                                                                         \
+  hipLaunchKernelGGL((k_assemble_c3d8<EO>), dim3(1), dim3(FXA_BLOCK), 0, c->stream, 1, d_coord, d_conn, D11, D12, D44, nul, \
+                     nul, nul, nul, nud, nud, nud, d_k, d_err)
+  if (elemopt == 1) ONE(1);
+  else if (elemopt == 2) ONE(2);
+  else if (elemopt == 3) ONE(3);
+  else { g_fx_error = "elemopt must be 1, 2 or 3"; return FX_ERROR_UNSUPPORTED; }
+#undef ONE
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipMemcpy(stiff, d_k, 576 * 8, hipMemcpyDeviceToHost));
+  dev_free(d_coord); dev_free(d_conn); dev_free(d_k); dev_free(d_err);
+  return 0;
+}

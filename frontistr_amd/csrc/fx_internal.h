@@ -1,0 +1,125 @@
+// Internal declarations of libfistr_hip (gfx950 only).  See include/fistr_hip.h for the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/fistr_hip.h"
+
+extern thread_local std::string g_fx_error;
+int fx_fail(const char *what, const char *file, int line);
+
+#define HIP_TRY(expr)                                                        \
+  do {                                                                       \
+    hipError_t _e = (expr);                                                  \
+    if (_e != hipSuccess) {                                                  \
+      g_fx_error = std::string(#expr) + ": " + hipGetErrorString(_e);        \
+      return fx_fail(g_fx_error.c_str(), __FILE__, __LINE__);                \
+    }                                                                        \
+  } while (0)
+
+// ---------------------------------------------------------------------------
+// Device copy of the reference layout (D / AL / AU with 1-based items), kept so
+// that assembly and BC elimination work on the arrays fistr1 owns and so the
+// matrix can be handed back bit-for-bit.
+// ---------------------------------------------------------------------------
+struct DevCSR {
+  int32_t N = 0, NP = 0, NPL = 0, NPU = 0;
+  int32_t *indexL = nullptr, *itemL = nullptr, *indexU = nullptr, *itemU = nullptr;
+  double *D = nullptr, *AL = nullptr, *AU = nullptr, *B = nullptr, *X = nullptr;
+};
+
+// ---------------------------------------------------------------------------
+// BELL-64: sliced block-ELL, the layout every sweep kernel streams.
+//   slot  = 64*slice + lane; one thread owns one block row.
+//   slice s holds pairs [pair_ptr[s], pair_ptr[s+1]) of 3x3 blocks; for pair p
+//   and block element e (row-major, 0..8) the two values of lane l sit in one
+//   16-byte word:  val2[(p*9 + e)*64 + l] = (block 2p, block 2p+1)[e]
+//   and the two column node ids (0-based) in one 8-byte word: col2[p*64 + l].
+//   => every wave-level load is 1 KiB (values) / 512 B (columns), fully coalesced,
+//   and a lane never needs a cross-lane reduction.
+//   Padding blocks carry value 0 and the row's own column (always a valid address).
+// ---------------------------------------------------------------------------
+struct Bell {
+  int32_t nslots = 0, nslices = 0;
+  int64_t npairs = 0;
+  int32_t *pair_ptr = nullptr;  // nslices+1
+  double2 *val2 = nullptr;      // npairs*9*64
+  int2 *col2 = nullptr;         // npairs*64
+  int2 *src2 = nullptr;         // npairs*64: source block codes 3*idx+{0 D,1 AL,2 AU}, -1 padding (kept for numeric refresh)
+  int32_t *slot_row = nullptr;  // nslots: 0-based node id of the slot, -1 = padding slot (may be null = identity)
+  int64_t nblocks = 0;          // real (non padding) blocks
+  size_t bytes() const { return (size_t)npairs * 64 * (9 * 16 + 8) + (size_t)(nslices + 1) * 4; }
+};
+
+// Multicolour SSOR state (hecmw_precond_SSOR_33.f90 module variables).
+struct SsorDev {
+  int32_t ncolor = 0;
+  std::vector<int32_t> color_slice;  // slice range per colour: [color_slice[c], color_slice[c+1])
+  Bell L, U;                         // strictly-lower / strictly-upper parts in colour-slot order
+  double *alu = nullptr;             // LU of the diagonal blocks, [slice][e][lane] layout
+  std::vector<int32_t> perm;         // new -> old (1-based), as the reference's perm(:)
+  std::vector<int32_t> colorindex;   // COLORindex(0:ncolor)
+};
+
+struct DiagDev {
+  double *alu = nullptr;  // [slice][e][lane]
+  int32_t nslices = 0;
+};
+
+// Scalars of the Krylov loops, resident on the device; the host only polls `status`.
+struct KrylovState {
+  double rho, rho1, beta, c1, alpha, omega, c2, cg0, cg1, dnrm2, bnrm2, resid, tol;
+  int32_t iter;         // Fortran ITER of the iteration being executed
+  int32_t status;       // 0 running, 1 converged/exit, else fx_status code
+  int32_t need_verify;  // RESID<=TOL seen, true residual check pending
+  int32_t n_indef;
+  int32_t maxit;
+  int32_t error;        // 3001 set while running (reference sets error and falls out of the DO)
+  int32_t pad[2];
+};
+
+struct HaloDev {
+  int32_t n_neighbor = 0;
+  std::vector<int32_t> neighbor, import_index, export_index;
+  int32_t *export_item = nullptr, *import_item = nullptr;  // device, 0-based
+  double *sendbuf = nullptr, *recvbuf = nullptr;
+  int32_t n_export = 0, n_import = 0;
+};
+
+struct fx_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  DevCSR A;
+  Bell M;  // full matrix (D + AL + AU) in natural row order, for SpMV
+  bool have_profile = false, have_values = false, bell_valid = false;
+  // host copies of the profile (ordering, conversion maps)
+  std::vector<int32_t> h_indexL, h_itemL, h_indexU, h_itemU;
+  // preconditioner
+  int precond_kind = 0;  // 0 none, 1 SSOR, 3 DIAG, 10 ILU0
+  DiagDev diag;
+  SsorDev ssor;
+  bool precond_valid = false;
+  int ssor_ncolor_in = 0;
+  // work vectors (3*NP each)
+  double *W[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int32_t wlen = 0;
+  // reductions
+  double *partials = nullptr;  // 3 * max_partials
+  int32_t max_partials = 0;
+  double *red_out = nullptr;  // small device scratch for reduced sums (8 doubles)
+  KrylovState *st = nullptr;   // device
+  KrylovState *st_host = nullptr;  // pinned
+  double *hist = nullptr;      // device residual history
+  int32_t hist_cap = 0;
+  // communication
+  int rank = 0, nranks = 1;
+  int32_t nn_internal = 0;
+  void *nccl = nullptr;
+  HaloDev halo;
+  // timing
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+

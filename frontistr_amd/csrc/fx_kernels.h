@@ -1,0 +1,488 @@
+// Device kernels of libfistr_hip (gfx950 / CDNA4, wave64).  Included once by fistr_hip.hip.
+//
+// All sweep kernels stream the BELL-64 layout (fx_internal.h): one thread per
+// block row, every wave-level load a full 1 KiB / 512 B coalesced segment, no
+// cross-lane reduction in the row loop.  Everything on this path is bound by HBM
+// bandwidth (SpMV arithmetic intensity ~0.23 flop/B), so
+// MFMA is deliberately not used: a 3x3 block per 72 B offers no dense tile.
+#pragma once
+#include "fx_internal.h"
+
+#define FX_BLOCK 256
+
+// ------------------------------------------------------------------------
+// reductions: wave shuffle (64 lanes) then LDS across the 4 waves, fixed order
+// => bitwise reproducible run to run.
+// ------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+template <int NV>
+__device__ __forceinline__ void block_sum_store(double (&v)[NV], double *out, int stride) {
+  __shared__ double sm[NV][FX_BLOCK / 64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    double s = wave_sum(v[i]);
+    if (lane == 0) sm[i][w] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < FX_BLOCK / 64; k++) s += sm[i][k];
+      out[(size_t)i * stride + blockIdx.x] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------
+// BELL fill: gather 3x3 blocks of the reference arrays into the sliced layout.
+// src code: 3*idx + which (0 = D, 1 = AL, 2 = AU), idx 0-based block; -1 = padding.
+// Run once per numeric refresh (Iarray(97)); reads 72 B segments, writes coalesced.
+// ------------------------------------------------------------------------
+__global__ void k_bell_fill(int32_t nslices, const int32_t *__restrict__ pair_ptr,
+                            const int2 *__restrict__ src2, const double *__restrict__ D,
+                            const double *__restrict__ AL, const double *__restrict__ AU,
+                            double2 *__restrict__ val2) {
+  const int slice = blockIdx.x * (FX_BLOCK / 64) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (slice >= nslices) return;
+  const int p0 = pair_ptr[slice], p1 = pair_ptr[slice + 1];
+  for (int p = p0; p < p1; p++) {
+    const int2 s = src2[(size_t)p * 64 + lane];
+    double a[9], b[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) { a[e] = 0.0; b[e] = 0.0; }
+    if (s.x >= 0) {
+      const int w = s.x % 3;
+      const double *base = (w == 0 ? D : (w == 1 ? AL : AU)) + (size_t)9 * (s.x / 3);
+#pragma unroll
+      for (int e = 0; e < 9; e++) a[e] = base[e];
+    }
+    if (s.y >= 0) {
+      const int w = s.y % 3;
+      const double *base = (w == 0 ? D : (w == 1 ? AL : AU)) + (size_t)9 * (s.y / 3);
+#pragma unroll
+      for (int e = 0; e < 9; e++) b[e] = base[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 9; e++) val2[((size_t)p * 9 + e) * 64 + lane] = make_double2(a[e], b[e]);
+  }
+}
+
+// ------------------------------------------------------------------------
+// K1/K2: y = A x  (hecmw_matvec_33_inner, hecmw_solver_las_33.f90:263-300)
+// MODE 0: y = A x            MODE 1: y = b - A x (hecmw_matresid_33 :371-379)
+// DOT  0: none  1: partial of x.y (p.q in CG)  2: partial of y.y (||r||^2 after matresid)
+// `gate` (may be null): device status word; the kernel is a no-op unless *gate == gate_val.
+// ------------------------------------------------------------------------
+template <int MODE, int DOT>
+__global__ __launch_bounds__(FX_BLOCK) void k_spmv(int32_t nslices, int32_t nrows,
+                                                   const int32_t *__restrict__ pair_ptr,
+                                                   const double2 *__restrict__ val2,
+                                                   const int2 *__restrict__ col2,
+                                                   const double *__restrict__ x, const double *__restrict__ b,
+                                                   double *__restrict__ y, double *__restrict__ partials,
+                                                   const int32_t *__restrict__ gate, int32_t gate_val) {
+  if (gate && *gate != gate_val) return;
+  const int slice = blockIdx.x * (FX_BLOCK / 64) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+  const int row = slice * 64 + lane;
+  if (slice < nslices) {
+    const int p0 = pair_ptr[slice], p1 = pair_ptr[slice + 1];
+    const double2 *v = val2 + (size_t)p0 * 576 + lane;
+    const int2 *c = col2 + (size_t)p0 * 64 + lane;
+    for (int p = p0; p < p1; p++, v += 576, c += 64) {
+      const int2 cc = *c;
+      double2 a[9];
+#pragma unroll
+      for (int e = 0; e < 9; e++) a[e] = v[e * 64];
+      const double *xa = x + (size_t)3 * cc.x, *xb = x + (size_t)3 * cc.y;
+      const double xa0 = xa[0], xa1 = xa[1], xa2 = xa[2];
+      const double xb0 = xb[0], xb1 = xb[1], xb2 = xb[2];
+      y0 += a[0].x * xa0 + a[1].x * xa1 + a[2].x * xa2;
+      y1 += a[3].x * xa0 + a[4].x * xa1 + a[5].x * xa2;
+      y2 += a[6].x * xa0 + a[7].x * xa1 + a[8].x * xa2;
+      y0 += a[0].y * xb0 + a[1].y * xb1 + a[2].y * xb2;
+      y1 += a[3].y * xb0 + a[4].y * xb1 + a[5].y * xb2;
+      y2 += a[6].y * xb0 + a[7].y * xb1 + a[8].y * xb2;
+    }
+  }
+  double d[1] = {0.0};
+  if (slice < nslices && row < nrows) {
+    if (MODE == 1) {
+      y0 = b[(size_t)3 * row] - y0; y1 = b[(size_t)3 * row + 1] - y1; y2 = b[(size_t)3 * row + 2] - y2;
+    }
+    y[(size_t)3 * row] = y0; y[(size_t)3 * row + 1] = y1; y[(size_t)3 * row + 2] = y2;
+    if (DOT == 1) d[0] = x[(size_t)3 * row] * y0 + x[(size_t)3 * row + 1] * y1 + x[(size_t)3 * row + 2] * y2;
+    if (DOT == 2) d[0] = y0 * y0 + y1 * y1 + y2 * y2;
+  }
+  if (DOT != 0) block_sum_store<1>(d, partials, 0);
+}
+
+// ------------------------------------------------------------------------
+// 3x3 LU helpers (hecmw_precond_DIAG_33.f90:96-105 and :140-144; identical code
+// in hecmw_precond_SSOR_33.f90:190-201, :341-345)
+// ------------------------------------------------------------------------
+__device__ __forceinline__ void lu33_dev(double *a) {
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    a[4 * k] = 1.0 / a[4 * k];
+#pragma unroll
+    for (int i = k + 1; i < 3; i++) {
+      a[3 * i + k] = a[3 * i + k] * a[4 * k];
+#pragma unroll
+      for (int j = k + 1; j < 3; j++) a[3 * i + j] = a[3 * i + j] - a[3 * i + k] * a[3 * k + j];
+    }
+  }
+}
+
+__device__ __forceinline__ void lusolve33_dev(const double *u, double &x1, double &x2, double &x3) {
+  x2 = x2 - u[3] * x1;
+  x3 = x3 - u[6] * x1 - u[7] * x2;
+  x3 = u[8] * x3;
+  x2 = u[4] * (x2 - u[5] * x3);
+  x1 = u[0] * (x1 - u[2] * x3 - u[1] * x2);
+}
+
+// ALU setup: slot_row (may be null = identity) maps slot -> 0-based node; D in reference layout.
+// Output layout [slice][e][lane].
+__global__ void k_alu_setup(int32_t nslots, int32_t nrows, const int32_t *__restrict__ slot_row,
+                            const double *__restrict__ D, double sigma_diag, double *__restrict__ alu) {
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= nslots) return;
+  const int row = slot_row ? slot_row[slot] : slot;
+  double a[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if (row >= 0 && row < nrows) {
+#pragma unroll
+    for (int e = 0; e < 9; e++) a[e] = D[(size_t)9 * row + e];
+    a[0] *= sigma_diag; a[4] *= sigma_diag; a[8] *= sigma_diag;
+    lu33_dev(a);
+  }
+  const size_t base = (size_t)(slot >> 6) * 576 + (slot & 63);
+#pragma unroll
+  for (int e = 0; e < 9; e++) alu[base + (size_t)e * 64] = a[e];
+}
+
+// K6: block-Jacobi apply z = D~^-1 r (hecmw_precond_DIAG_33.f90:125-152), fused with the
+// prologue/epilogue of hecmw_precond_apply (Z = 0 + ZP) and the partial of r.z.
+__global__ __launch_bounds__(FX_BLOCK) void k_diag_apply(int32_t nrows, const double *__restrict__ alu,
+                                                         const double *__restrict__ r, double *__restrict__ z,
+                                                         double *__restrict__ partials,
+                                                         const int32_t *__restrict__ gate) {
+  if (gate && *gate != 0) return;
+  const int row = blockIdx.x * FX_BLOCK + threadIdx.x;
+  double d[1] = {0.0};
+  if (row < nrows) {
+    double u[9];
+    const size_t base = (size_t)(row >> 6) * 576 + (row & 63);
+#pragma unroll
+    for (int e = 0; e < 9; e++) u[e] = alu[base + (size_t)e * 64];
+    const double r1 = r[(size_t)3 * row], r2 = r[(size_t)3 * row + 1], r3 = r[(size_t)3 * row + 2];
+    double x1 = r1, x2 = r2, x3 = r3;
+    lusolve33_dev(u, x1, x2, x3);
+    z[(size_t)3 * row] = x1; z[(size_t)3 * row + 1] = x2; z[(size_t)3 * row + 2] = x3;
+    d[0] = r1 * x1 + r2 * x2 + r3 * x3;
+  }
+  if (partials) block_sum_store<1>(d, partials, 0);
+}
+
+// K7: one colour of the multicolour block SSOR sweep (hecmw_precond_SSOR_33.f90:300-352
+// forward, :355-410 backward).  Vectors stay in the OLD numbering (the reference indexes ZP
+// through perm); rows of one colour are independent.
+//   FWD: z_i = D~_i^-1 ( r_i - sum_{j in L(i)} L_ij z_j )      (reads r for the own row: the
+//        reference's ZP=R copy is folded away, earlier colours are already final in z)
+//   BWD: z_i = z_i - D~_i^-1 sum_{j in U(i)} U_ij z_j           (+ partial of r.z when asked)
+template <bool FWD>
+__global__ __launch_bounds__(FX_BLOCK) void k_ssor_color(int32_t slice0, int32_t slice1,
+                                                         const int32_t *__restrict__ pair_ptr,
+                                                         const double2 *__restrict__ val2,
+                                                         const int2 *__restrict__ col2,
+                                                         const int32_t *__restrict__ slot_row,
+                                                         const double *__restrict__ alu,
+                                                         const double *__restrict__ r, double *__restrict__ z,
+                                                         double *__restrict__ partials,
+                                                         const int32_t *__restrict__ gate) {
+  if (gate && *gate != 0) return;
+  const int slice = slice0 + blockIdx.x * (FX_BLOCK / 64) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  double d[1] = {0.0};
+  if (slice < slice1) {
+    const int slot = slice * 64 + lane;
+    const int row = slot_row[slot];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    const int p0 = pair_ptr[slice], p1 = pair_ptr[slice + 1];
+    const double2 *v = val2 + (size_t)p0 * 576 + lane;
+    const int2 *c = col2 + (size_t)p0 * 64 + lane;
+    for (int p = p0; p < p1; p++, v += 576, c += 64) {
+      const int2 cc = *c;
+      double2 a[9];
+#pragma unroll
+      for (int e = 0; e < 9; e++) a[e] = v[e * 64];
+      const double *xa = z + (size_t)3 * cc.x, *xb = z + (size_t)3 * cc.y;
+      const double xa0 = xa[0], xa1 = xa[1], xa2 = xa[2];
+      const double xb0 = xb[0], xb1 = xb[1], xb2 = xb[2];
+      s0 += a[0].x * xa0 + a[1].x * xa1 + a[2].x * xa2;
+      s1 += a[3].x * xa0 + a[4].x * xa1 + a[5].x * xa2;
+      s2 += a[6].x * xa0 + a[7].x * xa1 + a[8].x * xa2;
+      s0 += a[0].y * xb0 + a[1].y * xb1 + a[2].y * xb2;
+      s1 += a[3].y * xb0 + a[4].y * xb1 + a[5].y * xb2;
+      s2 += a[6].y * xb0 + a[7].y * xb1 + a[8].y * xb2;
+    }
+    if (row >= 0) {
+      double u[9];
+      const size_t base = (size_t)slice * 576 + lane;
+#pragma unroll
+      for (int e = 0; e < 9; e++) u[e] = alu[base + (size_t)e * 64];
+      double *zi = z + (size_t)3 * row;
+      if (FWD) {
+        const double *ri = r + (size_t)3 * row;
+        double x1 = ri[0] - s0, x2 = ri[1] - s1, x3 = ri[2] - s2;
+        lusolve33_dev(u, x1, x2, x3);
+        zi[0] = x1; zi[1] = x2; zi[2] = x3;
+      } else {
+        lusolve33_dev(u, s0, s1, s2);
+        const double x1 = zi[0] - s0, x2 = zi[1] - s1, x3 = zi[2] - s2;
+        zi[0] = x1; zi[1] = x2; zi[2] = x3;
+        if (partials) {
+          const double *ri = r + (size_t)3 * row;
+          d[0] = ri[0] * x1 + ri[1] * x2 + ri[2] * x3;
+        }
+      }
+    }
+  }
+  if (!FWD && partials) block_sum_store<1>(d, partials, 0);
+}
+
+// ------------------------------------------------------------------------
+// K3/K4: vector kernels (3*nn_internal entries), grid-stride, partial sums per block.
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(FX_BLOCK) void k_dot(int64_t n, const double *__restrict__ x,
+                                                  const double *__restrict__ y, double *__restrict__ partials,
+                                                  const int32_t *__restrict__ gate, int32_t gate_val) {
+  if (gate && *gate != gate_val) return;
+  double d[1] = {0.0};
+  for (int64_t i = (int64_t)blockIdx.x * FX_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FX_BLOCK)
+    d[0] += x[i] * y[i];
+  block_sum_store<1>(d, partials, 0);
+}
+
+// two dots in one pass: (t.s, t.t) of BiCGSTAB (hecmw_solver_BiCGSTAB.f90:217-218)
+__global__ __launch_bounds__(FX_BLOCK) void k_dot2(int64_t n, const double *__restrict__ t,
+                                                   const double *__restrict__ s, double *__restrict__ partials,
+                                                   int32_t stride, const int32_t *__restrict__ gate) {
+  if (gate && *gate != 0) return;
+  double d[2] = {0.0, 0.0};
+  for (int64_t i = (int64_t)blockIdx.x * FX_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FX_BLOCK) {
+    const double tv = t[i];
+    d[0] += tv * s[i];
+    d[1] += tv * tv;
+  }
+  block_sum_store<2>(d, partials, stride);
+}
+
+// CG: p = z + beta p   (hecmw_solver_CG.f90:188-197; beta = 0 on the first iteration)
+__global__ __launch_bounds__(FX_BLOCK) void k_cg_update_p(int64_t n, const KrylovState *__restrict__ st,
+                                                          const double *__restrict__ z, double *__restrict__ p) {
+  if (st->status != 0) return;
+  const bool first = (st->iter == 1);
+  const double beta = st->beta;
+  for (int64_t i = (int64_t)blockIdx.x * FX_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FX_BLOCK)
+    p[i] = first ? z[i] : z[i] + beta * p[i];
+}
+
+// CG: x += alpha p ; r -= alpha q ; partial ||r||^2   (hecmw_solver_CG.f90:227-240)
+// UPDATE_R false on the iterations that recompute r = b - A x instead (:232-233).
+template <bool UPDATE_R>
+__global__ __launch_bounds__(FX_BLOCK) void k_cg_update_xr(int64_t n, const KrylovState *__restrict__ st,
+                                                           const double *__restrict__ p,
+                                                           const double *__restrict__ q, double *__restrict__ x,
+                                                           double *__restrict__ r, double *__restrict__ partials) {
+  if (st->status != 0) return;
+  const double alpha = st->alpha;
+  double d[1] = {0.0};
+  for (int64_t i = (int64_t)blockIdx.x * FX_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FX_BLOCK) {
+    x[i] = x[i] + alpha * p[i];
+    if (UPDATE_R) {
+      const double rv = r[i] - alpha * q[i];
+      r[i] = rv;
+      d[0] += rv * rv;
+    }
+  }
+  if (UPDATE_R) block_sum_store<1>(d, partials, 0);
+}
+
+// BiCGSTAB vector updates (hecmw_solver_BiCGSTAB.f90:160-170, :194-196, :231-241)
+__global__ __launch_bounds__(FX_BLOCK) void k_bi_update_p(int64_t n, const KrylovState *__restrict__ st,
+                                                          const double *__restrict__ r,
+                                                          const double *__restrict__ v, double *__restrict__ p) {
+  if (st->status != 0) return;
+  const bool first = (st->iter == 1);
+  const double beta = st->beta, omega = st->omega;
+  for (int64_t i = (int64_t)blockIdx.x * FX_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FX_BLOCK)
+    p[i] = first ? r[i] : r[i] + beta * (p[i] - omega * v[i]);
+}
+
+__global__ __launch_bounds__(FX_BLOCK) void k_bi_update_s(int64_t n, const KrylovState *__restrict__ st,
+                                                          const double *__restrict__ r,
+                                                          const double *__restrict__ v, double *__restrict__ s) {
+  if (st->status != 0) return;
+  const double alpha = st->alpha;
+  for (int64_t i = (int64_t)blockIdx.x * FX_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FX_BLOCK)
+    s[i] = r[i] - alpha * v[i];
+}
+
+template <bool UPDATE_R>
+__global__ __launch_bounds__(FX_BLOCK) void k_bi_update_xr(int64_t n, const KrylovState *__restrict__ st,
+                                                           const double *__restrict__ pt,
+                                                           const double *__restrict__ stl,
+                                                           const double *__restrict__ s,
+                                                           const double *__restrict__ t, double *__restrict__ x,
+                                                           double *__restrict__ r, double *__restrict__ partials) {
+  if (st->status != 0) return;
+  const double alpha = st->alpha, omega = st->omega;
+  double d[1] = {0.0};
+  for (int64_t i = (int64_t)blockIdx.x * FX_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FX_BLOCK) {
+    x[i] = x[i] + alpha * pt[i] + omega * stl[i];
+    if (UPDATE_R) {
+      const double rv = s[i] - omega * t[i];
+      r[i] = rv;
+      d[0] += rv * rv;
+    }
+  }
+  if (UPDATE_R) block_sum_store<1>(d, partials, 0);
+}
+
+__global__ void k_copy(int64_t n, const double *__restrict__ a, double *__restrict__ b) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    b[i] = a[i];
+}
+
+__global__ void k_axpy_plain(int64_t n, double a, const double *__restrict__ x, double *__restrict__ y) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] += a * x[i];
+}
+
+// ------------------------------------------------------------------------
+// Scalar stage: reduce the per-block partials in a fixed order, then the
+// reference's scalar logic, entirely on the device (no host round trip per dot).
+// phase 0: reduce + logic (single GPU);  1: reduce only -> red[slot..] (an RCCL
+// all-reduce follows);  2: logic only from red[].
+// ------------------------------------------------------------------------
+enum ScalarOp {
+  OP_BNRM2 = 0,    // ||b||^2, hecmw_solver_CG.f90:123-129
+  OP_CG_RHO,       // :168-180 (+ beta :193)
+  OP_CG_C1,        // :211-219
+  OP_RESID,        // :240-267 (shared with BiCGSTAB :243-262)
+  OP_VERIFY,       // :261-266 true-residual re-check
+  OP_BI_RHO,       // hecmw_solver_BiCGSTAB.f90:152, :161
+  OP_BI_C2,        // :188-190
+  OP_BI_OMEGA,     // :217-226
+  OP_PLAIN         // just the sum(s) -> red[]
+};
+
+__device__ __forceinline__ double reduce_partials(const double *partials, int n) {
+  __shared__ double sm[1024 / 64];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += partials[i];
+  s = wave_sum(s);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sm[w] = s;
+  __syncthreads();
+  double tot = 0.0;
+  if (threadIdx.x == 0)
+    for (int k = 0; k < (int)(blockDim.x >> 6); k++) tot += sm[k];
+  return tot;  // valid in thread 0
+}
+
+template <int OP>
+__global__ void k_scalar(const double *__restrict__ partials, int32_t nparts, int32_t stride,
+                         KrylovState *__restrict__ st, double *__restrict__ hist, double *__restrict__ red,
+                         int phase, int32_t recompute_every) {
+  // gating: VERIFY runs only when a check is pending, everything else only while running
+  if (OP == OP_VERIFY) { if (st->status != 0 || st->need_verify != 1) return; }
+  else if (OP != OP_BNRM2 && OP != OP_PLAIN) { if (st->status != 0) return; }
+  double v0 = 0.0, v1 = 0.0;
+  if (phase != 2) {
+    v0 = reduce_partials(partials, nparts);
+    if (OP == OP_BI_OMEGA || (OP == OP_PLAIN && stride > 0)) v1 = reduce_partials(partials + stride, nparts);
+    if (phase == 1 || OP == OP_PLAIN) {
+      if (threadIdx.x == 0) { red[0] = v0; red[1] = v1; }
+      return;
+    }
+  }
+  if (threadIdx.x != 0) return;
+  if (phase == 2) { v0 = red[0]; v1 = red[1]; }
+  if (OP == OP_BNRM2) {
+    st->bnrm2 = v0;
+    if (v0 == 0.0) { st->status = 1; st->resid = 0.0; st->iter = 1; }  // MAXIT=0: DO leaves ITER=1
+  } else if (OP == OP_CG_RHO) {
+    st->rho = v0;
+    if (v0 == 0.0) { st->status = 1; return; }
+    if (st->iter > 1 && v0 * st->rho1 <= 0.0) {
+      st->n_indef++;
+      if (st->n_indef >= 3) { st->status = FX_ERROR_DIVERGE_PC; return; }
+    }
+    st->beta = (st->iter > 1) ? v0 / st->rho1 : 0.0;
+  } else if (OP == OP_CG_C1) {
+    st->c1 = v0;
+    if (!(v0 > 0.0)) { st->status = FX_ERROR_DIVERGE_MAT; return; }  // `C1 <= 0` (NaN falls here too)
+    st->alpha = st->rho / v0;
+  } else if (OP == OP_RESID || OP == OP_VERIFY) {
+    st->dnrm2 = v0;
+    const double resid = sqrt(v0 / st->bnrm2);
+    st->resid = resid;
+    const int it = st->iter;
+    if (OP == OP_RESID) {
+      if (hist) hist[it - 1] = resid;
+      if (resid <= st->tol) {
+        if (it % recompute_every == 0) { st->status = 1; return; }
+        st->need_verify = 1;
+        return;
+      }
+    } else {
+      st->need_verify = 0;
+      if (resid <= st->tol) { st->status = 1; return; }
+    }
+    if (it == st->maxit) { st->error = FX_ERROR_NOCONV_MAXIT; st->status = FX_ERROR_NOCONV_MAXIT; st->iter = it + 1; return; }
+    st->rho1 = st->rho;
+    st->iter = it + 1;
+  } else if (OP == OP_BI_RHO) {
+    st->rho = v0;
+    st->beta = (st->iter > 1) ? (v0 / st->rho1) * (st->alpha / st->omega) : 0.0;
+  } else if (OP == OP_BI_C2) {
+    st->c2 = v0;
+    st->alpha = st->rho / v0;
+  } else if (OP == OP_BI_OMEGA) {
+    st->cg0 = v0; st->cg1 = v1;
+    st->omega = v0 / v1;
+  }
+}
+
+// Halo pack / unpack (hecmw_solve_send_recv_33, hecmw_solver_SR_33.F90:80-121)
+__global__ void k_halo_pack(int32_t n, const int32_t *__restrict__ item, const double *__restrict__ x,
+                            double *__restrict__ buf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int node = item[i];
+  buf[(size_t)3 * i] = x[(size_t)3 * node];
+  buf[(size_t)3 * i + 1] = x[(size_t)3 * node + 1];
+  buf[(size_t)3 * i + 2] = x[(size_t)3 * node + 2];
+}
+__global__ void k_halo_unpack(int32_t n, const int32_t *__restrict__ item, const double *__restrict__ buf,
+                              double *__restrict__ x) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int node = item[i];
+  x[(size_t)3 * node] = buf[(size_t)3 * i];
+  x[(size_t)3 * node + 1] = buf[(size_t)3 * i + 1];
+  x[(size_t)3 * node + 2] = buf[(size_t)3 * i + 2];
+}

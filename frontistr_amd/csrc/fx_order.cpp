@@ -1,0 +1,142 @@
+// Host-side orderings of libfistr_hip: the level ordering + greedy multicolouring the
+// reference uses for its threaded SSOR, so that the GPU sweep applies the SAME
+// preconditioner (same colours, same iteration counts) as the reference's OpenMP path.
+//
+//   reference: hecmw1/src/solver/matrix/hecmw_matrix_ordering_CM.f90:16-178
+//              hecmw1/src/solver/matrix/hecmw_matrix_ordering_MC.f90:15-72
+//              used by precond/33/hecmw_precond_SSOR_33.f90:102-111
+//
+// Work is on a 0-based adjacency (lower neighbours first, then upper, halo columns
+// dropped) built once; the up-to-5 candidate start nodes are explored concurrently.
+#include <stdint.h>
+
+#include <algorithm>
+#include <thread>
+#include <vector>
+
+namespace fxo {
+
+struct Graph {
+  int32_t n = 0;
+  std::vector<int64_t> ptr;
+  std::vector<int32_t> adj;  // lower neighbours (ascending) then upper (ascending), internal only
+};
+
+Graph build_graph(int32_t N, const int32_t *indexL, const int32_t *itemL, const int32_t *indexU,
+                  const int32_t *itemU) {
+  Graph g;
+  g.n = N;
+  g.ptr.assign((size_t)N + 1, 0);
+  for (int32_t i = 0; i < N; i++) {
+    int64_t c = indexL[i + 1] - indexL[i];
+    for (int32_t j = indexU[i]; j < indexU[i + 1]; j++) c += (itemU[j] <= N);
+    g.ptr[i + 1] = g.ptr[i] + c;
+  }
+  g.adj.resize((size_t)g.ptr[N]);
+  for (int32_t i = 0; i < N; i++) {
+    int64_t w = g.ptr[i];
+    for (int32_t j = indexL[i]; j < indexL[i + 1]; j++) g.adj[w++] = itemL[j] - 1;
+    for (int32_t j = indexU[i]; j < indexU[i + 1]; j++)
+      if (itemU[j] <= N) g.adj[w++] = itemU[j] - 1;
+  }
+  return g;
+}
+
+// Breadth-first level structure from `start`; nodes are appended in discovery order
+// (no degree sort inside a level, exactly like ordering_CM_inner).  When a component is
+// exhausted the lowest-numbered unvisited node opens the next level.
+static int32_t level_order(const Graph &g, int32_t start, std::vector<int32_t> &seq) {
+  const int32_t n = g.n;
+  std::vector<uint8_t> seen((size_t)n, 0);
+  seq.clear();
+  seq.reserve(n);
+  seq.push_back(start);
+  seen[start] = 1;
+  int32_t nlevel = 1, lo = 0, hi = 1, next_unseen = 0;
+  while ((int32_t)seq.size() < n) {
+    for (int32_t q = lo; q < hi && (int32_t)seq.size() < n; q++) {
+      const int32_t u = seq[q];
+      for (int64_t e = g.ptr[u]; e < g.ptr[u + 1]; e++) {
+        const int32_t v = g.adj[e];
+        if (!seen[v]) {
+          seen[v] = 1;
+          seq.push_back(v);
+          if ((int32_t)seq.size() == n) break;
+        }
+      }
+    }
+    if ((int32_t)seq.size() == hi) {  // nothing discovered: jump to any unvisited node
+      while (seen[next_unseen]) next_unseen++;
+      seen[next_unseen] = 1;
+      seq.push_back(next_unseen);
+    }
+    lo = hi;
+    hi = (int32_t)seq.size();
+    nlevel++;
+  }
+  return nlevel;
+}
+
+// "RCM" of the reference = level ordering from the best of <= 5 minimum-degree starts,
+// followed by reverse_ordering, which maps node id k -> N-1-k (0-based) instead of
+// reversing the sequence.  Returns the visiting sequence (new -> old, 0-based).
+std::vector<int32_t> rcm_sequence(const Graph &g) {
+  const int32_t n = g.n;
+  int64_t degmin = n;
+  std::vector<int32_t> starts;
+  int32_t nties = 0;
+  for (int32_t i = 0; i < n; i++) {
+    const int64_t deg = g.ptr[i + 1] - g.ptr[i];
+    if (deg == 0) continue;
+    if (deg < degmin) { degmin = deg; starts.assign(1, i); nties = 1; }
+    else if (deg == degmin) { if (++nties <= 5) starts.push_back(i); }
+  }
+  if (starts.empty()) starts.push_back(0);
+  std::vector<std::vector<int32_t>> seqs(starts.size());
+  std::vector<int32_t> nlev(starts.size(), 0);
+  std::vector<std::thread> th;
+  for (size_t s = 0; s < starts.size(); s++)
+    th.emplace_back([&, s] { nlev[s] = level_order(g, starts[s], seqs[s]); });
+  for (auto &t : th) t.join();
+  size_t best = 0;
+  for (size_t s = 1; s < starts.size(); s++)
+    if (nlev[s] > nlev[best]) best = s;
+  std::vector<int32_t> seq = std::move(seqs[best]);
+  for (auto &v : seq) v = n - 1 - v;  // reverse_ordering: id mirror
+  return seq;
+}
+
+// Greedy multicolouring walking `seq`; each colour is capped at n / ncolor_in nodes and
+// neighbours of a chosen node are blocked for the current colour only.
+// Out: perm (new -> old, 0-based) colour by colour, colorindex (ncolor+1 entries).
+void multicolor(const Graph &g, const std::vector<int32_t> &seq, int ncolor_in, std::vector<int32_t> &perm,
+                std::vector<int32_t> &colorindex) {
+  const int32_t n = g.n;
+  const int32_t cap = n / ncolor_in;
+  std::vector<int32_t> mark((size_t)n, 0);  // >0 coloured, -1 blocked this round
+  std::vector<int32_t> blocked;
+  perm.clear();
+  perm.reserve(n);
+  colorindex.assign(1, 0);
+  for (int32_t color = 1; (int32_t)perm.size() < n; color++) {
+    int32_t cnt = 0;
+    blocked.clear();
+    for (int32_t q = 0; q < n; q++) {
+      const int32_t u = seq[q];
+      if (mark[u] != 0) continue;
+      mark[u] = color;
+      perm.push_back(u);
+      cnt++;
+      if (cnt == cap || (int32_t)perm.size() == n) break;
+      for (int64_t e = g.ptr[u]; e < g.ptr[u + 1]; e++) {
+        const int32_t v = g.adj[e];
+        if (mark[v] == 0) { mark[v] = -1; blocked.push_back(v); }
+      }
+    }
+    colorindex.push_back((int32_t)perm.size());
+    for (int32_t v : blocked)
+      if (mark[v] == -1) mark[v] = 0;
+  }
+}
+
+}  // namespace fxo

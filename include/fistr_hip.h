@@ -1,0 +1,155 @@
+/* fistr_hip.h -- C ABI of the MI355X-native HEC-MW linear-solve hot path.
+ *
+ * Drop-in boundary.  The reference exposes Fortran module
+ * procedures only; the entry points below are what a thin Fortran shim
+ * (frontistr_amd/shim/hecmw_solver_hip.f90) binds with
+ * bind(C) after taking c_loc() of the members of hecmwST_matrix /
+ * hecmwST_local_mesh.  Plain pointers and sizes only.
+ *
+ * Conventions are the reference's (hecmw1/src/common/hecmw_util_f.F90:15-16,
+ * :433-468): int32 indices, 1-based `item` arrays, `index` arrays with NP+1
+ * entries starting at 0, fp64 values, 3x3 blocks row-major (A(9j-8..9j) = row 1,
+ * row 2, row 3 of block j).
+ *
+ * All functions return 0 on success, a HEC-MW solver code (fx_status) for the
+ * conditions the reference reports through hecmw_solve_error
+ * (hecmw1/src/solver/init/hecmw_solve_error.f90:9-15), or a negative value for
+ * a HIP/RCCL runtime failure (fx_last_error() then holds the message).
+ */
+#ifndef FISTR_HIP_H
+#define FISTR_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* hecmw_solve_error.f90:9-15 */
+enum fx_status {
+  FX_OK = 0,
+  FX_ERROR_INCONS_PC = 1001,    /* E: inconsistent solver/preconditioner        */
+  FX_ERROR_ZERO_DIAG = 2001,    /* E: zero component in diagonal block          */
+  FX_ERROR_ZERO_RHS = 2002,     /* W: zero RHS norm (X = 0 is returned)         */
+  FX_ERROR_NOCONV_MAXIT = 3001, /* W: not converged within ceratin iterations   */
+  FX_ERROR_DIVERGE_MAT = 3002,  /* W: diverged due to indefinite/neg-def matrix */
+  FX_ERROR_DIVERGE_PC = 3003,   /* W: diverged due to indefinite preconditioner */
+  FX_ERROR_RUNTIME = -1,        /* HIP / RCCL failure, see fx_last_error()      */
+  FX_ERROR_UNSUPPORTED = -2     /* NDOF != 3, or an option outside the hot path */
+};
+
+/* Borrowed view of hecmwST_matrix (hecmw_util_f.F90:433-468).  The caller owns
+ * every array (m_fstr.f90:807-857 allocates them once); the library writes X
+ * (all 3*NP entries, halo included: hecmw_solver_CG.f90:280) and never frees or
+ * reallocates anything. */
+typedef struct fx_matrix_view {
+  int32_t N, NP, NPL, NPU, NDOF;
+  const int32_t *indexL, *itemL; /* (0:NP), (NPL) */
+  const int32_t *indexU, *itemU; /* (0:NP), (NPU) */
+  const double *D, *AL, *AU;     /* 9*NP, 9*NPL, 9*NPU */
+  const double *B;               /* 3*NP */
+  double *X;                     /* 3*NP, in: initial guess, out: solution */
+} fx_matrix_view;
+
+/* Borrowed view of the communication part of hecmwST_local_mesh
+ * (hecmw_util_f.F90:298-310).  Serial runs pass n_neighbor_pe = 0 and PETOT = 1
+ * (or a NULL pointer). */
+typedef struct fx_comm_view {
+  int32_t my_rank, PETOT, nn_internal, n_node;
+  int32_t n_neighbor_pe;
+  const int32_t *neighbor_pe;  /* ranks, 0-based as in HEC-MW */
+  const int32_t *import_index; /* (0:n_neighbor_pe) */
+  const int32_t *import_item;  /* 1-based local node ids (> nn_internal) */
+  const int32_t *export_index; /* (0:n_neighbor_pe) */
+  const int32_t *export_item;  /* 1-based local node ids (<= nn_internal) */
+} fx_comm_view;
+
+/* What the reference prints / keeps per solve (hecmw_solver_Iterative.f90:192-208). */
+typedef struct fx_solve_info {
+  int32_t iterations;     /* ITER as in the '### summary of linear solver' line        */
+  int32_t method, precond;
+  int32_t ncolor;         /* SSOR: number of colours actually used                     */
+  int32_t n_hist;         /* residual-history entries written                          */
+  double resid;           /* RESID of the last iteration (sqrt(DNRM2/BNRM2))           */
+  double rel_resid;       /* final ||b-Ax||/||b|| (hecmw_rel_resid_L2)                 */
+  double time_setup, time_sol, time_comm, time_matvec, time_precond; /* seconds       */
+} fx_solve_info;
+
+typedef struct fx_context fx_context; /* device state the reference keeps in module `save` data */
+
+/* ---- life cycle ------------------------------------------------------- */
+/* device < 0: use LOCAL_RANK (or 0).  One context per MPI rank / subdomain. */
+int fx_create(int device, fx_context **out);
+void fx_destroy(fx_context *ctx);
+const char *fx_last_error(void);
+const char *fx_version(void);
+int fx_device_synchronize(fx_context *ctx);
+
+/* ---- the drop-in pair --------------------------------------------------- */
+/* hecmw_solve(hecMESH, hecMAT), hecmw1/src/solver/hecmw_solver.f90:9 ->
+ * hecmw_solve_iterative, iterative/hecmw_solver_Iterative.f90:13.
+ * Iarray/Rarray are hecMAT%Iarray/Rarray (slot map hecmw_matrix_misc.f90:89-121);
+ * on return Iarray(81) converged, (82) diverged, (96) nrecycle, (97),(98) are
+ * updated exactly as the reference does.  hist (may be NULL) receives RESID per
+ * iteration = the ITERLOG channel (hecmw_solver_CG.f90:245), at most hist_len. */
+int fx_solve(fx_context *ctx, const fx_matrix_view *mat, const fx_comm_view *comm, int32_t *Iarray,
+             double *Rarray, fx_solve_info *info, double *hist, int32_t hist_len);
+
+/* hecmw_matvec(hecMESH, hecMAT, X, Y, COMMtime), las/hecmw_solver_las.f90:57:
+ * halo update of X (X's halo part is written, as hecmw_update_3_R does), then
+ * Y(1:3N) = (D + AL + AU) X.  x, y are host arrays of 3*NP doubles. */
+int fx_matvec(fx_context *ctx, const fx_matrix_view *mat, const fx_comm_view *comm, double *x,
+              double *y, double *commtime);
+
+/* ---- staged, device-resident form (what fx_solve is made of) ------------ */
+/* Upload / refresh the system.  what: bit 0 profile (Iarray(98) semantics),
+ * bit 1 values (Iarray(97)), bit 2 B, bit 3 X. */
+enum { FX_UP_PROFILE = 1, FX_UP_VALUES = 2, FX_UP_RHS = 4, FX_UP_X = 8, FX_UP_ALL = 15 };
+int fx_upload(fx_context *ctx, const fx_matrix_view *mat, const fx_comm_view *comm, int what);
+/* hecmw_precond_setup, precond/hecmw_precond.f90:28-50 (DIAG_33 / SSOR_33 / BILU_33). */
+int fx_precond_setup(fx_context *ctx, const int32_t *Iarray, const double *Rarray);
+/* hecmw_solve_CG / hecmw_solve_BiCGSTAB on the resident system; no host<->device
+ * traffic except the status word.  This is the region bench.py times. */
+int fx_solve_resident(fx_context *ctx, int32_t *Iarray, double *Rarray, fx_solve_info *info,
+                      double *hist, int32_t hist_len);
+int fx_download_x(fx_context *ctx, double *X, int32_t n);          /* 3*NP doubles */
+int fx_download_matrix(fx_context *ctx, double *D, double *AL, double *AU, double *B);
+/* Resident single operations (tests, roofline timing). */
+int fx_matvec_resident(fx_context *ctx, int nrepeat, float *ms_per_call); /* y = A x on work vectors */
+int fx_precond_apply_host(fx_context *ctx, const double *r, double *z);   /* z = M^-1 r, 3*NP doubles */
+int fx_dot_host(fx_context *ctx, const double *x, const double *y, double *result);
+
+/* ---- assembly side ------------------------------------------------------ */
+/* hecmw_mat_con, matrix/hecmw_mat_con.f90:23: CRS block profile from element
+ * connectivity (conn 1-based, nn nodes per element).  Two-call protocol: with
+ * itemL == NULL only indexL/indexU (NP+1 each) are filled. */
+int fx_mat_con(int32_t NP, int32_t n_elem, int32_t nn, const int32_t *conn, int32_t *indexL,
+               int32_t *indexU, int32_t *itemL, int32_t *itemU);
+
+/* fstr_StiffMatrix (fistr1/src/analysis/static/fstr_StiffMatrix.f90:18-212) for one
+ * TYPE=361 element group with one isotropic linear-elastic material, then
+ * hecmw_mat_ass_bc (matrix/hecmw_mat_ass.f90:292) for the listed dofs:
+ * element stiffness (elemopt 1 = C3D8 incompatible modes STF_C3D8IC, 2 = B-bar
+ * STF_C3D8Bbar, 3 = full integration STF_C3) and scatter-add run on the device
+ * into the resident D/AL/AU; `load` (3*NP, may be NULL) becomes B.
+ * Requires a profile uploaded with fx_upload(..., FX_UP_PROFILE). */
+typedef struct fx_mesh_view {
+  int32_t n_node, n_elem;
+  const double *coord;  /* 3*n_node, hecMESH%node */
+  const int32_t *conn;  /* 8*n_elem, 1-based, hecMESH%elem_node_item */
+} fx_mesh_view;
+int fx_assemble_c3d8(fx_context *ctx, const fx_mesh_view *mesh, double E, double nu, int elemopt,
+                     const double *load, int32_t n_bc, const int32_t *bc_node,
+                     const int32_t *bc_dof, const double *bc_val, float *ms_assemble);
+/* One element stiffness through the device kernel (tests): ecoord 8x3, stiff 24x24 row-major. */
+int fx_element_stiffness_c3d8(fx_context *ctx, int elemopt, const double *ecoord, double E, double nu,
+                              double *stiff);
+
+/* ---- multi-GPU (one process per GPU, RCCL over xGMI) -------------------- */
+/* 128-byte ncclUniqueId made by rank 0 and broadcast by the host side
+ * (torch.distributed / MPI); then every rank calls fx_comm_init. */
+int fx_comm_unique_id(unsigned char id[128]);
+int fx_comm_init(fx_context *ctx, const unsigned char id[128], int rank, int nranks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FISTR_HIP_H */
