@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- CG iterations/sec + SpMV achieved HBM GB/s on the 10M-DOF 3x3-block hex mesh
+(BASELINE.json metric; configs[2]: synthetic 10M-DOF linear-elastic hex mesh, CG + SSOR(1), fp64).
+
+One "step" = one preconditioned-CG iteration of hecmw_solve_CG (precond apply, 3 dots,
+SpMV, 3 AXPYs) on the device-resident system.  Everything is resident in HBM before the
+timed region: the matrix is assembled ON the device (fx_assemble_c3d8) from the synthetic
+mesh, the multicolour SSOR is set up, r0/||b|| are computed; then W untimed + exactly K timed
+iterations run between barrier + synchronize pairs.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the global cube is split into
+px*py*pz node-based overlapping subdomains of 150^3 internal nodes each (weak scaling, the
+reference's own decomposition model); SpMV halo exchange and the dot-product all-reduces go
+through RCCL inside the library.
+
+The JSON line also carries
+  roofline     : the dominant kernel (BELL-64 SpMV) timed live with HIP events on the solver
+                 stream; achieved = algorithmic bytes (72*nb + 4*(nb-N) + 8*(N+1) +
+                 48*N) / time, peak 8 TB/s (MI355X_MICROARCH.md)
+  cpu_baseline : the REAL reference (oracle/_ref/ref_solve_omp, HEC-MW compiled from
+                 /root/reference with flang -fopenmp) timed on this box's host cores on a
+                 bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def decomposition(n):
+    return {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}.get(n) or (n, 1, 1)
+
+
+def spmv_algorithmic_bytes(N, nb):
+    # values + column ids + row index (both halves) + x once + y once
+    return 72 * nb + 4 * (nb - N) + 2 * 4 * (N + 1) + 24 * N + 24 * N
+
+
+def cpu_baseline(hip, n_sample, iters, cores):
+    """Reference CG + multicolour SSOR on a (n_sample+1)^3-node cube, `iters` iterations."""
+    from frontistr_amd.mesh import CubeMesh
+    from oracle import refrun
+    if not refrun.have_ref("ref_solve_omp"):
+        return None
+    mesh = CubeMesh(n_sample)
+    hm = hip.hecmwST_local_mesh(n_node=mesh.n_node)
+    hm.elem_node_item = mesh.conn.ravel()
+    m = hip.hecmw_mat_con(hm, hip.hecmwST_matrix())
+    ctx = hip.SolverContext()
+    ctx.upload(m, what=hip.FX_UP_PROFILE)
+    ctx.assemble_c3d8(mesh.coord, mesh.conn, 210000.0, 0.3, elemopt=1, load=mesh.load(), bc=mesh.dirichlet())
+    ctx.download_matrix(m)          # the sample system is exactly what the GPU path assembled
+    ctx.close()
+    A = refrun.BSR(m.N, m.NP, m.indexL, m.itemL, m.indexU, m.itemU, m.D, m.AL, m.AU, m.B)
+    I, R = refrun.default_params(method=1, precond=1, maxit=iters, tol=1e-30, iterlog=0, timelog=1)
+    wd = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    r = refrun.run_solve(A, I, R, threads=cores, workdir=wd, timeout=900)
+    if "t_per_iter" not in r or r["t_per_iter"] <= 0:
+        return None
+    return dict(per_iter=r["t_per_iter"], solver=r.get("t_solver"), setup=r.get("t_setup"),
+                matvec=r.get("t_matvec"), precond=r.get("t_precond"), ndof=3 * mesh.n_node)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--n", type=int, default=149, help="elements per edge per GPU (149 -> 150^3 nodes = 10.125M DOF)")
+    ap.add_argument("--precond", type=int, default=1, help="1 SSOR (config 3), 3 block-Jacobi (config 2)")
+    ap.add_argument("--method", type=int, default=1, help="1 CG, 2 BiCGSTAB")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-n", type=int, default=69)
+    ap.add_argument("--cpu-sample-iters", type=int, default=40)
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from frontistr_amd import hecmw as hip
+    from frontistr_amd.mesh import CubeMesh
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libfistr_hip has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    t_setup0 = time.time()
+    ctx = hip.SolverContext(device=local_rank)
+    E, NU = 210000.0, 0.3
+    if world == 1:
+        mesh = CubeMesh(a.n)
+        hm = hip.hecmwST_local_mesh(n_node=mesh.n_node)
+        coord, conn, load, bc = mesh.coord, mesh.conn, mesh.load(), mesh.dirichlet()
+    else:
+        from frontistr_amd.partition import cube_subdomain
+        if rank == 0:
+            uid = torch.tensor(list(hip.comm_unique_id()), dtype=torch.uint8, device="cuda")
+        else:
+            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        dist.broadcast(uid, 0)
+        ctx.comm_init(bytes(uid.cpu().tolist()), rank, world)
+        sub = cube_subdomain(a.n + 1, decomposition(world), rank)
+        hm = sub.hecmesh(hip)
+        coord, conn, load, bc = sub.coord, sub.conn, sub.load(), sub.dirichlet()
+    hm.elem_node_item = conn.ravel()
+    m = hip.hecmw_mat_con(hm, hip.hecmwST_matrix())
+    t_con = time.time() - t_setup0
+    ctx.upload(m, hm, what=hip.FX_UP_PROFILE)
+    ms_asm = ctx.assemble_c3d8(coord, conn, E, NU, elemopt=1, load=load, bc=bc)
+    m.Iarray[0] = a.warmup + a.steps + 8          # MAXIT: never reached inside the timed region
+    m.Iarray[1] = a.method
+    m.Iarray[2] = a.precond
+    m.Rarray[0] = 1.0e-30                          # tolerance far below reach: no early exit
+    t0 = time.time()
+    ctx.precond_setup(m)
+    t_pre = time.time() - t0
+    st = ctx.stats()
+    N, nb = st["N"], st["M_blocks"]
+
+    ctx.krylov_begin(m)
+    it, status, resid = ctx.krylov_steps(a.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    it, status, resid = ctx.krylov_steps(a.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    assert status == 0 and it == a.warmup + a.steps + 1, (status, it)
+    assert np.isfinite(resid)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # roofline of the dominant kernel, timed live with HIP events on the solver stream
+    ms_spmv = ctx.matvec_resident_ms(20)
+    ms_prec = ctx.precond_apply_ms(10)
+    alg = spmv_algorithmic_bytes(N, nb)
+    achieved = alg / (ms_spmv * 1e-3) / 1e9
+    # streamed bytes of one SSOR apply: L and U blocks (values + column ids), ALU twice, r once, z r/w twice
+    if a.precond == 1:
+        prec_bytes = 76 * (st["L_blocks"] + st["U_blocks"]) + 2 * 72 * N + 24 * N + 4 * 24 * N
+    else:
+        prec_bytes = 72 * N + 48 * N
+    bell_pad = 2.0 * st["M_pairs"] * 64 / max(nb, 1) - 1.0
+
+    out = {
+        "metric": "CG iterations/sec + SpMV achieved HBM GB/s, 10M-DOF 3x3-block mesh",
+        "value": a.steps / dt,
+        "unit": "CG iterations/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": 1e3 * dt / a.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "synthetic %d^3-node linear-elastic C3D8 cube per GPU (%.3fM DOF/GPU, %.2fM DOF total), %s + %s, fp64"
+                        % (a.n + 1, 3 * N / 1e6, 3 * N * world / 1e6, {1: "CG", 2: "BiCGSTAB"}[a.method],
+                           {1: "SSOR(1) multicolour", 3: "block-Jacobi"}[a.precond]),
+            "decomposition": "x".join(str(d) for d in decomposition(world)),
+            "ncolor": st["ncolor"],
+            "block_rows": N, "blocks": nb,
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": "k_spmv (BELL-64 3x3-block SpMV)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "algorithmic_bytes": alg, "ms_per_launch": ms_spmv,
+            "bell_padding_frac": bell_pad,
+            "precond_apply": {"ms": ms_prec, "algorithmic_bytes": prec_bytes,
+                              "achieved_GBs": prec_bytes / (ms_prec * 1e-3) / 1e9},
+            "iteration_GBs": (alg + prec_bytes + 480 * N) / (dt / a.steps) / 1e9,
+        },
+        "setup_s": {"mat_con": t_con, "assemble_ms": ms_asm, "precond_setup": t_pre},
+        "resid_after_steps": resid,
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cores = max(1, min(len(os.sched_getaffinity(0)), 16))
+        try:
+            cb = cpu_baseline(hip, a.cpu_sample_n, a.cpu_sample_iters, cores)
+        except Exception as e:  # the baseline is reporting only; never fail the bench on it
+            cb = None
+            out["cpu_baseline_error"] = repr(e)
+        if cb:
+            scale = cb["ndof"] / (3.0 * N)      # memory-bound sweeps: time per iteration ~ DOF
+            out["cpu_baseline"] = {
+                "value": (1.0 / cb["per_iter"]) * scale, "unit": "CG iterations/s", "cores": cores,
+                "kind": "reference",
+                "sample": "HEC-MW reference (flang -fopenmp, OMP_NUM_THREADS=%d) CG+SSOR multicolour on a %d^3-node cube "
+                          "(%.2fM DOF), %d iterations: %.4f s/iter measured = %.2f it/s; value = that rate scaled by DOF "
+                          "ratio %.4f to the %.2fM-DOF workload"
+                          % (cores, a.cpu_sample_n + 1, cb["ndof"] / 1e6, a.cpu_sample_iters, cb["per_iter"],
+                             1.0 / cb["per_iter"], scale, 3 * N / 1e6),
+                "measured_it_per_s_at_sample": 1.0 / cb["per_iter"],
+                "sample_matvec_s": cb.get("matvec"), "sample_precond_s": cb.get("precond"),
+            }
+    if rank == 0:
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

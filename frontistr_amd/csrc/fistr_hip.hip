@@ -676,113 +676,150 @@ static int poll_state(fx_context *c, KrylovState *out) {
   return 0;
 }
 
-// hecmw_solve_CG, hecmw_solver_CG.f90:19-312
-static int run_cg(fx_context *c, int maxit, double tol, KrylovState *fin) {
+// hecmw_solve_CG (hecmw_solver_CG.f90:19-312) / hecmw_solve_BiCGSTAB (hecmw_solver_BiCGSTAB.f90:16-297)
+// split into begin (r0, ||b||) / steps (n iterations enqueued) / poll, so that callers can
+// time an exact number of iterations with nothing else in the bracket.
+static int krylov_begin(fx_context *c, int method, int maxit, double tol) {
+  const int64_t n3 = (int64_t)3 * c->nn_internal;
+  double *X = c->A.X, *B = c->A.B, *R = c->W[0];
+  int np;
+  c->k_method = method; c->k_maxit = maxit; c->k_it = 1;
+  if (krylov_init_state(c, maxit, tol)) return FX_ERROR_RUNTIME;
+  HIP_TRY(hipMemsetAsync(c->W[2], 0, (size_t)c->wlen * 8, c->stream));  // P
+  if (method == 2) HIP_TRY(hipMemsetAsync(c->W[6], 0, (size_t)c->wlen * 8, c->stream));  // V
+  // r0 = b - A x0 (CG :120 / BiCGSTAB :107) ; ||b||^2 (:123-129 / :115-121)
+  if (spmv(c, 1, 0, X, B, R, nullptr, 0)) return FX_ERROR_RUNTIME;
+  if (method == 2) {
+    hipLaunchKernelGGL(k_copy, dim3(grid_for(n3, FX_BLOCK, 2048)), dim3(256), 0, c->stream, n3, R, c->W[1]);  // r_tld = r0
+  }
+  if (dot_into_partials(c, B, B, nullptr, 0, &np)) return FX_ERROR_RUNTIME;
+  if (scalar_stage<OP_BNRM2>(c, np, 0, 50)) return FX_ERROR_RUNTIME;
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+static int cg_iteration(fx_context *c, int it) {
   const int64_t n3 = (int64_t)3 * c->nn_internal;
   double *R = c->W[0], *Z = c->W[1], *Q = c->W[1], *P = c->W[2];
   double *X = c->A.X, *B = c->A.B;
   const int RECOMPUTE = 50;
-  int np;
-  if (krylov_init_state(c, maxit, tol)) return FX_ERROR_RUNTIME;
-  HIP_TRY(hipMemsetAsync(P, 0, (size_t)c->wlen * 8, c->stream));
-  // r0 = b - A x0 (:120) ; ||b||^2 (:123-129)
-  if (spmv(c, 1, 0, X, B, R, nullptr, 0)) return FX_ERROR_RUNTIME;
-  if (dot_into_partials(c, B, B, nullptr, 0, &np)) return FX_ERROR_RUNTIME;
-  if (scalar_stage<OP_BNRM2>(c, np, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
   const int vgrid = grid_for(n3, FX_BLOCK, 2048);
-  const int chunk = 16;
-  KrylovState s;
-  for (int it = 1; it <= maxit; it++) {
-    // z = M^-1 r (:160) with the partial of rho = r.z (:168) fused in
-    if (precond_apply(c, R, Z, true, &np)) return FX_ERROR_RUNTIME;
-    if (np == 0 && dot_into_partials(c, R, Z, gate_status(c), 0, &np)) return FX_ERROR_RUNTIME;
-    if (scalar_stage<OP_CG_RHO>(c, np, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
-    // p = z + beta p (:188-197)
-    hipLaunchKernelGGL(k_cg_update_p, dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, n3, c->st, Z, P);
-    // q = A p (:204) + partial of p.q (:211)
-    if (spmv(c, 0, 1, P, nullptr, Q, gate_status(c), 0)) return FX_ERROR_RUNTIME;
-    if (scalar_stage<OP_CG_C1>(c, spmv_nparts(c), 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
-    // x += alpha p ; r -= alpha q | r = b - A x every 50 iterations (:227-238) ; ||r||^2 (:240)
-    if (it % RECOMPUTE == 0) {
-      hipLaunchKernelGGL((k_cg_update_xr<false>), dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, n3, c->st, P, Q, X, R, c->partials);
-      if (spmv(c, 1, 2, X, B, R, gate_status(c), 0)) return FX_ERROR_RUNTIME;
-      np = spmv_nparts(c);
-    } else {
-      hipLaunchKernelGGL((k_cg_update_xr<true>), dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, n3, c->st, P, Q, X, R, c->partials);
-      np = vgrid;
-    }
-    if (scalar_stage<OP_RESID>(c, np, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
-    // converged by the recurrence: recompute the true residual and re-test (:259-266)
-    if (it % RECOMPUTE != 0) {
-      if (spmv(c, 1, 2, X, B, R, gate_verify(c), 1)) return FX_ERROR_RUNTIME;
-      if (scalar_stage<OP_VERIFY>(c, spmv_nparts(c), 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
-    }
-    HIP_TRY(hipGetLastError());
-    if (it % chunk == 0 || it == maxit) {
-      if (poll_state(c, &s)) return FX_ERROR_RUNTIME;
-      if (s.status != 0) break;
-    }
+  int np;
+  // z = M^-1 r (:160) with the partial of rho = r.z (:168) fused in
+  if (precond_apply(c, R, Z, true, &np)) return FX_ERROR_RUNTIME;
+  if (np == 0 && dot_into_partials(c, R, Z, gate_status(c), 0, &np)) return FX_ERROR_RUNTIME;
+  if (scalar_stage<OP_CG_RHO>(c, np, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
+  // p = z + beta p (:188-197)
+  hipLaunchKernelGGL(k_cg_update_p, dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, n3, c->st, Z, P);
+  // q = A p (:204) + partial of p.q (:211)
+  if (spmv(c, 0, 1, P, nullptr, Q, gate_status(c), 0)) return FX_ERROR_RUNTIME;
+  if (scalar_stage<OP_CG_C1>(c, spmv_nparts(c), 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
+  // x += alpha p ; r -= alpha q | r = b - A x every 50 iterations (:227-238) ; ||r||^2 (:240)
+  if (it % RECOMPUTE == 0) {
+    hipLaunchKernelGGL((k_cg_update_xr<false>), dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, n3, c->st, P, Q, X, R, c->partials);
+    if (spmv(c, 1, 2, X, B, R, gate_status(c), 0)) return FX_ERROR_RUNTIME;
+    np = spmv_nparts(c);
+  } else {
+    hipLaunchKernelGGL((k_cg_update_xr<true>), dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, n3, c->st, P, Q, X, R, c->partials);
+    np = vgrid;
   }
-  if (poll_state(c, &s)) return FX_ERROR_RUNTIME;
-  *fin = s;
+  if (scalar_stage<OP_RESID>(c, np, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
+  // converged by the recurrence: recompute the true residual and re-test (:259-266)
+  if (it % RECOMPUTE != 0) {
+    if (spmv(c, 1, 2, X, B, R, gate_verify(c), 1)) return FX_ERROR_RUNTIME;
+    if (scalar_stage<OP_VERIFY>(c, spmv_nparts(c), 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
+  }
+  HIP_TRY(hipGetLastError());
   return 0;
 }
 
-// hecmw_solve_BiCGSTAB, hecmw_solver_BiCGSTAB.f90:16-297
-static int run_bicgstab(fx_context *c, int maxit, double tol, KrylovState *fin) {
+static int bicgstab_iteration(fx_context *c, int it) {
   const int64_t n3 = (int64_t)3 * c->nn_internal;
   // R=1 RT=2 P=3 PT=4 S=5 ST=1 T=6 V=7 (:45-53); ST aliases R as in the reference
   double *R = c->W[0], *RT = c->W[1], *P = c->W[2], *PT = c->W[3], *S = c->W[4], *ST = c->W[0], *T = c->W[5], *V = c->W[6];
   double *X = c->A.X, *B = c->A.B;
   const int RECOMPUTE = 100;
-  int np;
-  if (krylov_init_state(c, maxit, tol)) return FX_ERROR_RUNTIME;
-  HIP_TRY(hipMemsetAsync(P, 0, (size_t)c->wlen * 8, c->stream));
-  HIP_TRY(hipMemsetAsync(V, 0, (size_t)c->wlen * 8, c->stream));
-  if (spmv(c, 1, 0, X, B, R, nullptr, 0)) return FX_ERROR_RUNTIME;
   const int vgrid = grid_for(n3, FX_BLOCK, 2048);
-  hipLaunchKernelGGL(k_copy, dim3(vgrid), dim3(256), 0, c->stream, n3, R, RT);
-  if (dot_into_partials(c, B, B, nullptr, 0, &np)) return FX_ERROR_RUNTIME;
-  if (scalar_stage<OP_BNRM2>(c, np, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
-  const int chunk = 8;
+  int np;
+  if (dot_into_partials(c, R, RT, gate_status(c), 0, &np)) return FX_ERROR_RUNTIME;           // :152
+  if (scalar_stage<OP_BI_RHO>(c, np, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
+  hipLaunchKernelGGL(k_bi_update_p, dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, n3, c->st, R, V, P);  // :160-170
+  if (precond_apply(c, P, PT, false, &np)) return FX_ERROR_RUNTIME;                            // :177
+  if (spmv(c, 0, 0, PT, nullptr, V, gate_status(c), 0)) return FX_ERROR_RUNTIME;               // :184
+  if (dot_into_partials(c, RT, V, gate_status(c), 0, &np)) return FX_ERROR_RUNTIME;            // :188
+  if (scalar_stage<OP_BI_C2>(c, np, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
+  hipLaunchKernelGGL(k_bi_update_s, dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, n3, c->st, R, V, S);  // :194-196
+  if (precond_apply(c, S, ST, false, &np)) return FX_ERROR_RUNTIME;                            // :203
+  if (spmv(c, 0, 0, ST, nullptr, T, gate_status(c), 0)) return FX_ERROR_RUNTIME;               // :210
+  hipLaunchKernelGGL(k_dot2, dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, n3, T, S, c->partials, c->max_partials,
+                     gate_status(c));                                                          // :217-218
+  if (scalar_stage<OP_BI_OMEGA>(c, vgrid, c->max_partials, RECOMPUTE)) return FX_ERROR_RUNTIME;
+  if (it % RECOMPUTE == 0) {                                                                   // :231-241
+    hipLaunchKernelGGL((k_bi_update_xr<false>), dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, n3, c->st, PT, ST, S, T, X, R,
+                       c->partials);
+    if (spmv(c, 1, 2, X, B, R, gate_status(c), 0)) return FX_ERROR_RUNTIME;
+    np = spmv_nparts(c);
+  } else {
+    hipLaunchKernelGGL((k_bi_update_xr<true>), dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, n3, c->st, PT, ST, S, T, X, R,
+                       c->partials);
+    np = vgrid;
+  }
+  if (scalar_stage<OP_RESID>(c, np, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
+  if (it % RECOMPUTE != 0) {
+    if (spmv(c, 1, 2, X, B, R, gate_verify(c), 1)) return FX_ERROR_RUNTIME;
+    if (scalar_stage<OP_VERIFY>(c, spmv_nparts(c), 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// Enqueue up to n iterations (never past MAXIT).  The host polls the device status word
+// every `chunk` iterations only; once the device has left the RUNNING state the already
+// enqueued kernels are no-ops.  *st_out is the state after the last poll.
+static int krylov_steps(fx_context *c, int n, KrylovState *st_out) {
+  const int chunk = (c->k_method == 1) ? 16 : 8;
   KrylovState s;
-  for (int it = 1; it <= maxit; it++) {
-    if (dot_into_partials(c, R, RT, gate_status(c), 0, &np)) return FX_ERROR_RUNTIME;           // :152
-    if (scalar_stage<OP_BI_RHO>(c, np, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
-    hipLaunchKernelGGL(k_bi_update_p, dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, n3, c->st, R, V, P);  // :160-170
-    if (precond_apply(c, P, PT, false, &np)) return FX_ERROR_RUNTIME;                            // :177
-    if (spmv(c, 0, 0, PT, nullptr, V, gate_status(c), 0)) return FX_ERROR_RUNTIME;               // :184
-    if (dot_into_partials(c, RT, V, gate_status(c), 0, &np)) return FX_ERROR_RUNTIME;            // :188
-    if (scalar_stage<OP_BI_C2>(c, np, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
-    hipLaunchKernelGGL(k_bi_update_s, dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, n3, c->st, R, V, S);  // :194-196
-    if (precond_apply(c, S, ST, false, &np)) return FX_ERROR_RUNTIME;                            // :203
-    if (spmv(c, 0, 0, ST, nullptr, T, gate_status(c), 0)) return FX_ERROR_RUNTIME;               // :210
-    hipLaunchKernelGGL(k_dot2, dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, n3, T, S, c->partials, c->max_partials,
-                       gate_status(c));                                                          // :217-218
-    if (scalar_stage<OP_BI_OMEGA>(c, vgrid, c->max_partials, RECOMPUTE)) return FX_ERROR_RUNTIME;
-    if (it % RECOMPUTE == 0) {                                                                   // :231-241
-      hipLaunchKernelGGL((k_bi_update_xr<false>), dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, n3, c->st, PT, ST, S, T, X, R,
-                         c->partials);
-      if (spmv(c, 1, 2, X, B, R, gate_status(c), 0)) return FX_ERROR_RUNTIME;
-      np = spmv_nparts(c);
-    } else {
-      hipLaunchKernelGGL((k_bi_update_xr<true>), dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, n3, c->st, PT, ST, S, T, X, R,
-                         c->partials);
-      np = vgrid;
-    }
-    if (scalar_stage<OP_RESID>(c, np, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
-    if (it % RECOMPUTE != 0) {
-      if (spmv(c, 1, 2, X, B, R, gate_verify(c), 1)) return FX_ERROR_RUNTIME;
-      if (scalar_stage<OP_VERIFY>(c, spmv_nparts(c), 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
-    }
-    HIP_TRY(hipGetLastError());
-    if (it % chunk == 0 || it == maxit) {
+  memset(&s, 0, sizeof s);
+  int done = 0;
+  while (done < n && c->k_it <= c->k_maxit) {
+    const int it = c->k_it;
+    const int e = (c->k_method == 1) ? cg_iteration(c, it) : bicgstab_iteration(c, it);
+    if (e) return e;
+    c->k_it++;
+    done++;
+    if (done % chunk == 0 || done == n || it == c->k_maxit) {
       if (poll_state(c, &s)) return FX_ERROR_RUNTIME;
       if (s.status != 0) break;
     }
   }
   if (poll_state(c, &s)) return FX_ERROR_RUNTIME;
-  *fin = s;
+  *st_out = s;
+  return 0;
+}
+
+static int run_krylov(fx_context *c, int method, int maxit, double tol, KrylovState *fin) {
+  if (krylov_begin(c, method, maxit, tol)) return FX_ERROR_RUNTIME;
+  return krylov_steps(c, maxit, fin);
+}
+
+extern "C" int fx_krylov_begin(fx_context *c, const int32_t *Iarray, const double *Rarray) {
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->have_values || !c->precond_valid) { g_fx_error = "fx_krylov_begin: matrix / preconditioner not resident"; return FX_ERROR_RUNTIME; }
+  if (Iarray[1] != 1 && Iarray[1] != 2) { g_fx_error = "METHOD must be 1 (CG) or 2 (BiCGSTAB)"; return FX_ERROR_INCONS_PC; }
+  const int e = krylov_begin(c, Iarray[1], Iarray[0], Rarray[0]);
+  if (e) return e;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int fx_krylov_steps(fx_context *c, int32_t nsteps, int32_t *iter, int32_t *status, double *resid) {
+  HIP_TRY(hipSetDevice(c->device));
+  KrylovState s;
+  const int e = krylov_steps(c, nsteps, &s);
+  if (e) return e;
+  if (iter) *iter = s.iter;
+  if (status) *status = s.status;
+  if (resid) *resid = s.resid;
   return 0;
 }
 
@@ -855,8 +892,7 @@ extern "C" int fx_solve_resident(fx_context *c, int32_t *Iarray, double *Rarray,
   for (;;) {
     Iarray[80] = 0; Iarray[81] = 0;
     int e;
-    if (method == 1) e = run_cg(c, maxit, tol, &s);
-    else if (method == 2) e = run_bicgstab(c, maxit, tol, &s);
+    if (method == 1 || method == 2) e = run_krylov(c, method, maxit, tol, &s);
     else { g_fx_error = "METHOD must be 1 (CG) or 2 (BiCGSTAB) on the GPU hot path"; return FX_ERROR_INCONS_PC; }
     if (e) return e;
     if (s.status == FX_ERROR_DIVERGE_PC || s.status == FX_ERROR_DIVERGE_MAT) {  // :145-156
@@ -981,6 +1017,38 @@ extern "C" int fx_dot_host(fx_context *c, const double *x, const double *y, doub
   double tmp;
   if (dot_into_partials(c, c->W[6], c->W[7], nullptr, 0, &np)) return FX_ERROR_RUNTIME;
   return host_sum(c, np, 0, result, &tmp);
+}
+
+// z = M^-1 r on resident work vectors, timed with HIP events on the solver stream.
+extern "C" int fx_precond_apply_resident(fx_context *c, int nrepeat, float *ms_per_call) {
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->precond_valid) { g_fx_error = "fx_precond_apply_resident: preconditioner not set up"; return FX_ERROR_RUNTIME; }
+  KrylovState s;
+  memset(&s, 0, sizeof s);
+  HIP_TRY(hipMemcpyAsync(c->st, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
+  int np;
+  HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  for (int i = 0; i < nrepeat; i++)
+    if (precond_apply(c, c->A.B, c->W[7], true, &np)) return FX_ERROR_RUNTIME;
+  HIP_TRY(hipEventRecord(c->ev1, c->stream));
+  HIP_TRY(hipEventSynchronize(c->ev1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  if (ms_per_call) *ms_per_call = ms / std::max(nrepeat, 1);
+  return 0;
+}
+
+// Sizes of the resident structures (for the algorithmic-bytes accounting of bench.py).
+// out[0] N, [1] NP, [2] NPL, [3] NPU, [4] M.npairs, [5] M.nblocks, [6] M.nslices,
+// [7] ssor.ncolor, [8] L.npairs, [9] L.nblocks, [10] U.npairs, [11] U.nblocks, [12] ssor slices
+extern "C" int fx_get_stats(fx_context *c, int64_t out[16]) {
+  memset(out, 0, 16 * sizeof(int64_t));
+  out[0] = c->A.N; out[1] = c->A.NP; out[2] = c->A.NPL; out[3] = c->A.NPU;
+  out[4] = c->M.npairs; out[5] = c->M.nblocks; out[6] = c->M.nslices;
+  out[7] = c->ssor.ncolor;
+  out[8] = c->ssor.L.npairs; out[9] = c->ssor.L.nblocks; out[10] = c->ssor.U.npairs; out[11] = c->ssor.U.nblocks;
+  out[12] = c->ssor.L.nslices;
+  return 0;
 }
 
 #include "fx_assemble_host.h"

@@ -114,6 +114,7 @@ struct fx_context {
   KrylovState *st_host = nullptr;  // pinned
   double *hist = nullptr;      // device residual history
   int32_t hist_cap = 0;
+  int k_method = 1, k_maxit = 0, k_it = 1;  // host mirror of the running Krylov loop
   // communication
   int rank = 0, nranks = 1;
   int32_t nn_internal = 0;

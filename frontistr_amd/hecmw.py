@@ -228,6 +228,26 @@ class SolverContext:
         _chk(lib().fx_matvec_resident(self.h, nrepeat, C.byref(ms)))
         return ms.value
 
+    def precond_apply_ms(self, nrepeat=5):
+        ms = C.c_float(0)
+        _chk(lib().fx_precond_apply_resident(self.h, nrepeat, C.byref(ms)))
+        return ms.value
+
+    def stats(self):
+        out = (C.c_int64 * 16)()
+        _chk(lib().fx_get_stats(self.h, out))
+        keys = ("N", "NP", "NPL", "NPU", "M_pairs", "M_blocks", "M_slices", "ncolor", "L_pairs", "L_blocks",
+                "U_pairs", "U_blocks", "ssor_slices")
+        return {k: int(out[i]) for i, k in enumerate(keys)}
+
+    def krylov_begin(self, hecMAT):
+        _chk(lib().fx_krylov_begin(self.h, _ptr(hecMAT.Iarray), _ptr(hecMAT.Rarray)))
+
+    def krylov_steps(self, nsteps):
+        it, st, rs = C.c_int32(0), C.c_int32(0), C.c_double(0)
+        _chk(lib().fx_krylov_steps(self.h, int(nsteps), C.byref(it), C.byref(st), C.byref(rs)))
+        return it.value, st.value, rs.value
+
     def precond_apply(self, r):
         r = np.ascontiguousarray(r, dtype=np.float64)
         z = np.zeros_like(r)

@@ -110,11 +110,20 @@ int fx_precond_setup(fx_context *ctx, const int32_t *Iarray, const double *Rarra
  * traffic except the status word.  This is the region bench.py times. */
 int fx_solve_resident(fx_context *ctx, int32_t *Iarray, double *Rarray, fx_solve_info *info,
                       double *hist, int32_t hist_len);
+/* The same loop in pieces, for callers that time an exact number of iterations:
+ * begin = r0 = b - A x0 and ||b|| (hecmw_solver_CG.f90:120-129); steps = enqueue up to
+ * nsteps iterations (never past Iarray(1)) and return the device state after them
+ * (iter = Fortran ITER, status 0 = still running, 1 = converged, else an fx_status). */
+int fx_krylov_begin(fx_context *ctx, const int32_t *Iarray, const double *Rarray);
+int fx_krylov_steps(fx_context *ctx, int32_t nsteps, int32_t *iter, int32_t *status, double *resid);
 int fx_download_x(fx_context *ctx, double *X, int32_t n);          /* 3*NP doubles */
 int fx_download_matrix(fx_context *ctx, double *D, double *AL, double *AU, double *B);
 /* Resident single operations (tests, roofline timing). */
 int fx_matvec_resident(fx_context *ctx, int nrepeat, float *ms_per_call); /* y = A x on work vectors */
+int fx_precond_apply_resident(fx_context *ctx, int nrepeat, float *ms_per_call); /* z = M^-1 b, timed */
 int fx_precond_apply_host(fx_context *ctx, const double *r, double *z);   /* z = M^-1 r, 3*NP doubles */
+/* out[0..12]: N NP NPL NPU | M pairs, blocks, slices | ncolor | L pairs, blocks | U pairs, blocks | slices */
+int fx_get_stats(fx_context *ctx, int64_t out[16]);
 int fx_dot_host(fx_context *ctx, const double *x, const double *y, double *result);
 
 /* ---- assembly side ------------------------------------------------------ */
