@@ -109,6 +109,8 @@ extern "C" int fx_create(int device, fx_context **out) {
   HIP_TRY(hipEventCreate(&c->ev1));
   if (dev_alloc(&c->st, 1)) return FX_ERROR_RUNTIME;
   HIP_TRY(hipHostMalloc((void **)&c->st_host, sizeof(KrylovState) * 4, hipHostMallocDefault));
+  if (const char *e = getenv("FX_PIPE_SPMV")) c->pipe_spmv = atoi(e) != 0;
+  if (const char *e = getenv("FX_PIPE_SSOR")) c->pipe_ssor = atoi(e) != 0;
   if (dev_alloc(&c->red_out, 16)) return FX_ERROR_RUNTIME;
   *out = c;
   return 0;
@@ -447,9 +449,15 @@ static int spmv(fx_context *c, int mode, int dot, double *x, const double *b, do
   const Bell &M = c->M;
   const dim3 g((M.nslices + 3) / 4), blk(FX_BLOCK);
   double *part = c->partials;
-#define SPMV_LAUNCH(MODE, DOT)                                                                                   \
-  hipLaunchKernelGGL((k_spmv<MODE, DOT>), g, blk, 0, c->stream, M.nslices, c->A.N, M.pair_ptr, M.val2, M.col2, x, b, \
-                     y, part, gate, gate_val)
+#define SPMV_LAUNCH(MODE, DOT)                                                                                       \
+  do {                                                                                                               \
+    if (c->pipe_spmv)                                                                                                \
+      hipLaunchKernelGGL((k_spmv<MODE, DOT, true>), g, blk, 0, c->stream, M.nslices, c->A.N, M.pair_ptr, M.val2, M.col2, x, \
+                         b, y, part, gate, gate_val);                                                                \
+    else                                                                                                             \
+      hipLaunchKernelGGL((k_spmv<MODE, DOT, false>), g, blk, 0, c->stream, M.nslices, c->A.N, M.pair_ptr, M.val2, M.col2, x, \
+                         b, y, part, gate, gate_val);                                                                \
+  } while (0)
   if (mode == 0 && dot == 0) SPMV_LAUNCH(0, 0);
   else if (mode == 0 && dot == 1) SPMV_LAUNCH(0, 1);
   else if (mode == 1 && dot == 0) SPMV_LAUNCH(1, 0);
@@ -525,6 +533,9 @@ static int ssor_setup_symbolic(fx_context *c, int ncolor_in) {
   S.color_slice.assign(1, 0);
   for (int32_t col = 0; col < S.ncolor; col++) {
     std::vector<int32_t> rows(perm0.begin() + cidx[col], perm0.begin() + cidx[col + 1]);
+    // natural node order inside a colour (rows of one colour are independent): neighbouring lanes then
+    // gather neighbouring z entries; the stable sort by lower-block count only splits off boundary rows
+    std::sort(rows.begin(), rows.end());
     std::stable_sort(rows.begin(), rows.end(), [&](int32_t a, int32_t b) { return nlow[a] < nlow[b]; });
     slot_row.insert(slot_row.end(), rows.begin(), rows.end());
     while (slot_row.size() % 64) slot_row.push_back(-1);
@@ -619,17 +630,26 @@ static int precond_apply(fx_context *c, const double *r, double *z, bool want_do
     for (int col = 0; col < S.ncolor; col++) {
       const int s0 = S.color_slice[col], s1 = S.color_slice[col + 1];
       if (s1 <= s0) continue;
-      hipLaunchKernelGGL((k_ssor_color<true>), dim3((s1 - s0 + 3) / 4), dim3(FX_BLOCK), 0, c->stream, s0, s1, S.L.pair_ptr,
-                         S.L.val2, S.L.col2, S.L.slot_row, S.alu, r, z, (double *)nullptr, gate_status(c));
+      if (c->pipe_ssor)
+        hipLaunchKernelGGL((k_ssor_color<true, true>), dim3((s1 - s0 + 3) / 4), dim3(FX_BLOCK), 0, c->stream, s0, s1,
+                           S.L.pair_ptr, S.L.val2, S.L.col2, S.L.slot_row, S.alu, r, z, (double *)nullptr, gate_status(c));
+      else
+        hipLaunchKernelGGL((k_ssor_color<true, false>), dim3((s1 - s0 + 3) / 4), dim3(FX_BLOCK), 0, c->stream, s0, s1,
+                           S.L.pair_ptr, S.L.val2, S.L.col2, S.L.slot_row, S.alu, r, z, (double *)nullptr, gate_status(c));
     }
     int off = 0;
     for (int col = S.ncolor - 1; col >= 0; col--) {
       const int s0 = S.color_slice[col], s1 = S.color_slice[col + 1];
       if (s1 <= s0) continue;
       const int g = (s1 - s0 + 3) / 4;
-      hipLaunchKernelGGL((k_ssor_color<false>), dim3(g), dim3(FX_BLOCK), 0, c->stream, s0, s1, S.U.pair_ptr, S.U.val2,
-                         S.U.col2, S.U.slot_row, S.alu, r, z, want_dot ? c->partials + off : (double *)nullptr,
-                         gate_status(c));
+      if (c->pipe_ssor)
+        hipLaunchKernelGGL((k_ssor_color<false, true>), dim3(g), dim3(FX_BLOCK), 0, c->stream, s0, s1, S.U.pair_ptr, S.U.val2,
+                           S.U.col2, S.U.slot_row, S.alu, r, z, want_dot ? c->partials + off : (double *)nullptr,
+                           gate_status(c));
+      else
+        hipLaunchKernelGGL((k_ssor_color<false, false>), dim3(g), dim3(FX_BLOCK), 0, c->stream, s0, s1, S.U.pair_ptr, S.U.val2,
+                           S.U.col2, S.U.slot_row, S.alu, r, z, want_dot ? c->partials + off : (double *)nullptr,
+                           gate_status(c));
       if (want_dot) off += g;
     }
     *nparts = off;
@@ -964,8 +984,9 @@ extern "C" int fx_matvec(fx_context *c, const fx_matrix_view *m, const fx_comm_v
   HIP_TRY(hipMemsetAsync(c->W[7], 0, len, c->stream));
   {
     const Bell &M = c->M;
-    hipLaunchKernelGGL((k_spmv<0, 0>), dim3((M.nslices + 3) / 4), dim3(FX_BLOCK), 0, c->stream, M.nslices, c->A.N, M.pair_ptr,
-                       M.val2, M.col2, c->W[6], (const double *)nullptr, c->W[7], c->partials, (const int32_t *)nullptr, 0);
+    hipLaunchKernelGGL((k_spmv<0, 0, false>), dim3((M.nslices + 3) / 4), dim3(FX_BLOCK), 0, c->stream, M.nslices, c->A.N,
+                       M.pair_ptr, M.val2, M.col2, c->W[6], (const double *)nullptr, c->W[7], c->partials,
+                       (const int32_t *)nullptr, 0);
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipMemcpyAsync(y, c->W[7], (size_t)3 * c->A.N * 8, hipMemcpyDeviceToHost, c->stream));
@@ -978,11 +999,9 @@ extern "C" int fx_matvec(fx_context *c, const fx_matrix_view *m, const fx_comm_v
 extern "C" int fx_matvec_resident(fx_context *c, int nrepeat, float *ms_per_call) {
   HIP_TRY(hipSetDevice(c->device));
   if (!c->bell_valid) { g_fx_error = "fx_matvec_resident: no matrix resident"; return FX_ERROR_RUNTIME; }
-  const Bell &M = c->M;
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
   for (int i = 0; i < nrepeat; i++)
-    hipLaunchKernelGGL((k_spmv<0, 0>), dim3((M.nslices + 3) / 4), dim3(FX_BLOCK), 0, c->stream, M.nslices, c->A.N, M.pair_ptr,
-                       M.val2, M.col2, c->A.B, (const double *)nullptr, c->W[7], c->partials, (const int32_t *)nullptr, 0);
+    if (spmv(c, 0, 0, c->A.B, nullptr, c->W[7], nullptr, 0)) return FX_ERROR_RUNTIME;
   HIP_TRY(hipEventRecord(c->ev1, c->stream));
   HIP_TRY(hipEventSynchronize(c->ev1));
   HIP_TRY(hipGetLastError());

@@ -10,6 +10,15 @@
 
 #define FX_BLOCK 256
 
+// XCD-aware block order (cdna_hip_programming.md T1): hardware deals workgroups round-robin
+// over the 8 XCDs, each with a private 4 MiB L2.  Remapping so that every XCD walks one
+// CONTIGUOUS eighth of the slices lets the x / z gathers of neighbouring rows hit the same
+// L2 (bijective for any grid size).  Pure speed: results do not depend on placement.
+__device__ __forceinline__ int xcd_block(int b, int nb) {
+  const int q = nb >> 3, r = nb & 7, x = b & 7, k = b >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
 // ------------------------------------------------------------------------
 // reductions: wave shuffle (64 lanes) then LDS across the 4 waves, fixed order
 // => bitwise reproducible run to run.
@@ -21,7 +30,8 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 template <int NV>
-__device__ __forceinline__ void block_sum_store(double (&v)[NV], double *out, int stride) {
+__device__ __forceinline__ void block_sum_store(double (&v)[NV], double *out, int stride, int slot = -1) {
+  if (slot < 0) slot = blockIdx.x;
   __shared__ double sm[NV][FX_BLOCK / 64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
@@ -36,7 +46,7 @@ __device__ __forceinline__ void block_sum_store(double (&v)[NV], double *out, in
       double s = 0.0;
 #pragma unroll
       for (int k = 0; k < FX_BLOCK / 64; k++) s += sm[i][k];
-      out[(size_t)i * stride + blockIdx.x] = s;
+      out[(size_t)i * stride + slot] = s;
     }
   }
 }
@@ -76,13 +86,88 @@ __global__ void k_bell_fill(int32_t nslices, const int32_t *__restrict__ pair_pt
   }
 }
 
+
+// ------------------------------------------------------------------------
+// The row loop shared by SpMV and the SSOR sweeps:  s += sum_k A_k * x[col_k] over the
+// block pairs [p0,p1) of this lane's row.  PIPE = false: plain loop (two dependent memory
+// latencies per pair: column ids, then the gather).  PIPE = true: 2-deep software
+// pipeline -- while pair i is being multiplied, the 9 value words and the 6 gathered
+// vector entries of pair i+1 and the column ids of pair i+2 are already in flight, so a
+// wave exposes at most one latency per pair and keeps ~2x the bytes in flight.
+// ------------------------------------------------------------------------
+template <bool PIPE>
+__device__ __forceinline__ void bell_row_sweep(int p0, int p1, const double2 *__restrict__ val2,
+                                               const int2 *__restrict__ col2, int lane,
+                                               const double *__restrict__ x, double &s0, double &s1, double &s2) {
+  const int np = p1 - p0;
+  if (np <= 0) return;
+  const double2 *v = val2 + (size_t)p0 * 576 + lane;
+  const int2 *c = col2 + (size_t)p0 * 64 + lane;
+  if (!PIPE) {
+    for (int i = 0; i < np; i++, v += 576, c += 64) {
+      const int2 cc = *c;
+      double2 a[9];
+#pragma unroll
+      for (int e = 0; e < 9; e++) a[e] = v[e * 64];
+      const double *xa = x + (size_t)3 * cc.x, *xb = x + (size_t)3 * cc.y;
+      const double xa0 = xa[0], xa1 = xa[1], xa2 = xa[2];
+      const double xb0 = xb[0], xb1 = xb[1], xb2 = xb[2];
+      s0 += a[0].x * xa0 + a[1].x * xa1 + a[2].x * xa2;
+      s1 += a[3].x * xa0 + a[4].x * xa1 + a[5].x * xa2;
+      s2 += a[6].x * xa0 + a[7].x * xa1 + a[8].x * xa2;
+      s0 += a[0].y * xb0 + a[1].y * xb1 + a[2].y * xb2;
+      s1 += a[3].y * xb0 + a[4].y * xb1 + a[5].y * xb2;
+      s2 += a[6].y * xb0 + a[7].y * xb1 + a[8].y * xb2;
+    }
+    return;
+  }
+  int2 cc1 = (np > 1) ? c[64] : c[0];
+  double2 a[9];
+  double xa0, xa1, xa2, xb0, xb1, xb2;
+  {
+    const int2 cc0 = c[0];
+#pragma unroll
+    for (int e = 0; e < 9; e++) a[e] = v[e * 64];
+    const double *xa = x + (size_t)3 * cc0.x, *xb = x + (size_t)3 * cc0.y;
+    xa0 = xa[0]; xa1 = xa[1]; xa2 = xa[2];
+    xb0 = xb[0]; xb1 = xb[1]; xb2 = xb[2];
+  }
+  for (int i = 0; i < np; i++) {
+    const bool more = (i + 1 < np);  // wave-uniform: p0/p1 belong to the slice
+    double2 an[9];
+    double xan0 = 0, xan1 = 0, xan2 = 0, xbn0 = 0, xbn1 = 0, xbn2 = 0;
+    int2 cc2 = cc1;
+    if (more) {
+      v += 576; c += 64;
+#pragma unroll
+      for (int e = 0; e < 9; e++) an[e] = v[e * 64];
+      const double *xa = x + (size_t)3 * cc1.x, *xb = x + (size_t)3 * cc1.y;
+      xan0 = xa[0]; xan1 = xa[1]; xan2 = xa[2];
+      xbn0 = xb[0]; xbn1 = xb[1]; xbn2 = xb[2];
+      if (i + 2 < np) cc2 = c[64];
+    }
+    s0 += a[0].x * xa0 + a[1].x * xa1 + a[2].x * xa2;
+    s1 += a[3].x * xa0 + a[4].x * xa1 + a[5].x * xa2;
+    s2 += a[6].x * xa0 + a[7].x * xa1 + a[8].x * xa2;
+    s0 += a[0].y * xb0 + a[1].y * xb1 + a[2].y * xb2;
+    s1 += a[3].y * xb0 + a[4].y * xb1 + a[5].y * xb2;
+    s2 += a[6].y * xb0 + a[7].y * xb1 + a[8].y * xb2;
+    if (more) {
+#pragma unroll
+      for (int e = 0; e < 9; e++) a[e] = an[e];
+      xa0 = xan0; xa1 = xan1; xa2 = xan2; xb0 = xbn0; xb1 = xbn1; xb2 = xbn2;
+      cc1 = cc2;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------
 // K1/K2: y = A x  (hecmw_matvec_33_inner, hecmw_solver_las_33.f90:263-300)
 // MODE 0: y = A x            MODE 1: y = b - A x (hecmw_matresid_33 :371-379)
 // DOT  0: none  1: partial of x.y (p.q in CG)  2: partial of y.y (||r||^2 after matresid)
 // `gate` (may be null): device status word; the kernel is a no-op unless *gate == gate_val.
 // ------------------------------------------------------------------------
-template <int MODE, int DOT>
+template <int MODE, int DOT, bool PIPE>
 __global__ __launch_bounds__(FX_BLOCK) void k_spmv(int32_t nslices, int32_t nrows,
                                                    const int32_t *__restrict__ pair_ptr,
                                                    const double2 *__restrict__ val2,
@@ -91,30 +176,13 @@ __global__ __launch_bounds__(FX_BLOCK) void k_spmv(int32_t nslices, int32_t nrow
                                                    double *__restrict__ y, double *__restrict__ partials,
                                                    const int32_t *__restrict__ gate, int32_t gate_val) {
   if (gate && *gate != gate_val) return;
-  const int slice = blockIdx.x * (FX_BLOCK / 64) + (threadIdx.x >> 6);
+  const int vb = xcd_block(blockIdx.x, gridDim.x);
+  const int slice = vb * (FX_BLOCK / 64) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   double y0 = 0.0, y1 = 0.0, y2 = 0.0;
   const int row = slice * 64 + lane;
-  if (slice < nslices) {
-    const int p0 = pair_ptr[slice], p1 = pair_ptr[slice + 1];
-    const double2 *v = val2 + (size_t)p0 * 576 + lane;
-    const int2 *c = col2 + (size_t)p0 * 64 + lane;
-    for (int p = p0; p < p1; p++, v += 576, c += 64) {
-      const int2 cc = *c;
-      double2 a[9];
-#pragma unroll
-      for (int e = 0; e < 9; e++) a[e] = v[e * 64];
-      const double *xa = x + (size_t)3 * cc.x, *xb = x + (size_t)3 * cc.y;
-      const double xa0 = xa[0], xa1 = xa[1], xa2 = xa[2];
-      const double xb0 = xb[0], xb1 = xb[1], xb2 = xb[2];
-      y0 += a[0].x * xa0 + a[1].x * xa1 + a[2].x * xa2;
-      y1 += a[3].x * xa0 + a[4].x * xa1 + a[5].x * xa2;
-      y2 += a[6].x * xa0 + a[7].x * xa1 + a[8].x * xa2;
-      y0 += a[0].y * xb0 + a[1].y * xb1 + a[2].y * xb2;
-      y1 += a[3].y * xb0 + a[4].y * xb1 + a[5].y * xb2;
-      y2 += a[6].y * xb0 + a[7].y * xb1 + a[8].y * xb2;
-    }
-  }
+  if (slice < nslices)
+    bell_row_sweep<PIPE>(pair_ptr[slice], pair_ptr[slice + 1], val2, col2, lane, x, y0, y1, y2);
   double d[1] = {0.0};
   if (slice < nslices && row < nrows) {
     if (MODE == 1) {
@@ -124,7 +192,7 @@ __global__ __launch_bounds__(FX_BLOCK) void k_spmv(int32_t nslices, int32_t nrow
     if (DOT == 1) d[0] = x[(size_t)3 * row] * y0 + x[(size_t)3 * row + 1] * y1 + x[(size_t)3 * row + 2] * y2;
     if (DOT == 2) d[0] = y0 * y0 + y1 * y1 + y2 * y2;
   }
-  if (DOT != 0) block_sum_store<1>(d, partials, 0);
+  if (DOT != 0) block_sum_store<1>(d, partials, 0, vb);
 }
 
 // ------------------------------------------------------------------------
@@ -200,7 +268,7 @@ __global__ __launch_bounds__(FX_BLOCK) void k_diag_apply(int32_t nrows, const do
 //   FWD: z_i = D~_i^-1 ( r_i - sum_{j in L(i)} L_ij z_j )      (reads r for the own row: the
 //        reference's ZP=R copy is folded away, earlier colours are already final in z)
 //   BWD: z_i = z_i - D~_i^-1 sum_{j in U(i)} U_ij z_j           (+ partial of r.z when asked)
-template <bool FWD>
+template <bool FWD, bool PIPE>
 __global__ __launch_bounds__(FX_BLOCK) void k_ssor_color(int32_t slice0, int32_t slice1,
                                                          const int32_t *__restrict__ pair_ptr,
                                                          const double2 *__restrict__ val2,
@@ -211,31 +279,15 @@ __global__ __launch_bounds__(FX_BLOCK) void k_ssor_color(int32_t slice0, int32_t
                                                          double *__restrict__ partials,
                                                          const int32_t *__restrict__ gate) {
   if (gate && *gate != 0) return;
-  const int slice = slice0 + blockIdx.x * (FX_BLOCK / 64) + (threadIdx.x >> 6);
+  const int vb = xcd_block(blockIdx.x, gridDim.x);
+  const int slice = slice0 + vb * (FX_BLOCK / 64) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   double d[1] = {0.0};
   if (slice < slice1) {
     const int slot = slice * 64 + lane;
     const int row = slot_row[slot];
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    const int p0 = pair_ptr[slice], p1 = pair_ptr[slice + 1];
-    const double2 *v = val2 + (size_t)p0 * 576 + lane;
-    const int2 *c = col2 + (size_t)p0 * 64 + lane;
-    for (int p = p0; p < p1; p++, v += 576, c += 64) {
-      const int2 cc = *c;
-      double2 a[9];
-#pragma unroll
-      for (int e = 0; e < 9; e++) a[e] = v[e * 64];
-      const double *xa = z + (size_t)3 * cc.x, *xb = z + (size_t)3 * cc.y;
-      const double xa0 = xa[0], xa1 = xa[1], xa2 = xa[2];
-      const double xb0 = xb[0], xb1 = xb[1], xb2 = xb[2];
-      s0 += a[0].x * xa0 + a[1].x * xa1 + a[2].x * xa2;
-      s1 += a[3].x * xa0 + a[4].x * xa1 + a[5].x * xa2;
-      s2 += a[6].x * xa0 + a[7].x * xa1 + a[8].x * xa2;
-      s0 += a[0].y * xb0 + a[1].y * xb1 + a[2].y * xb2;
-      s1 += a[3].y * xb0 + a[4].y * xb1 + a[5].y * xb2;
-      s2 += a[6].y * xb0 + a[7].y * xb1 + a[8].y * xb2;
-    }
+    bell_row_sweep<PIPE>(pair_ptr[slice], pair_ptr[slice + 1], val2, col2, lane, z, s0, s1, s2);
     if (row >= 0) {
       double u[9];
       const size_t base = (size_t)slice * 576 + lane;
@@ -258,7 +310,7 @@ __global__ __launch_bounds__(FX_BLOCK) void k_ssor_color(int32_t slice0, int32_t
       }
     }
   }
-  if (!FWD && partials) block_sum_store<1>(d, partials, 0);
+  if (!FWD && partials) block_sum_store<1>(d, partials, 0, vb);
 }
 
 // ------------------------------------------------------------------------
