@@ -153,6 +153,8 @@ extern "C" void fx_destroy(fx_context *c) {
   dev_free(c->halo.sendbuf); dev_free(c->halo.recvbuf);
   dev_free(c->st); dev_free(c->red_out); dev_free(c->hist);
   if (c->st_host) (void)hipHostFree(c->st_host);
+  if (c->h_send) (void)hipHostFree(c->h_send);
+  if (c->h_recv) (void)hipHostFree(c->h_recv);
   if (c->nccl) ncclCommDestroy((ncclComm_t)c->nccl);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -409,15 +411,54 @@ extern "C" int fx_comm_init(fx_context *c, const unsigned char id[128], int rank
   return 0;
 }
 
+extern "C" int fx_comm_set_host_callbacks(fx_context *c, int rank, int nranks, fx_halo_fn halo, fx_allreduce_fn allreduce,
+                                          void *user) {
+  c->cb_halo = halo; c->cb_allreduce = allreduce; c->cb_user = user;
+  c->rank = rank; c->nranks = nranks;
+  return 0;
+}
+
+static inline bool multi_rank(const fx_context *c) { return c->nranks > 1 && (c->nccl || c->cb_allreduce); }
+
+// SUM over ranks of n (<= 8) doubles living at device address v, on the solver stream.
+static int allreduce_dev(fx_context *c, double *v, int n) {
+  if (c->nccl) {
+    NCCL_TRY(ncclAllReduce(v, v, n, ncclDouble, ncclSum, (ncclComm_t)c->nccl, c->stream));
+    return 0;
+  }
+  double h[8];
+  HIP_TRY(hipMemcpyAsync(h, v, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->cb_allreduce(h, n, c->cb_user);
+  HIP_TRY(hipMemcpyAsync(v, h, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 // hecmw_update_3_R (hecmw_comm_f.F90:669-694): persistent device buffers, one grouped
 // send/recv per neighbour, all on the solver stream (no host synchronisation).
 static int halo_update(fx_context *c, double *x) {
   HaloDev &h = c->halo;
   if (h.n_neighbor <= 0 || c->nranks <= 1) return 0;
-  if (!c->nccl) { g_fx_error = "halo exchange requested but fx_comm_init was not called"; return FX_ERROR_RUNTIME; }
+  if (!c->nccl && !c->cb_halo) { g_fx_error = "halo exchange requested but no communicator (fx_comm_init) was set"; return FX_ERROR_RUNTIME; }
   if (h.n_export > 0)
     hipLaunchKernelGGL(k_halo_pack, dim3((h.n_export + 255) / 256), dim3(256), 0, c->stream, h.n_export, h.export_item, x,
                        h.sendbuf);
+  if (!c->nccl) {  // host-staged transport
+    if (!c->h_send) {
+      HIP_TRY(hipHostMalloc((void **)&c->h_send, (size_t)3 * std::max(h.n_export, 1) * 8, hipHostMallocDefault));
+      HIP_TRY(hipHostMalloc((void **)&c->h_recv, (size_t)3 * std::max(h.n_import, 1) * 8, hipHostMallocDefault));
+    }
+    HIP_TRY(hipMemcpyAsync(c->h_send, h.sendbuf, (size_t)3 * h.n_export * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->cb_halo(c->h_send, c->h_recv, c->cb_user);
+    HIP_TRY(hipMemcpyAsync(h.recvbuf, c->h_recv, (size_t)3 * h.n_import * 8, hipMemcpyHostToDevice, c->stream));
+    if (h.n_import > 0)
+      hipLaunchKernelGGL(k_halo_unpack, dim3((h.n_import + 255) / 256), dim3(256), 0, c->stream, h.n_import, h.import_item,
+                         h.recvbuf, x);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   NCCL_TRY(ncclGroupStart());
   for (int k = 0; k < h.n_neighbor; k++) {
     const int32_t ns = h.export_index[k + 1] - h.export_index[k], nr = h.import_index[k + 1] - h.import_index[k];
@@ -471,10 +512,10 @@ static inline int spmv_nparts(fx_context *c) { return (c->M.nslices + 3) / 4; }
 
 template <int OP>
 static int scalar_stage(fx_context *c, int nparts, int stride, int recompute_every) {
-  if (c->nranks > 1 && c->nccl) {
+  if (multi_rank(c)) {
     hipLaunchKernelGGL((k_scalar<OP>), dim3(1), dim3(1024), 0, c->stream, c->partials, nparts, stride, c->st, c->hist,
                        c->red_out, 1, recompute_every);
-    NCCL_TRY(ncclAllReduce(c->red_out, c->red_out, 2, ncclDouble, ncclSum, (ncclComm_t)c->nccl, c->stream));
+    if (allreduce_dev(c, c->red_out, 2)) return FX_ERROR_RUNTIME;
     hipLaunchKernelGGL((k_scalar<OP>), dim3(1), dim3(64), 0, c->stream, c->partials, nparts, stride, c->st, c->hist,
                        c->red_out, 2, recompute_every);
   } else {
@@ -849,8 +890,7 @@ extern "C" int fx_krylov_steps(fx_context *c, int32_t nsteps, int32_t *iter, int
 static int host_sum(fx_context *c, int nparts, int stride, double *v0, double *v1) {
   hipLaunchKernelGGL((k_scalar<OP_PLAIN>), dim3(1), dim3(1024), 0, c->stream, c->partials, nparts, stride, c->st,
                      (double *)nullptr, c->red_out, 1, 1);
-  if (c->nranks > 1 && c->nccl)
-    NCCL_TRY(ncclAllReduce(c->red_out, c->red_out, 2, ncclDouble, ncclSum, (ncclComm_t)c->nccl, c->stream));
+  if (multi_rank(c) && allreduce_dev(c, c->red_out, 2)) return FX_ERROR_RUNTIME;
   double h[2];
   HIP_TRY(hipMemcpyAsync(h, c->red_out, 16, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -885,10 +925,13 @@ extern "C" int fx_solve_resident(fx_context *c, int32_t *Iarray, double *Rarray,
     int32_t hflag = 0;
     HIP_TRY(hipMemcpyAsync(&hflag, flag, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->nranks > 1 && c->nccl) {
-      NCCL_TRY(ncclAllReduce(flag, flag, 1, ncclInt32, ncclMax, (ncclComm_t)c->nccl, c->stream));
-      HIP_TRY(hipMemcpyAsync(&hflag, flag, 4, hipMemcpyDeviceToHost, c->stream));
+    if (multi_rank(c)) {  // MAX of 0/1 flags == (SUM > 0)
+      double f = hflag ? 1.0 : 0.0;
+      HIP_TRY(hipMemcpyAsync(c->red_out + 4, &f, 8, hipMemcpyHostToDevice, c->stream));
+      if (allreduce_dev(c, c->red_out + 4, 1)) return FX_ERROR_RUNTIME;
+      HIP_TRY(hipMemcpyAsync(&f, c->red_out + 4, 8, hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(hipStreamSynchronize(c->stream));
+      hflag = f > 0.0;
     }
     if (hflag && precond < 10 && iterpremax > 0) return FX_ERROR_ZERO_DIAG;
   }

@@ -122,6 +122,11 @@ struct fx_context {
   int rank = 0, nranks = 1;
   int32_t nn_internal = 0;
   void *nccl = nullptr;
+  // host-staged communication hooks (testing / non-RCCL transports): see fx_comm_set_host_callbacks
+  void (*cb_halo)(const double *, double *, void *) = nullptr;
+  void (*cb_allreduce)(double *, int, void *) = nullptr;
+  void *cb_user = nullptr;
+  double *h_send = nullptr, *h_recv = nullptr;  // pinned staging
   HaloDev halo;
   // timing
   hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -157,6 +157,15 @@ int fx_element_stiffness_c3d8(fx_context *ctx, int elemopt, const double *ecoord
  * (torch.distributed / MPI); then every rank calls fx_comm_init. */
 int fx_comm_unique_id(unsigned char id[128]);
 int fx_comm_init(fx_context *ctx, const unsigned char id[128], int rank, int nranks);
+/* Alternative transport (tests on one GPU, MPI builds of fistr1 without RCCL): the library
+ * stages through pinned host buffers and calls back.  halo: send holds 3*n_export doubles in
+ * export_item order, recv must be filled with 3*n_import doubles in import_item order
+ * (hecmw_solve_send_recv_33, hecmw_solver_SR_33.F90:42-124).  allreduce: in-place SUM over
+ * ranks of n doubles (hecmw_allreduce_R, hecmw_comm_f.F90:346-379). */
+typedef void (*fx_halo_fn)(const double *send, double *recv, void *user);
+typedef void (*fx_allreduce_fn)(double *v, int n, void *user);
+int fx_comm_set_host_callbacks(fx_context *ctx, int rank, int nranks, fx_halo_fn halo, fx_allreduce_fn allreduce,
+                               void *user);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,62 @@
+"""Worker for the multi-process tests (spawned by test_distributed.py / test_gpu_distributed.py).
+argv: mode(oracle|hip) rank world port m method precond outfile"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+
+def main():
+    mode, rank, world, port, m, meth, pc, out = sys.argv[1:9]
+    rank, world, m, meth, pc = int(rank), int(world), int(m), int(meth), int(pc)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from frontistr_amd.partition import cube_subdomain
+    from frontistr_amd.comm import NeighborExchange
+    dims = {2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}[world]
+    sub = cube_subdomain(m, dims, rank)
+    E, NU = 210000.0, 0.3
+    if mode == "oracle":
+        from oracle import pyoracle as po
+        from oracle.refrun import default_params
+        A = po.assemble(1, sub.coord, sub.conn, E, NU, bc=sub.dirichlet(), load=sub.load())
+        A.N = sub.nn_internal                                    # rows 1..N are solved, N+1..NP are halo
+        ex = NeighborExchange(sub.neighbor_pe, sub.import_index, sub.export_index)
+        exp0, imp0 = sub.export_item - 1, sub.import_item - 1
+
+        def halo(x):                                             # hecmw_update_3_R on a full vector
+            xv = x.reshape(-1, 3)
+            send = np.ascontiguousarray(xv[exp0]).ravel()
+            recv = np.zeros(3 * ex.n_import)
+            ex.exchange(send, recv)
+            xv[imp0] = recv.reshape(-1, 3)
+
+        comm = po.Comm(halo=halo, allreduce=ex.allreduce_sum, nvec=3 * sub.n_node)
+        I, R = default_params(method=meth, precond=pc)
+        o = po.solve_iterative(A, I, R, nthreads=4, comm=comm)
+        X, it, hist, code = o["X"], o["iter"], o["history"], o["code"]
+    else:
+        from frontistr_amd import hecmw as hip
+        from frontistr_amd.comm import attach_host_callbacks
+        hm = sub.hecmesh(hip)
+        hm.elem_node_item = sub.conn.ravel()
+        mat = hip.hecmw_mat_con(hm, hip.hecmwST_matrix())
+        ctx = hip.SolverContext(device=0)
+        attach_host_callbacks(ctx, hm, hip.lib())
+        ctx.upload(mat, hm, what=hip.FX_UP_PROFILE)
+        ctx.assemble_c3d8(sub.coord, sub.conn, E, NU, elemopt=1, load=sub.load(), bc=sub.dirichlet())
+        mat.Iarray[0] = 10000; mat.Iarray[1] = meth; mat.Iarray[2] = pc
+        code = ctx.solve_resident(mat)
+        ctx.download_x(mat)
+        X, it, hist = mat.X, ctx.info.iterations, ctx.history
+        ctx.close()
+    np.savez(out, X=X, it=it, hist=hist, code=code, gid=sub.global_id, nn_internal=sub.nn_internal)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
