@@ -1,6 +1,7 @@
 // libfistr_hip: MI355X-native HEC-MW linear-solve hot path behind the C ABI of
 // include/fistr_hip.h.  Host orchestration; the kernels live in fx_kernels.h /
 // fx_assemble.h.  gfx950 only -- there is no CPU fallback anywhere in this library.
+#include <dlfcn.h>
 #include <rccl/rccl.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -36,11 +37,52 @@ int fx_fail(const char *what, const char *file, int line) {
   return FX_ERROR_RUNTIME;
 }
 
+// RCCL is bound lazily (dlopen) the first time a communicator is requested: single-GPU runs never
+// load the 0.5 GB library, and a process that already holds an RCCL (e.g. through torch.distributed)
+// shares that copy instead of mixing two.
+struct RcclApi {
+  void *h = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+
+static int rccl_load() {
+  if (g_rccl.h) return 0;
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char *n : names) {
+    g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (g_rccl.h) break;
+  }
+  if (!g_rccl.h) { g_fx_error = std::string("cannot load RCCL: ") + dlerror(); return FX_ERROR_RUNTIME; }
+#define RCCL_SYM(field, name)                                                                  \
+  g_rccl.field = (decltype(g_rccl.field))dlsym(g_rccl.h, name);                                  \
+  if (!g_rccl.field) { g_fx_error = std::string("RCCL symbol missing: ") + name; return FX_ERROR_RUNTIME; }
+  RCCL_SYM(GetUniqueId, "ncclGetUniqueId")
+  RCCL_SYM(CommInitRank, "ncclCommInitRank")
+  RCCL_SYM(CommDestroy, "ncclCommDestroy")
+  RCCL_SYM(GroupStart, "ncclGroupStart")
+  RCCL_SYM(GroupEnd, "ncclGroupEnd")
+  RCCL_SYM(Send, "ncclSend")
+  RCCL_SYM(Recv, "ncclRecv")
+  RCCL_SYM(AllReduce, "ncclAllReduce")
+  RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef RCCL_SYM
+  return 0;
+}
+
 #define NCCL_TRY(expr)                                                       \
   do {                                                                       \
     ncclResult_t _e = (expr);                                                \
     if (_e != ncclSuccess) {                                                 \
-      g_fx_error = std::string(#expr) + ": " + ncclGetErrorString(_e);       \
+      g_fx_error = std::string(#expr) + ": " + g_rccl.GetErrorString(_e);    \
       return fx_fail(g_fx_error.c_str(), __FILE__, __LINE__);                \
     }                                                                        \
   } while (0)
@@ -155,7 +197,7 @@ extern "C" void fx_destroy(fx_context *c) {
   if (c->st_host) (void)hipHostFree(c->st_host);
   if (c->h_send) (void)hipHostFree(c->h_send);
   if (c->h_recv) (void)hipHostFree(c->h_recv);
-  if (c->nccl) ncclCommDestroy((ncclComm_t)c->nccl);
+  if (c->nccl && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)c->nccl);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -391,8 +433,9 @@ extern "C" int fx_download_matrix(fx_context *c, double *D, double *AL, double *
 // communication: halo exchange (C1) and scalar all-reduce (C2) over RCCL
 // ---------------------------------------------------------------------------
 extern "C" int fx_comm_unique_id(unsigned char id[128]) {
+  if (rccl_load()) return FX_ERROR_RUNTIME;
   ncclUniqueId u;
-  NCCL_TRY(ncclGetUniqueId(&u));
+  NCCL_TRY(g_rccl.GetUniqueId(&u));
   static_assert(sizeof(ncclUniqueId) <= 128, "ncclUniqueId larger than the ABI slot");
   memset(id, 0, 128);
   memcpy(id, &u, sizeof u);
@@ -401,10 +444,11 @@ extern "C" int fx_comm_unique_id(unsigned char id[128]) {
 
 extern "C" int fx_comm_init(fx_context *c, const unsigned char id[128], int rank, int nranks) {
   HIP_TRY(hipSetDevice(c->device));
+  if (rccl_load()) return FX_ERROR_RUNTIME;
   ncclUniqueId u;
   memcpy(&u, id, sizeof u);
   ncclComm_t comm;
-  NCCL_TRY(ncclCommInitRank(&comm, nranks, u, rank));
+  NCCL_TRY(g_rccl.CommInitRank(&comm, nranks, u, rank));
   c->nccl = comm;
   c->rank = rank;
   c->nranks = nranks;
@@ -418,12 +462,17 @@ extern "C" int fx_comm_set_host_callbacks(fx_context *c, int rank, int nranks, f
   return 0;
 }
 
-static inline bool multi_rank(const fx_context *c) { return c->nranks > 1 && (c->nccl || c->cb_allreduce); }
+// FX_FORCE_COMM=1 routes the scalar reductions through the communicator even with one rank
+// (lets a single-GPU box exercise the RCCL all-reduce path).
+static inline bool multi_rank(const fx_context *c) {
+  static const bool force = getenv("FX_FORCE_COMM") && atoi(getenv("FX_FORCE_COMM")) != 0;
+  return (c->nranks > 1 || force) && (c->nccl || c->cb_allreduce);
+}
 
 // SUM over ranks of n (<= 8) doubles living at device address v, on the solver stream.
 static int allreduce_dev(fx_context *c, double *v, int n) {
   if (c->nccl) {
-    NCCL_TRY(ncclAllReduce(v, v, n, ncclDouble, ncclSum, (ncclComm_t)c->nccl, c->stream));
+    NCCL_TRY(g_rccl.AllReduce(v, v, n, ncclDouble, ncclSum, (ncclComm_t)c->nccl, c->stream));
     return 0;
   }
   double h[8];
@@ -459,17 +508,17 @@ static int halo_update(fx_context *c, double *x) {
     HIP_TRY(hipGetLastError());
     return 0;
   }
-  NCCL_TRY(ncclGroupStart());
+  NCCL_TRY(g_rccl.GroupStart());
   for (int k = 0; k < h.n_neighbor; k++) {
     const int32_t ns = h.export_index[k + 1] - h.export_index[k], nr = h.import_index[k + 1] - h.import_index[k];
     if (ns > 0)
-      NCCL_TRY(ncclSend(h.sendbuf + (size_t)3 * h.export_index[k], (size_t)3 * ns, ncclDouble, h.neighbor[k], (ncclComm_t)c->nccl,
+      NCCL_TRY(g_rccl.Send(h.sendbuf + (size_t)3 * h.export_index[k], (size_t)3 * ns, ncclDouble, h.neighbor[k], (ncclComm_t)c->nccl,
                         c->stream));
     if (nr > 0)
-      NCCL_TRY(ncclRecv(h.recvbuf + (size_t)3 * h.import_index[k], (size_t)3 * nr, ncclDouble, h.neighbor[k], (ncclComm_t)c->nccl,
+      NCCL_TRY(g_rccl.Recv(h.recvbuf + (size_t)3 * h.import_index[k], (size_t)3 * nr, ncclDouble, h.neighbor[k], (ncclComm_t)c->nccl,
                         c->stream));
   }
-  NCCL_TRY(ncclGroupEnd());
+  NCCL_TRY(g_rccl.GroupEnd());
   if (h.n_import > 0)
     hipLaunchKernelGGL(k_halo_unpack, dim3((h.n_import + 255) / 256), dim3(256), 0, c->stream, h.n_import, h.import_item,
                        h.recvbuf, x);

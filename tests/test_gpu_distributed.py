@@ -30,3 +30,32 @@ def test_hip_distributed_ssor_matches_distributed_oracle(oracle, tmp_path):
         assert np.abs(a["X"] - b["X"]).max() < 1e-8 * np.abs(b["X"]).max()
         k = min(10, len(a["hist"]), len(b["hist"]))
         assert np.all(np.abs(a["hist"][:k] - b["hist"][:k]) <= 1e-9 * b["hist"][:k])
+
+
+def test_rccl_allreduce_path_single_rank(tmp_path):
+    """RCCL binding (dlopen), ncclCommInitRank and the in-stream ncclAllReduce of the scalar stage,
+    exercised with a 1-rank communicator (FX_FORCE_COMM=1) in a fresh process."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r"""
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))
+import numpy as np
+from conftest import golden_matrix, load_golden
+from frontistr_amd import hecmw as hip
+g = load_golden('cube4'); A = golden_matrix(g)
+m = hip.hecmwST_matrix.from_arrays(A.N, A.NP, A.indexL, A.itemL, A.indexU, A.itemU, A.D, A.AL, A.AU, A.B.copy())
+m.Iarray[0] = 10000; m.Iarray[2] = 1
+ctx = hip.SolverContext()
+ctx.comm_init(hip.comm_unique_id(), 0, 1)
+assert hip.hecmw_solve(None, m, ctx=ctx) == 0
+assert abs(ctx.info.iterations - int(g['sol_m1_p1_t4_iter'])) <= 1
+assert np.abs(m.X - g['sol_m1_p1_t4_X']).max() < 1e-8 * np.abs(g['sol_m1_p1_t4_X']).max()
+print('rccl ok', ctx.info.iterations)
+""" % (ROOT, ROOT)
+    env = dict(os.environ, FX_FORCE_COMM="1")
+    p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=600)
+    assert p.returncode == 0 and "rccl ok" in p.stdout, p.stdout[-3000:]
