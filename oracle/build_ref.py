@@ -119,7 +119,7 @@ def scan_driver(path):
     return us - INTRINSIC
 
 
-def build_variant(name, drivers, omp, jobs, provides, uses):
+def build_variant(name, drivers, omp, jobs, provides, uses, overrides=None, defines=(), extra_link=(), exe_name=None):
     objdir = os.path.join(OUT, "obj_" + name)
     moddir = os.path.join(OUT, "mod_" + name)
     os.makedirs(objdir, exist_ok=True)
@@ -136,7 +136,13 @@ def build_variant(name, drivers, omp, jobs, provides, uses):
         fflags.append("-fopenmp")
         cflags.append("-fopenmp")
 
+    fflags += ["-D" + d for d in defines]
     extra = {d: scan_driver(d) for d in drivers}
+    if overrides:                      # e.g. module hecmw_solver provided by our shim instead of the reference
+        provides = dict(provides)
+        for mod, f in overrides.items():
+            provides[mod] = f
+            extra[f] = scan_driver(f)
     order = closure(drivers, provides, uses, extra)
     # Fortran must be compiled in dependency order (module files).
     fobjs = []
@@ -182,10 +188,10 @@ def build_variant(name, drivers, omp, jobs, provides, uses):
 
     exes = []
     for d in drivers:
-        exe = os.path.join(OUT, os.path.basename(d).replace("_driver.f90", "") + ("_omp" if omp else ""))
+        exe = os.path.join(OUT, exe_name or (os.path.basename(d).replace("_driver.f90", "") + ("_omp" if omp else "")))
         dobj = objname(objdir, d)
         others = [o for o in fobjs if o != dobj and not any(o == objname(objdir, x) for x in drivers)]
-        link = [FLANG, "-o", exe, dobj] + others + [lib, "-lm"]
+        link = [FLANG, "-o", exe, dobj] + others + [lib] + list(extra_link) + ["-lm"]
         if omp:
             link.append("-fopenmp")
         # External (non-module) Fortran procedures, e.g. the user-material
@@ -228,7 +234,7 @@ def build_variant(name, drivers, omp, jobs, provides, uses):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--jobs", type=int, default=4)
-    ap.add_argument("--only", choices=["solve", "fem"], default=None)
+    ap.add_argument("--only", choices=["solve", "fem", "shim"], default=None)
     a = ap.parse_args()
     if not os.path.isdir(REF):
         print(f"reference not present at {REF}; oracle/_ref left as is")
@@ -245,6 +251,15 @@ def main():
         build_variant("omp", [solve], True, a.jobs, provides, uses)
     if a.only in (None, "fem") and os.path.exists(fem):
         build_variant("fem", [fem], False, a.jobs, provides, uses)
+    # Integration check of the drop-in boundary: the SAME driver, but `hecmw_solve` now comes from
+    # frontistr_amd/shim/hecmw_solver_hip.f90 (module hecmw_solver) -> libfistr_hip.so.  The reference's
+    # derived types and every other module are the reference's own objects.
+    shim = os.path.join(os.path.dirname(HERE), "frontistr_amd", "shim", "hecmw_solver_hip.f90")
+    hiplib = os.path.join(os.path.dirname(HERE), "frontistr_amd", "libfistr_hip.so")
+    if a.only in (None, "shim") and os.path.exists(shim) and os.path.exists(hiplib):
+        build_variant("shim", [solve], False, a.jobs, provides, uses, overrides={"hecmw_solver": shim},
+                      defines=("USE_SHIM",), exe_name="shim_solve",
+                      extra_link=(hiplib, "-Wl,-rpath," + os.path.dirname(hiplib), "-Wl,-rpath,/opt/rocm/lib"))
     return 0
 
 

@@ -124,10 +124,10 @@ def parse_stdout(text):
     return info
 
 
-def run_solve(m, I, R, mode=1, threads=1, nrepeat=1, workdir=None, timeout=None):
+def run_solve(m, I, R, mode=1, threads=1, nrepeat=1, workdir=None, timeout=None, exe_name=None, extra_env=None):
     """Run the reference.  threads==1 -> serial build (natural-order SSOR);
     threads>=2 -> OpenMP build (RCM + multicolour SSOR)."""
-    exe = os.path.join(REFDIR, "ref_solve_omp" if threads > 1 else "ref_solve")
+    exe = os.path.join(REFDIR, exe_name or ("ref_solve_omp" if threads > 1 else "ref_solve"))
     if not os.path.exists(exe):
         raise FileNotFoundError(exe + " (run python oracle/build_ref.py where /root/reference exists)")
     with tempfile.TemporaryDirectory(dir=workdir) as td:
@@ -135,6 +135,8 @@ def run_solve(m, I, R, mode=1, threads=1, nrepeat=1, workdir=None, timeout=None)
         write_system(fin, mode, m, I, R, nrepeat)
         env = dict(os.environ)
         env["OMP_NUM_THREADS"] = str(threads)
+        if extra_env:
+            env.update(extra_env)
         p = subprocess.run([exe, fin, fout], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                            text=True, env=env, timeout=timeout)
         info = parse_stdout(p.stdout)

@@ -1,0 +1,46 @@
+"""The drop-in boundary end to end: a Fortran program holding the REFERENCE's own
+hecmwST_matrix / hecmwST_local_mesh calls `hecmw_solve(hecMESH, hecMAT)` -- as
+fistr1/src/lib/solve_LINEQ.f90:22 does -- and that name now resolves to
+frontistr_amd/shim/hecmw_solver_hip.f90 -> libfistr_hip.so (oracle/_ref/shim_solve, linked by
+oracle/build_ref.py from the reference's objects + our shim).  Output must match the golden
+vectors the unmodified reference produced."""
+import numpy as np
+import pytest
+
+from conftest import golden_matrix, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("deck", ["cube4", "cube3s"])
+@pytest.mark.parametrize("meth,pc,thr", [(1, 3, 1), (1, 1, 4)])
+def test_fistr_side_call_through_shim(deck, meth, pc, thr):
+    from oracle import refrun
+    if not refrun.have_ref("shim_solve"):
+        pytest.skip("oracle/_ref/shim_solve not built (needs /root/reference at build time)")
+    g = load_golden(deck)
+    A = golden_matrix(g)
+    I, R = refrun.default_params(method=meth, precond=pc)
+    r = refrun.run_solve(A, I, R, exe_name="shim_solve")
+    assert r["returncode"] == 0, r["stdout"][-2000:]
+    tag = "sol_m%d_p%d_t%d_" % (meth, pc, thr)
+    x_ref, h_ref = g[tag + "X"], g[tag + "hist"]
+    assert np.abs(r["X"] - x_ref).max() < 1e-8 * np.abs(x_ref).max()
+    h = np.array([v for _, v in r["history"]])            # the shim prints the reference's ITERLOG format
+    assert abs(len(h) - len(h_ref)) <= 1
+    k = min(10, len(h), len(h_ref))
+    assert np.all(np.abs(h[:k] - h_ref[:k]) <= 2e-6 * h_ref[:k])
+    assert r["Iarray"][80] == 1 and r["Iarray"][96] == 0 and r["Iarray"][97] == 0
+    assert abs(r["rel_resid"] - float(g[tag + "rel_resid"])) <= 0.5 * float(g[tag + "rel_resid"]) + 1e-12
+
+
+def test_shim_cpu_escape_hatch():
+    """HECMW_GPU=0 keeps the reference's CPU path inside the same binary."""
+    from oracle import refrun
+    if not refrun.have_ref("shim_solve"):
+        pytest.skip("oracle/_ref/shim_solve not built")
+    g = load_golden("cube4")
+    A = golden_matrix(g)
+    I, R = refrun.default_params(method=1, precond=3)
+    r = refrun.run_solve(A, I, R, exe_name="shim_solve", extra_env={"HECMW_GPU": "0"})
+    assert np.array_equal(r["X"], g["sol_m1_p3_t1_X"])      # bit-for-bit the reference
