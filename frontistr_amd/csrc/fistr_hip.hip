@@ -140,7 +140,10 @@ extern "C" int fx_create(int device, fx_context **out) {
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (ndev <= 0) { g_fx_error = "no HIP device: libfistr_hip has no CPU path"; return FX_ERROR_RUNTIME; }
   if (device < 0) {
-    const char *lr = getenv("LOCAL_RANK");
+    const char *lr = getenv("LOCAL_RANK");                          // torchrun
+    if (!lr) lr = getenv("OMPI_COMM_WORLD_LOCAL_RANK");             // Open MPI
+    if (!lr) lr = getenv("MPI_LOCALRANKID");                        // MPICH / Intel MPI
+    if (!lr) lr = getenv("SLURM_LOCALID");
     device = lr ? atoi(lr) % ndev : 0;
   }
   HIP_TRY(hipSetDevice(device));
