@@ -172,6 +172,10 @@ static void free_matrix(fx_context *c) {
   dev_free(A.D); dev_free(A.AL); dev_free(A.AU); dev_free(A.B); dev_free(A.X);
   A = DevCSR();
   bell_free(c->M);
+  dev_free(c->ord.d_slot_node); dev_free(c->ord.d_slot_of);
+  c->ord = Ordering();
+  c->m_symbolic = false;
+  dev_free(c->Bs); dev_free(c->Xs);
   for (auto &w : c->W) dev_free(w);
   dev_free(c->partials);
   c->wlen = 0;
@@ -258,12 +262,8 @@ static int bell_build2(fx_context *c, Bell &b, int32_t nslots, const std::vector
       for (int l = 0; l < 64; l++) {
         const int64_t slot = s * 64 + l;
         ent.clear();
-        int32_t self = 0;
-        if (slot < nslots) {
-          self = slot_row ? (*slot_row)[slot] : (int32_t)slot;
-          if (self >= 0) fill((int32_t)slot, ent);
-          else self = 0;
-        }
+        const int32_t self = (int32_t)std::min<int64_t>(slot, (int64_t)b.nslices * 64 - 1);  // always a valid vector slot
+        if (slot < nslots && (!slot_row || (*slot_row)[slot] >= 0)) fill((int32_t)slot, ent);
         for (int32_t p = p0; p < p1; p++) {
           const size_t k = (size_t)(p - p0) * 2;
           int2 cc, ss;
@@ -284,13 +284,6 @@ static int bell_build2(fx_context *c, Bell &b, int32_t nslots, const std::vector
   HIP_TRY(hipMemcpyAsync(b.pair_ptr, pair_ptr.data(), pair_ptr.size() * 4, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(b.col2, col2.data(), col2.size() * sizeof(int2), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(b.src2, src2.data(), src2.size() * sizeof(int2), hipMemcpyHostToDevice, c->stream));
-  if (slot_row) {
-    if (dev_alloc(&b.slot_row, (size_t)b.nslices * 64)) return FX_ERROR_RUNTIME;
-    std::vector<int32_t> sr((size_t)b.nslices * 64, -1);
-    std::copy(slot_row->begin(), slot_row->end(), sr.begin());
-    HIP_TRY(hipMemcpyAsync(b.slot_row, sr.data(), sr.size() * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-  }
   HIP_TRY(hipStreamSynchronize(c->stream));  // host staging vectors die here
   return 0;
 }
@@ -303,37 +296,118 @@ static int bell_fill_values(fx_context *c, Bell &b) {
   return 0;
 }
 
-// full matrix M = [D | AL | AU] per row, in the reference's summation order
+// ---------------------------------------------------------------------------
+// solver numbering (Ordering) and the structures that depend on it
+// ---------------------------------------------------------------------------
+static int set_ordering(fx_context *c, int kind, const std::vector<int32_t> *color_slots /* slot -> node, -1 pad */) {
+  Ordering &o = c->ord;
+  const int32_t N = c->A.N, NP = c->A.NP;
+  dev_free(o.d_slot_node); dev_free(o.d_slot_of);
+  o = Ordering();
+  o.kind = kind;
+  o.nhalo = NP - N;
+  if (kind == 0) {
+    o.nslots = (N + 63) / 64 * 64;
+    o.slot_node.assign((size_t)o.nslots + o.nhalo, -1);
+    for (int32_t i = 0; i < N; i++) o.slot_node[i] = i;
+  } else {
+    o.nslots = (int32_t)color_slots->size();
+    o.slot_node.assign((size_t)o.nslots + o.nhalo, -1);
+    std::copy(color_slots->begin(), color_slots->end(), o.slot_node.begin());
+  }
+  for (int32_t h = 0; h < o.nhalo; h++) o.slot_node[(size_t)o.nslots + h] = N + h;
+  o.slot_of.assign((size_t)NP, 0);
+  for (int32_t s = 0; s < o.vslots(); s++)
+    if (o.slot_node[s] >= 0) o.slot_of[o.slot_node[s]] = s;
+  if (dev_alloc(&o.d_slot_node, o.slot_node.size()) || dev_alloc(&o.d_slot_of, o.slot_of.size())) return FX_ERROR_RUNTIME;
+  HIP_TRY(hipMemcpy(o.d_slot_node, o.slot_node.data(), o.slot_node.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(o.d_slot_of, o.slot_of.data(), o.slot_of.size() * 4, hipMemcpyHostToDevice));
+  c->m_symbolic = false;
+  c->bell_valid = false;
+  // halo tables in slot numbering
+  HaloDev &h = c->halo;
+  if (h.n_neighbor > 0) {
+    std::vector<int32_t> ei(h.h_export), ii(h.h_import);
+    for (auto &v : ei) v = o.slot_of[v];
+    for (auto &v : ii) v = o.slot_of[v];
+    HIP_TRY(hipMemcpy(h.export_item, ei.data(), ei.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h.import_item, ii.data(), ii.size() * 4, hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
+// full matrix M = [D | AL | AU] per row in the reference's summation order, rows and columns
+// in slot numbering
 static int build_full_bell(fx_context *c) {
-  const int32_t N = c->A.N;
+  const Ordering &o = c->ord;
   const int32_t *iL = c->h_indexL.data(), *jL = c->h_itemL.data(), *iU = c->h_indexU.data(), *jU = c->h_itemU.data();
-  auto count = [=](int32_t row) { return 1 + (iL[row + 1] - iL[row]) + (iU[row + 1] - iU[row]); };
-  auto fill = [=](int32_t row, std::vector<BellEntry> &e) {
-    e.push_back({3 * row + 0, row});
-    for (int32_t j = iL[row]; j < iL[row + 1]; j++) e.push_back({3 * j + 1, jL[j] - 1});
-    for (int32_t j = iU[row]; j < iU[row + 1]; j++) e.push_back({3 * j + 2, jU[j] - 1});
+  const int32_t *sn = o.slot_node.data(), *so = o.slot_of.data();
+  auto count = [=](int32_t slot) {
+    const int32_t r = sn[slot];
+    return r < 0 ? 0 : 1 + (iL[r + 1] - iL[r]) + (iU[r + 1] - iU[r]);
+  };
+  auto fill = [=](int32_t slot, std::vector<BellEntry> &e) {
+    const int32_t r = sn[slot];
+    e.push_back({3 * r + 0, slot});
+    for (int32_t j = iL[r]; j < iL[r + 1]; j++) e.push_back({3 * j + 1, so[jL[j] - 1]});
+    for (int32_t j = iU[r]; j < iU[r + 1]; j++) e.push_back({3 * j + 2, so[jU[j] - 1]});
   };
   if ((int64_t)3 * std::max(c->A.NPL, c->A.NPU) + 2 > INT32_MAX) {
     g_fx_error = "matrix too large for int32 block codes";
     return FX_ERROR_UNSUPPORTED;
   }
-  return bell_build2(c, c->M, N, nullptr, count, fill);
+  std::vector<int32_t> sr(o.slot_node.begin(), o.slot_node.begin() + o.nslots);
+  if (bell_build2(c, c->M, o.nslots, &sr, count, fill)) return FX_ERROR_RUNTIME;
+  c->m_symbolic = true;
+  c->bell_valid = false;
+  return 0;
+}
+
+static int ensure_work(fx_context *c);
+
+// Make the ordering, M (symbolic + values) and the work vectors current.
+static int ensure_solver(fx_context *c) {
+  if (c->ord.kind < 0 && set_ordering(c, 0, nullptr)) return FX_ERROR_RUNTIME;
+  if (!c->m_symbolic && build_full_bell(c)) return FX_ERROR_RUNTIME;
+  if (ensure_work(c)) return FX_ERROR_RUNTIME;
+  if (!c->bell_valid && c->have_values) {
+    if (bell_fill_values(c, c->M)) return FX_ERROR_RUNTIME;
+    c->bell_valid = true;
+  }
+  return 0;
+}
+
+static int to_slots(fx_context *c, const double *nat, double *out) {
+  const int vs = c->ord.vslots();
+  hipLaunchKernelGGL(k_to_slots, dim3((vs + 255) / 256), dim3(256), 0, c->stream, vs, c->ord.d_slot_node, nat, out);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+static int from_slots(fx_context *c, const double *in, double *nat) {
+  const int np = c->A.NP;
+  hipLaunchKernelGGL(k_from_slots, dim3((np + 255) / 256), dim3(256), 0, c->stream, np, c->ord.d_slot_of, in, nat);
+  HIP_TRY(hipGetLastError());
+  return 0;
 }
 
 // ---------------------------------------------------------------------------
 // upload
 // ---------------------------------------------------------------------------
 static int ensure_work(fx_context *c) {
-  const int32_t len = 3 * c->A.NP;
+  const int32_t len = 3 * c->ord.vslots();
   if (c->wlen != len) {
     for (auto &w : c->W) dev_free(w);
+    dev_free(c->Bs); dev_free(c->Xs);
     for (auto &w : c->W) {
       if (dev_alloc(&w, (size_t)len)) return FX_ERROR_RUNTIME;
       HIP_TRY(hipMemsetAsync(w, 0, (size_t)len * 8, c->stream));
     }
+    if (dev_alloc(&c->Bs, (size_t)len) || dev_alloc(&c->Xs, (size_t)len)) return FX_ERROR_RUNTIME;
+    HIP_TRY(hipMemsetAsync(c->Bs, 0, (size_t)len * 8, c->stream));
+    HIP_TRY(hipMemsetAsync(c->Xs, 0, (size_t)len * 8, c->stream));
     c->wlen = len;
   }
-  const int32_t need = std::max((c->A.N + FX_BLOCK - 1) / FX_BLOCK + 8, 4096 + 8);
+  const int32_t need = c->ord.nslots / FX_BLOCK + 4096 + 8;  // per-block partials of the largest grid + one slot per colour
   if (c->max_partials < need) {
     dev_free(c->partials);
     if (dev_alloc(&c->partials, (size_t)need * 3)) return FX_ERROR_RUNTIME;
@@ -356,14 +430,13 @@ static int setup_halo(fx_context *c, const fx_comm_view *cm) {
   h.export_index.assign(cm->export_index, cm->export_index + h.n_neighbor + 1);
   h.n_import = h.import_index.back();
   h.n_export = h.export_index.back();
-  std::vector<int32_t> ei(cm->export_item, cm->export_item + h.n_export), ii(cm->import_item, cm->import_item + h.n_import);
-  for (auto &v : ei) v -= 1;
-  for (auto &v : ii) v -= 1;
-  if (dev_alloc(&h.export_item, ei.size()) || dev_alloc(&h.import_item, ii.size())) return FX_ERROR_RUNTIME;
+  h.h_export.assign(cm->export_item, cm->export_item + h.n_export);
+  h.h_import.assign(cm->import_item, cm->import_item + h.n_import);
+  for (auto &v : h.h_export) v -= 1;
+  for (auto &v : h.h_import) v -= 1;
+  if (dev_alloc(&h.export_item, h.h_export.size()) || dev_alloc(&h.import_item, h.h_import.size())) return FX_ERROR_RUNTIME;
   if (dev_alloc(&h.sendbuf, (size_t)3 * h.n_export) || dev_alloc(&h.recvbuf, (size_t)3 * h.n_import)) return FX_ERROR_RUNTIME;
-  HIP_TRY(hipMemcpy(h.export_item, ei.data(), ei.size() * 4, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(h.import_item, ii.data(), ii.size() * 4, hipMemcpyHostToDevice));
-  return 0;
+  return 0;  // device item lists are written (in slot numbering) by set_ordering
 }
 
 extern "C" int fx_upload(fx_context *c, const fx_matrix_view *m, const fx_comm_view *cm, int what) {
@@ -392,9 +465,7 @@ extern "C" int fx_upload(fx_context *c, const fx_matrix_view *m, const fx_comm_v
     c->h_itemL.assign(m->itemL, m->itemL + A.NPL);
     c->h_itemU.assign(m->itemU, m->itemU + A.NPU);
     if (setup_halo(c, cm)) return FX_ERROR_RUNTIME;
-    if (ensure_work(c)) return FX_ERROR_RUNTIME;
-    if (build_full_bell(c)) return FX_ERROR_RUNTIME;
-    c->have_profile = true;
+    c->have_profile = true;  // ordering, BELL layout and work vectors are built on first use (ensure_solver)
     what |= FX_UP_VALUES;
     if (!m->D) what &= ~FX_UP_VALUES;  // profile-only upload (device assembly follows)
   }
@@ -402,9 +473,8 @@ extern "C" int fx_upload(fx_context *c, const fx_matrix_view *m, const fx_comm_v
     HIP_TRY(hipMemcpyAsync(A.D, m->D, (size_t)9 * A.NP * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(A.AL, m->AL, (size_t)9 * A.NPL * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(A.AU, m->AU, (size_t)9 * A.NPU * 8, hipMemcpyHostToDevice, c->stream));
-    if (bell_fill_values(c, c->M)) return FX_ERROR_RUNTIME;
     c->have_values = true;
-    c->bell_valid = true;
+    c->bell_valid = false;
     c->precond_valid = false;
   }
   if ((what & FX_UP_RHS) && m->B)
@@ -545,10 +615,10 @@ static int spmv(fx_context *c, int mode, int dot, double *x, const double *b, do
 #define SPMV_LAUNCH(MODE, DOT)                                                                                       \
   do {                                                                                                               \
     if (c->pipe_spmv)                                                                                                \
-      hipLaunchKernelGGL((k_spmv<MODE, DOT, true>), g, blk, 0, c->stream, M.nslices, c->A.N, M.pair_ptr, M.val2, M.col2, x, \
+      hipLaunchKernelGGL((k_spmv<MODE, DOT, true>), g, blk, 0, c->stream, M.nslices, c->ord.nslots, M.pair_ptr, M.val2, M.col2, x, \
                          b, y, part, gate, gate_val);                                                                \
     else                                                                                                             \
-      hipLaunchKernelGGL((k_spmv<MODE, DOT, false>), g, blk, 0, c->stream, M.nslices, c->A.N, M.pair_ptr, M.val2, M.col2, x, \
+      hipLaunchKernelGGL((k_spmv<MODE, DOT, false>), g, blk, 0, c->stream, M.nslices, c->ord.nslots, M.pair_ptr, M.val2, M.col2, x, \
                          b, y, part, gate, gate_val);                                                                \
   } while (0)
   if (mode == 0 && dot == 0) SPMV_LAUNCH(0, 0);
@@ -582,12 +652,11 @@ static int scalar_stage(fx_context *c, int nparts, int stride, int recompute_eve
 // preconditioner setup (hecmw_precond_33_setup, 33/hecmw_precond_33.f90:27-50)
 // ---------------------------------------------------------------------------
 static int diag_setup(fx_context *c, double sigma_diag) {
-  const int32_t N = c->A.N;
-  c->diag.nslices = (N + 63) / 64;
+  const int32_t nslots = c->ord.nslots;
+  c->diag.nslices = nslots / 64;
   dev_free(c->diag.alu);
   if (dev_alloc(&c->diag.alu, (size_t)c->diag.nslices * 576)) return FX_ERROR_RUNTIME;
-  const int nslots = c->diag.nslices * 64;
-  hipLaunchKernelGGL(k_alu_setup, dim3((nslots + 255) / 256), dim3(256), 0, c->stream, nslots, N, (const int32_t *)nullptr,
+  hipLaunchKernelGGL(k_alu_setup, dim3((nslots + 255) / 256), dim3(256), 0, c->stream, nslots, c->A.N, c->ord.d_slot_node,
                      c->A.D, sigma_diag, c->diag.alu);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -620,14 +689,14 @@ static int ssor_setup_symbolic(fx_context *c, int ncolor_in) {
       nlow[r] = k;
     }
   });
-  // slot order: colour by colour (each colour starts a new slice), inside a colour by nlow
+  // slot order: colour by colour (each colour starts a new slice); inside a colour natural node
+  // order (rows of one colour are independent), split only by the lower-block count so that
+  // boundary rows do not pad the interior slices
   std::vector<int32_t> slot_row;
   slot_row.reserve((size_t)N + 64 * S.ncolor);
   S.color_slice.assign(1, 0);
   for (int32_t col = 0; col < S.ncolor; col++) {
     std::vector<int32_t> rows(perm0.begin() + cidx[col], perm0.begin() + cidx[col + 1]);
-    // natural node order inside a colour (rows of one colour are independent): neighbouring lanes then
-    // gather neighbouring z entries; the stable sort by lower-block count only splits off boundary rows
     std::sort(rows.begin(), rows.end());
     std::stable_sort(rows.begin(), rows.end(), [&](int32_t a, int32_t b) { return nlow[a] < nlow[b]; });
     slot_row.insert(slot_row.end(), rows.begin(), rows.end());
@@ -635,22 +704,29 @@ static int ssor_setup_symbolic(fx_context *c, int ncolor_in) {
     S.color_slice.push_back((int32_t)(slot_row.size() / 64));
   }
   const int32_t nslots = (int32_t)slot_row.size();
-  // map old row -> (is block j of AL / AU) lists, ordered by new index as the reference does
+  // the whole solver now runs in this numbering (vectors, SpMV layout, halo lists)
+  if (set_ordering(c, 1, &slot_row)) return FX_ERROR_RUNTIME;
+  const int32_t *so = c->ord.slot_of.data();
+  // lower / upper parts per slot, entries ordered by the reference's new index (ascending for the
+  // forward sweep, descending for the backward sweep, as SSOR_33.f90:312 / :369 walk them)
   auto collect = [&](int32_t slot, std::vector<BellEntry> &e, bool lower) {
     const int32_t r = slot_row[slot];
     const int32_t me = newpos[r];
     const size_t first = e.size();
+    std::vector<std::pair<int32_t, BellEntry>> tmp;
     for (int32_t j = iL[r]; j < iL[r + 1]; j++) {
       const int32_t co = jL[j] - 1;
-      if ((newpos[co] < me) == lower) e.push_back({3 * j + 1, co});
+      if ((newpos[co] < me) == lower) tmp.push_back({newpos[co], {3 * j + 1, so[co]}});
     }
     for (int32_t j = iU[r]; j < iU[r + 1]; j++) {
       const int32_t co = jU[j] - 1;
       if (co >= N) continue;  // halo columns are dropped (hecmw_matrix_reorder.f90:50)
-      if ((newpos[co] < me) == lower) e.push_back({3 * j + 2, co});
+      if ((newpos[co] < me) == lower) tmp.push_back({newpos[co], {3 * j + 2, so[co]}});
     }
-    if (lower) std::sort(e.begin() + first, e.end(), [&](const BellEntry &a, const BellEntry &b) { return newpos[a.col] < newpos[b.col]; });
-    else std::sort(e.begin() + first, e.end(), [&](const BellEntry &a, const BellEntry &b) { return newpos[a.col] > newpos[b.col]; });
+    if (lower) std::sort(tmp.begin(), tmp.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+    else std::sort(tmp.begin(), tmp.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
+    (void)first;
+    for (auto &t : tmp) e.push_back(t.second);
   };
   auto countL = [&](int32_t slot) { const int32_t r = slot_row[slot]; return r < 0 ? 0 : nlow[r]; };
   auto countU = [&](int32_t slot) {
@@ -670,8 +746,8 @@ static int ssor_setup_numeric(fx_context *c, double sigma_diag) {
   SsorDev &S = c->ssor;
   if (bell_fill_values(c, S.L) || bell_fill_values(c, S.U)) return FX_ERROR_RUNTIME;
   const int nslots = S.L.nslices * 64;
-  hipLaunchKernelGGL(k_alu_setup, dim3((nslots + 255) / 256), dim3(256), 0, c->stream, nslots, c->A.N, S.L.slot_row, c->A.D,
-                     sigma_diag, S.alu);
+  hipLaunchKernelGGL(k_alu_setup, dim3((nslots + 255) / 256), dim3(256), 0, c->stream, nslots, c->A.N, c->ord.d_slot_node,
+                     c->A.D, sigma_diag, S.alu);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -682,7 +758,12 @@ extern "C" int fx_precond_setup(fx_context *c, const int32_t *Iarray, const doub
   const int precond = Iarray[2], iterpremax = Iarray[4], ncolor_in = Iarray[33] > 0 ? Iarray[33] : 10;
   double sigma_diag = Rarray[1];
   if (sigma_diag < 0.0) sigma_diag = 1.0;  // auto mode starts from 1 (hecmw_solver_Iterative.f90:68-73)
-  if (iterpremax <= 0) { free_precond(c); c->precond_valid = true; return 0; }
+  if (iterpremax <= 0) {
+    free_precond(c);
+    if (ensure_solver(c)) return FX_ERROR_RUNTIME;
+    c->precond_valid = true;
+    return 0;
+  }
   int kind;
   switch (precond) {
     case 1: case 2: kind = 1; break;
@@ -694,12 +775,15 @@ extern "C" int fx_precond_setup(fx_context *c, const int32_t *Iarray, const doub
   const bool symbolic = (kind != c->precond_kind) || (kind == 1 && (c->ssor.ncolor == 0 || c->ssor_ncolor_in != ncolor_in));
   if (symbolic) { free_precond(c); c->precond_kind = kind; }
   if (kind == 3) {
+    if (c->ord.kind != 0 && set_ordering(c, 0, nullptr)) return FX_ERROR_RUNTIME;  // block-Jacobi: natural numbering
+    if (ensure_solver(c)) return FX_ERROR_RUNTIME;
     if (diag_setup(c, sigma_diag)) return FX_ERROR_RUNTIME;
   } else {
     if (symbolic) {
       c->ssor_ncolor_in = ncolor_in;
-      if (ssor_setup_symbolic(c, ncolor_in)) return FX_ERROR_RUNTIME;
+      if (ssor_setup_symbolic(c, ncolor_in)) return FX_ERROR_RUNTIME;  // also switches the solver numbering
     }
+    if (ensure_solver(c)) return FX_ERROR_RUNTIME;
     if (ssor_setup_numeric(c, sigma_diag)) return FX_ERROR_RUNTIME;
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -711,7 +795,7 @@ extern "C" int fx_precond_setup(fx_context *c, const int32_t *Iarray, const doub
 // ZP/Z prologue is folded into the kernels).  want_dot: leave partials of r.z.
 // Returns the number of partials written (0 if none).
 static int precond_apply(fx_context *c, const double *r, double *z, bool want_dot, int *nparts) {
-  const int32_t N = c->A.N;
+  const int32_t N = c->ord.nslots;
   *nparts = 0;
   if (c->precond_kind == 3) {
     const int g = (N + FX_BLOCK - 1) / FX_BLOCK;
@@ -725,10 +809,10 @@ static int precond_apply(fx_context *c, const double *r, double *z, bool want_do
       if (s1 <= s0) continue;
       if (c->pipe_ssor)
         hipLaunchKernelGGL((k_ssor_color<true, true>), dim3((s1 - s0 + 3) / 4), dim3(FX_BLOCK), 0, c->stream, s0, s1,
-                           S.L.pair_ptr, S.L.val2, S.L.col2, S.L.slot_row, S.alu, r, z, (double *)nullptr, gate_status(c));
+                           S.L.pair_ptr, S.L.val2, S.L.col2, S.alu, r, z, (double *)nullptr, gate_status(c));
       else
         hipLaunchKernelGGL((k_ssor_color<true, false>), dim3((s1 - s0 + 3) / 4), dim3(FX_BLOCK), 0, c->stream, s0, s1,
-                           S.L.pair_ptr, S.L.val2, S.L.col2, S.L.slot_row, S.alu, r, z, (double *)nullptr, gate_status(c));
+                           S.L.pair_ptr, S.L.val2, S.L.col2, S.alu, r, z, (double *)nullptr, gate_status(c));
     }
     int off = 0;
     for (int col = S.ncolor - 1; col >= 0; col--) {
@@ -737,11 +821,11 @@ static int precond_apply(fx_context *c, const double *r, double *z, bool want_do
       const int g = (s1 - s0 + 3) / 4;
       if (c->pipe_ssor)
         hipLaunchKernelGGL((k_ssor_color<false, true>), dim3(g), dim3(FX_BLOCK), 0, c->stream, s0, s1, S.U.pair_ptr, S.U.val2,
-                           S.U.col2, S.U.slot_row, S.alu, r, z, want_dot ? c->partials + off : (double *)nullptr,
+                           S.U.col2, S.alu, r, z, want_dot ? c->partials + off : (double *)nullptr,
                            gate_status(c));
       else
         hipLaunchKernelGGL((k_ssor_color<false, false>), dim3(g), dim3(FX_BLOCK), 0, c->stream, s0, s1, S.U.pair_ptr, S.U.val2,
-                           S.U.col2, S.U.slot_row, S.alu, r, z, want_dot ? c->partials + off : (double *)nullptr,
+                           S.U.col2, S.alu, r, z, want_dot ? c->partials + off : (double *)nullptr,
                            gate_status(c));
       if (want_dot) off += g;
     }
@@ -755,7 +839,7 @@ static int precond_apply(fx_context *c, const double *r, double *z, bool want_do
 
 static int dot_into_partials(fx_context *c, const double *x, const double *y, const int32_t *gate, int32_t gate_val,
                              int *nparts) {
-  const int64_t n = (int64_t)3 * c->nn_internal;
+  const int64_t n = (int64_t)3 * c->ord.nslots;  // internal slots (padding entries are zero); the halo tail is excluded
   const int g = grid_for(n, FX_BLOCK, 2048);
   hipLaunchKernelGGL(k_dot, dim3(g), dim3(FX_BLOCK), 0, c->stream, n, x, y, c->partials, gate, gate_val);
   HIP_TRY(hipGetLastError());
@@ -793,9 +877,11 @@ static int poll_state(fx_context *c, KrylovState *out) {
 // split into begin (r0, ||b||) / steps (n iterations enqueued) / poll, so that callers can
 // time an exact number of iterations with nothing else in the bracket.
 static int krylov_begin(fx_context *c, int method, int maxit, double tol) {
-  const int64_t n3 = (int64_t)3 * c->nn_internal;
-  double *X = c->A.X, *B = c->A.B, *R = c->W[0];
+  const int64_t n3 = (int64_t)3 * c->ord.nslots;
+  double *X = c->Xs, *B = c->Bs, *R = c->W[0];
   int np;
+  if (ensure_solver(c)) return FX_ERROR_RUNTIME;
+  if (to_slots(c, c->A.B, c->Bs) || to_slots(c, c->A.X, c->Xs)) return FX_ERROR_RUNTIME;
   c->k_method = method; c->k_maxit = maxit; c->k_it = 1;
   if (krylov_init_state(c, maxit, tol)) return FX_ERROR_RUNTIME;
   HIP_TRY(hipMemsetAsync(c->W[2], 0, (size_t)c->wlen * 8, c->stream));  // P
@@ -812,9 +898,9 @@ static int krylov_begin(fx_context *c, int method, int maxit, double tol) {
 }
 
 static int cg_iteration(fx_context *c, int it) {
-  const int64_t n3 = (int64_t)3 * c->nn_internal;
+  const int64_t n3 = (int64_t)3 * c->ord.nslots;
   double *R = c->W[0], *Z = c->W[1], *Q = c->W[1], *P = c->W[2];
-  double *X = c->A.X, *B = c->A.B;
+  double *X = c->Xs, *B = c->Bs;
   const int RECOMPUTE = 50;
   const int vgrid = grid_for(n3, FX_BLOCK, 2048);
   int np;
@@ -847,10 +933,10 @@ static int cg_iteration(fx_context *c, int it) {
 }
 
 static int bicgstab_iteration(fx_context *c, int it) {
-  const int64_t n3 = (int64_t)3 * c->nn_internal;
+  const int64_t n3 = (int64_t)3 * c->ord.nslots;
   // R=1 RT=2 P=3 PT=4 S=5 ST=1 T=6 V=7 (:45-53); ST aliases R as in the reference
   double *R = c->W[0], *RT = c->W[1], *P = c->W[2], *PT = c->W[3], *S = c->W[4], *ST = c->W[0], *T = c->W[5], *V = c->W[6];
-  double *X = c->A.X, *B = c->A.B;
+  double *X = c->Xs, *B = c->Bs;
   const int RECOMPUTE = 100;
   const int vgrid = grid_for(n3, FX_BLOCK, 2048);
   int np;
@@ -963,7 +1049,17 @@ extern "C" int fx_solve_resident(fx_context *c, int32_t *Iarray, double *Rarray,
   double t0 = now_s();
   // hecmw_solve_check_zerorhs (:242-278): warning 2002, X = 0, the solve continues
   double rhs2 = 0.0, tmp;
-  if (dot_into_partials(c, c->A.B, c->A.B, nullptr, 0, &np)) return FX_ERROR_RUNTIME;
+  if (c->max_partials < 4096 + 8) {  // the two checks below only need the partial-sum buffer
+    dev_free(c->partials);
+    if (dev_alloc(&c->partials, (size_t)(4096 + 8) * 3)) return FX_ERROR_RUNTIME;
+    c->max_partials = 4096 + 8;
+  }
+  {  // sum over the internal rows of B (natural numbering: independent of the solver numbering)
+    const int64_t n = (int64_t)3 * c->A.N;
+    np = grid_for(n, FX_BLOCK, 2048);
+    hipLaunchKernelGGL(k_dot, dim3(np), dim3(FX_BLOCK), 0, c->stream, n, c->A.B, c->A.B, c->partials, (const int32_t *)nullptr, 0);
+    HIP_TRY(hipGetLastError());
+  }
   if (host_sum(c, np, 0, &rhs2, &tmp)) return FX_ERROR_RUNTIME;
   if (rhs2 == 0.0) {
     ret = FX_ERROR_ZERO_RHS;
@@ -1016,15 +1112,16 @@ extern "C" int fx_solve_resident(fx_context *c, int32_t *Iarray, double *Rarray,
     }
     break;
   }
-  // X halo (hecmw_update_m_R, hecmw_solver_CG.f90:280)
-  if (halo_update(c, c->A.X)) return FX_ERROR_RUNTIME;
+  // X halo (hecmw_update_m_R, hecmw_solver_CG.f90:280), then back to the caller's numbering
+  if (halo_update(c, c->Xs)) return FX_ERROR_RUNTIME;
+  if (from_slots(c, c->Xs, c->A.X)) return FX_ERROR_RUNTIME;
   HIP_TRY(hipStreamSynchronize(c->stream));
   const double t_sol = now_s() - t1;
   if (s.status > 1) ret = s.status;
   // final true residual (hecmw_rel_resid_L2, hecmw_solver_las.f90:129-158) -> Iarray(81)
   double r2 = 0.0, b2 = rhs2;
   if (b2 == 0.0) b2 = 1.0;
-  if (spmv(c, 1, 2, c->A.X, c->A.B, c->W[7], nullptr, 0)) return FX_ERROR_RUNTIME;
+  if (spmv(c, 1, 2, c->Xs, c->Bs, c->W[7], nullptr, 0)) return FX_ERROR_RUNTIME;
   if (host_sum(c, spmv_nparts(c), 0, &r2, &tmp)) return FX_ERROR_RUNTIME;
   const double resid2 = sqrt(r2 / b2);
   if (resid2 < Rarray[0]) Iarray[80] = 1;
@@ -1071,21 +1168,26 @@ extern "C" int fx_matvec(fx_context *c, const fx_matrix_view *m, const fx_comm_v
     if (e) return e;
   }
   HIP_TRY(hipSetDevice(c->device));
+  if (ensure_solver(c)) return FX_ERROR_RUNTIME;
   const size_t len = (size_t)3 * c->A.NP * 8;
-  HIP_TRY(hipMemcpyAsync(c->W[6], x, len, hipMemcpyHostToDevice, c->stream));
+  // natural-order staging in A.X's shadow: use W[5] (>= 3*NP doubles) for the host image
+  HIP_TRY(hipMemcpyAsync(c->W[5], x, len, hipMemcpyHostToDevice, c->stream));
+  if (to_slots(c, c->W[5], c->W[6])) return FX_ERROR_RUNTIME;
   const double t0 = now_s();
   if (halo_update(c, c->W[6])) return FX_ERROR_RUNTIME;
   if (commtime) { HIP_TRY(hipStreamSynchronize(c->stream)); *commtime += now_s() - t0; }
-  HIP_TRY(hipMemsetAsync(c->W[7], 0, len, c->stream));
+  HIP_TRY(hipMemsetAsync(c->W[7], 0, (size_t)c->wlen * 8, c->stream));
   {
     const Bell &M = c->M;
-    hipLaunchKernelGGL((k_spmv<0, 0, false>), dim3((M.nslices + 3) / 4), dim3(FX_BLOCK), 0, c->stream, M.nslices, c->A.N,
+    hipLaunchKernelGGL((k_spmv<0, 0, false>), dim3((M.nslices + 3) / 4), dim3(FX_BLOCK), 0, c->stream, M.nslices, c->ord.nslots,
                        M.pair_ptr, M.val2, M.col2, c->W[6], (const double *)nullptr, c->W[7], c->partials,
                        (const int32_t *)nullptr, 0);
     HIP_TRY(hipGetLastError());
   }
-  HIP_TRY(hipMemcpyAsync(y, c->W[7], (size_t)3 * c->A.N * 8, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(x, c->W[6], len, hipMemcpyDeviceToHost, c->stream));  // halo part of X is updated
+  if (from_slots(c, c->W[7], c->W[5])) return FX_ERROR_RUNTIME;
+  HIP_TRY(hipMemcpyAsync(y, c->W[5], (size_t)3 * c->A.N * 8, hipMemcpyDeviceToHost, c->stream));
+  if (from_slots(c, c->W[6], c->W[4])) return FX_ERROR_RUNTIME;
+  HIP_TRY(hipMemcpyAsync(x, c->W[4], len, hipMemcpyDeviceToHost, c->stream));  // halo part of X is updated
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -1093,10 +1195,12 @@ extern "C" int fx_matvec(fx_context *c, const fx_matrix_view *m, const fx_comm_v
 // y = A x on resident work vectors, timed with HIP events on the solver stream.
 extern "C" int fx_matvec_resident(fx_context *c, int nrepeat, float *ms_per_call) {
   HIP_TRY(hipSetDevice(c->device));
-  if (!c->bell_valid) { g_fx_error = "fx_matvec_resident: no matrix resident"; return FX_ERROR_RUNTIME; }
+  if (!c->have_values) { g_fx_error = "fx_matvec_resident: no matrix resident"; return FX_ERROR_RUNTIME; }
+  if (ensure_solver(c)) return FX_ERROR_RUNTIME;
+  if (to_slots(c, c->A.B, c->Bs)) return FX_ERROR_RUNTIME;
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
   for (int i = 0; i < nrepeat; i++)
-    if (spmv(c, 0, 0, c->A.B, nullptr, c->W[7], nullptr, 0)) return FX_ERROR_RUNTIME;
+    if (spmv(c, 0, 0, c->Bs, nullptr, c->W[7], nullptr, 0)) return FX_ERROR_RUNTIME;
   HIP_TRY(hipEventRecord(c->ev1, c->stream));
   HIP_TRY(hipEventSynchronize(c->ev1));
   HIP_TRY(hipGetLastError());
@@ -1113,11 +1217,14 @@ extern "C" int fx_precond_apply_host(fx_context *c, const double *r, double *z) 
   KrylovState s;
   memset(&s, 0, sizeof s);
   HIP_TRY(hipMemcpyAsync(c->st, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(c->W[6], r, len, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemsetAsync(c->W[7], 0, len, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->W[5], r, len, hipMemcpyHostToDevice, c->stream));
+  if (to_slots(c, c->W[5], c->W[6])) return FX_ERROR_RUNTIME;
+  HIP_TRY(hipMemsetAsync(c->W[6] + (size_t)3 * c->ord.nslots, 0, (size_t)3 * c->ord.nhalo * 8, c->stream));  // ZP(halo) = 0
+  HIP_TRY(hipMemsetAsync(c->W[7], 0, (size_t)c->wlen * 8, c->stream));
   int np;
   if (precond_apply(c, c->W[6], c->W[7], false, &np)) return FX_ERROR_RUNTIME;
-  HIP_TRY(hipMemcpyAsync(z, c->W[7], len, hipMemcpyDeviceToHost, c->stream));
+  if (from_slots(c, c->W[7], c->W[5])) return FX_ERROR_RUNTIME;
+  HIP_TRY(hipMemcpyAsync(z, c->W[5], len, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -1125,8 +1232,10 @@ extern "C" int fx_precond_apply_host(fx_context *c, const double *r, double *z) 
 extern "C" int fx_dot_host(fx_context *c, const double *x, const double *y, double *result) {
   HIP_TRY(hipSetDevice(c->device));
   const size_t len = (size_t)3 * c->A.NP * 8;
-  HIP_TRY(hipMemcpyAsync(c->W[6], x, len, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(c->W[7], y, len, hipMemcpyHostToDevice, c->stream));
+  if (ensure_solver(c)) return FX_ERROR_RUNTIME;
+  HIP_TRY(hipMemcpyAsync(c->W[4], x, len, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->W[5], y, len, hipMemcpyHostToDevice, c->stream));
+  if (to_slots(c, c->W[4], c->W[6]) || to_slots(c, c->W[5], c->W[7])) return FX_ERROR_RUNTIME;
   int np;
   double tmp;
   if (dot_into_partials(c, c->W[6], c->W[7], nullptr, 0, &np)) return FX_ERROR_RUNTIME;
@@ -1141,14 +1250,26 @@ extern "C" int fx_precond_apply_resident(fx_context *c, int nrepeat, float *ms_p
   memset(&s, 0, sizeof s);
   HIP_TRY(hipMemcpyAsync(c->st, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
   int np;
+  if (to_slots(c, c->A.B, c->Bs)) return FX_ERROR_RUNTIME;
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
   for (int i = 0; i < nrepeat; i++)
-    if (precond_apply(c, c->A.B, c->W[7], true, &np)) return FX_ERROR_RUNTIME;
+    if (precond_apply(c, c->Bs, c->W[7], true, &np)) return FX_ERROR_RUNTIME;
   HIP_TRY(hipEventRecord(c->ev1, c->stream));
   HIP_TRY(hipEventSynchronize(c->ev1));
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
   if (ms_per_call) *ms_per_call = ms / std::max(nrepeat, 1);
+  return 0;
+}
+
+// Scalars of the Krylov loop as they stand on the device (diagnostics):
+// out = rho rho1 beta c1 alpha omega c2 cg0 cg1 dnrm2 bnrm2 resid tol iter status need_verify
+extern "C" int fx_debug_state(fx_context *c, double out[16]) {
+  KrylovState s;
+  if (poll_state(c, &s)) return FX_ERROR_RUNTIME;
+  const double v[16] = {s.rho, s.rho1, s.beta, s.c1, s.alpha, s.omega, s.c2, s.cg0, s.cg1, s.dnrm2, s.bnrm2, s.resid, s.tol,
+                        (double)s.iter, (double)s.status, (double)s.need_verify};
+  memcpy(out, v, sizeof v);
   return 0;
 }
 

@@ -127,9 +127,7 @@ extern "C" int fx_assemble_c3d8(fx_context *c, const fx_mesh_view *mesh, double 
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(c->ev1, c->stream));
-  // refresh the streaming layout from the freshly assembled values
-  if (bell_fill_values(c, c->M)) return FX_ERROR_RUNTIME;
-  int32_t herr = 0;
+  int32_t herr = 0;  // the streaming (BELL) layouts re-gather these values on next use (ensure_solver)
   HIP_TRY(hipMemcpyAsync(&herr, d_err, 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   float ms = 0.f;
@@ -140,7 +138,7 @@ extern "C" int fx_assemble_c3d8(fx_context *c, const fx_mesh_view *mesh, double 
   if (herr == 1) { g_fx_error = "PIVOT ERROR in the incompatible-mode condensation (calInverse)"; return FX_ERROR_RUNTIME; }
   if (herr == 2) { g_fx_error = "###ERROR### : cannot find connectivity (element not covered by the profile)"; return FX_ERROR_RUNTIME; }
   c->have_values = true;
-  c->bell_valid = true;
+  c->bell_valid = false;
   c->precond_valid = false;
   return 0;
 }

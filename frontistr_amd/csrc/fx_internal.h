@@ -54,6 +54,24 @@ struct Bell {
   size_t bytes() const { return (size_t)npairs * 64 * (9 * 16 + 8) + (size_t)(nslices + 1) * 4; }
 };
 
+// Solver numbering.  All Krylov vectors and the BELL structures live in "slot" space:
+//   kind 0 (natural):      slot = node, padded to a multiple of 64;
+//   kind 1 (colour-major): the multicolour SSOR ordering of the reference (same colours), each
+//                          colour starting a new 64-slot slice, natural node order inside a
+//                          colour.  Neighbouring lanes then gather neighbouring vector entries
+//                          both in the colour sweeps and in the SpMV (full cache lines), which
+//                          the reference's old-numbering ZP indexing does not give a GPU.
+// Halo nodes N+h keep slot nslots+h.  Padding slots carry no blocks, an identity diagonal
+// factor and zeros in every vector, so kernels treat every slot as a row.
+struct Ordering {
+  int kind = -1;
+  int32_t nslots = 0, nhalo = 0;
+  std::vector<int32_t> slot_node;  // nslots+nhalo: 0-based node of a slot, -1 = padding
+  std::vector<int32_t> slot_of;    // NP: node -> slot
+  int32_t *d_slot_node = nullptr, *d_slot_of = nullptr;
+  int32_t vslots() const { return nslots + nhalo; }
+};
+
 // Multicolour SSOR state (hecmw_precond_SSOR_33.f90 module variables).
 struct SsorDev {
   int32_t ncolor = 0;
@@ -84,7 +102,8 @@ struct KrylovState {
 struct HaloDev {
   int32_t n_neighbor = 0;
   std::vector<int32_t> neighbor, import_index, export_index;
-  int32_t *export_item = nullptr, *import_item = nullptr;  // device, 0-based
+  std::vector<int32_t> h_export, h_import;                 // host, 0-based node ids
+  int32_t *export_item = nullptr, *import_item = nullptr;  // device, slot ids
   double *sendbuf = nullptr, *recvbuf = nullptr;
   int32_t n_export = 0, n_import = 0;
 };
@@ -93,8 +112,11 @@ struct fx_context {
   int device = 0;
   hipStream_t stream = nullptr;
   DevCSR A;
-  Bell M;  // full matrix (D + AL + AU) in natural row order, for SpMV
+  Ordering ord;
+  Bell M;  // full matrix (D + AL + AU) in slot order, for SpMV
   bool have_profile = false, have_values = false, bell_valid = false;
+  bool m_symbolic = false;   // M's source map matches the current ordering
+  double *Bs = nullptr, *Xs = nullptr;  // B, X in slot space
   // host copies of the profile (ordering, conversion maps)
   std::vector<int32_t> h_indexL, h_itemL, h_indexU, h_itemU;
   // preconditioner

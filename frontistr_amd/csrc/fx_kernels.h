@@ -184,7 +184,7 @@ __global__ __launch_bounds__(FX_BLOCK) void k_spmv(int32_t nslices, int32_t nrow
   if (slice < nslices)
     bell_row_sweep<PIPE>(pair_ptr[slice], pair_ptr[slice + 1], val2, col2, lane, x, y0, y1, y2);
   double d[1] = {0.0};
-  if (slice < nslices && row < nrows) {
+  if (slice < nslices) {
     if (MODE == 1) {
       y0 = b[(size_t)3 * row] - y0; y1 = b[(size_t)3 * row + 1] - y1; y2 = b[(size_t)3 * row + 2] - y2;
     }
@@ -273,7 +273,6 @@ __global__ __launch_bounds__(FX_BLOCK) void k_ssor_color(int32_t slice0, int32_t
                                                          const int32_t *__restrict__ pair_ptr,
                                                          const double2 *__restrict__ val2,
                                                          const int2 *__restrict__ col2,
-                                                         const int32_t *__restrict__ slot_row,
                                                          const double *__restrict__ alu,
                                                          const double *__restrict__ r, double *__restrict__ z,
                                                          double *__restrict__ partials,
@@ -284,11 +283,10 @@ __global__ __launch_bounds__(FX_BLOCK) void k_ssor_color(int32_t slice0, int32_t
   const int lane = threadIdx.x & 63;
   double d[1] = {0.0};
   if (slice < slice1) {
-    const int slot = slice * 64 + lane;
-    const int row = slot_row[slot];
+    const int row = slice * 64 + lane;  // slot space: every slot is a row (padding rows are all-zero)
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     bell_row_sweep<PIPE>(pair_ptr[slice], pair_ptr[slice + 1], val2, col2, lane, z, s0, s1, s2);
-    if (row >= 0) {
+    {
       double u[9];
       const size_t base = (size_t)slice * 576 + lane;
 #pragma unroll
@@ -493,6 +491,13 @@ __global__ void k_scalar(const double *__restrict__ partials, int32_t nparts, in
     const double resid = sqrt(v0 / st->bnrm2);
     st->resid = resid;
     const int it = st->iter;
+    if (!(resid == resid) || resid > 1.0e300) {
+      // Breakdown (BiCGSTAB rho or r~.v -> 0; the reference has no guard, hecmw_solver_BiCGSTAB.f90 and
+      // SURVEY 3.2, and would spin on NaN until MAXIT).  Deliberate deviation: stop now with the same
+      // outcome the reference reaches at MAXIT -- W-3001, not converged.
+      st->error = FX_ERROR_NOCONV_MAXIT; st->status = FX_ERROR_NOCONV_MAXIT; st->need_verify = 0;
+      return;
+    }
     if (OP == OP_RESID) {
       if (hist) hist[it - 1] = resid;
       if (resid <= st->tol) {
@@ -517,6 +522,24 @@ __global__ void k_scalar(const double *__restrict__ partials, int32_t nparts, in
     st->cg0 = v0; st->cg1 = v1;
     st->omega = v0 / v1;
   }
+}
+
+// natural <-> slot numbering of a 3-dof vector
+__global__ void k_to_slots(int32_t vslots, const int32_t *__restrict__ slot_node, const double *__restrict__ nat,
+                           double *__restrict__ out) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= vslots) return;
+  const int node = slot_node[s];
+  double a = 0.0, b = 0.0, c = 0.0;
+  if (node >= 0) { a = nat[(size_t)3 * node]; b = nat[(size_t)3 * node + 1]; c = nat[(size_t)3 * node + 2]; }
+  out[(size_t)3 * s] = a; out[(size_t)3 * s + 1] = b; out[(size_t)3 * s + 2] = c;
+}
+__global__ void k_from_slots(int32_t nnode, const int32_t *__restrict__ slot_of, const double *__restrict__ in,
+                             double *__restrict__ nat) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nnode) return;
+  const int s = slot_of[i];
+  nat[(size_t)3 * i] = in[(size_t)3 * s]; nat[(size_t)3 * i + 1] = in[(size_t)3 * s + 1]; nat[(size_t)3 * i + 2] = in[(size_t)3 * s + 2];
 }
 
 // Halo pack / unpack (hecmw_solve_send_recv_33, hecmw_solver_SR_33.F90:80-121)
