@@ -156,13 +156,16 @@ extern "C" int fx_create(int device, fx_context **out) {
   HIP_TRY(hipHostMalloc((void **)&c->st_host, sizeof(KrylovState) * 4, hipHostMallocDefault));
   if (const char *e = getenv("FX_PIPE_SPMV")) c->pipe_spmv = atoi(e) != 0;
   if (const char *e = getenv("FX_PIPE_SSOR")) c->pipe_ssor = atoi(e) != 0;
+  if (const char *e = getenv("FX_SSOR_MODE")) c->ssor_mode = atoi(e);
+  if (const char *e = getenv("FX_PIPE_MAX_SLICES")) c->pipe_max_slices = atoi(e);
   if (dev_alloc(&c->red_out, 16)) return FX_ERROR_RUNTIME;
   *out = c;
   return 0;
 }
 
 static void bell_free(Bell &b) {
-  dev_free(b.pair_ptr); dev_free(b.val2); dev_free(b.col2); dev_free(b.slot_row); dev_free(b.src2);
+  dev_free(b.pair_ptr); dev_free(b.val2_base); dev_free(b.col2); dev_free(b.slot_row); dev_free(b.src2);
+  b.val2 = nullptr;
   b = Bell();
 }
 
@@ -186,7 +189,7 @@ static void free_matrix(fx_context *c) {
 static void free_precond(fx_context *c) {
   dev_free(c->diag.alu);
   bell_free(c->ssor.L); bell_free(c->ssor.U);
-  dev_free(c->ssor.alu);
+  dev_free(c->ssor.alu); dev_free(c->ssor.slot_node); dev_free(c->ssor.zs);
   c->ssor = SsorDev();
   c->precond_valid = false;
   c->precond_kind = 0;
@@ -280,7 +283,14 @@ static int bell_build2(fx_context *c, Bell &b, int32_t nslots, const std::vector
   if (dev_alloc(&b.pair_ptr, (size_t)b.nslices + 1)) return FX_ERROR_RUNTIME;
   if (dev_alloc(&b.col2, (size_t)tot * 64)) return FX_ERROR_RUNTIME;
   if (dev_alloc(&b.src2, (size_t)tot * 64)) return FX_ERROR_RUNTIME;
-  if (dev_alloc(&b.val2, (size_t)tot * 576)) return FX_ERROR_RUNTIME;
+  {
+    size_t pad = 0;
+    if (const char *e = getenv("FX_VAL2_PAD")) pad = (size_t)atoll(e);
+    char *base = nullptr;
+    if (dev_alloc(&base, (size_t)tot * 576 * 16 + pad)) return FX_ERROR_RUNTIME;
+    b.val2_base = base;
+    b.val2 = (double2 *)(base + pad);
+  }
   HIP_TRY(hipMemcpyAsync(b.pair_ptr, pair_ptr.data(), pair_ptr.size() * 4, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(b.col2, col2.data(), col2.size() * sizeof(int2), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(b.src2, src2.data(), src2.size() * sizeof(int2), hipMemcpyHostToDevice, c->stream));
@@ -704,9 +714,21 @@ static int ssor_setup_symbolic(fx_context *c, int ncolor_in) {
     S.color_slice.push_back((int32_t)(slot_row.size() / 64));
   }
   const int32_t nslots = (int32_t)slot_row.size();
-  // the whole solver now runs in this numbering (vectors, SpMV layout, halo lists)
-  if (set_ordering(c, 1, &slot_row)) return FX_ERROR_RUNTIME;
-  const int32_t *so = c->ord.slot_of.data();
+  // node -> slot of the sweep's private colour-major vector
+  std::vector<int32_t> slot_of((size_t)N, 0);
+  for (int32_t sl = 0; sl < nslots; sl++)
+    if (slot_row[sl] >= 0) slot_of[slot_row[sl]] = sl;
+  const int32_t *so = slot_of.data();
+  S.nslots = nslots;
+  dev_free(S.slot_node); dev_free(S.zs);
+  if (dev_alloc(&S.slot_node, (size_t)nslots) || dev_alloc(&S.zs, (size_t)3 * nslots)) return FX_ERROR_RUNTIME;
+  HIP_TRY(hipMemcpy(S.slot_node, slot_row.data(), (size_t)nslots * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(S.zs, 0, (size_t)3 * nslots * 8));
+  if (c->ssor_mode == 1) {  // the whole solver runs in this numbering (vectors, SpMV layout, halo lists)
+    if (set_ordering(c, 1, &slot_row)) return FX_ERROR_RUNTIME;
+  } else if (c->ord.kind != 0) {
+    if (set_ordering(c, 0, nullptr)) return FX_ERROR_RUNTIME;
+  }
   // lower / upper parts per slot, entries ordered by the reference's new index (ascending for the
   // forward sweep, descending for the backward sweep, as SSOR_33.f90:312 / :369 walk them)
   auto collect = [&](int32_t slot, std::vector<BellEntry> &e, bool lower) {
@@ -746,8 +768,8 @@ static int ssor_setup_numeric(fx_context *c, double sigma_diag) {
   SsorDev &S = c->ssor;
   if (bell_fill_values(c, S.L) || bell_fill_values(c, S.U)) return FX_ERROR_RUNTIME;
   const int nslots = S.L.nslices * 64;
-  hipLaunchKernelGGL(k_alu_setup, dim3((nslots + 255) / 256), dim3(256), 0, c->stream, nslots, c->A.N, c->ord.d_slot_node,
-                     c->A.D, sigma_diag, S.alu);
+  hipLaunchKernelGGL(k_alu_setup, dim3((nslots + 255) / 256), dim3(256), 0, c->stream, nslots, c->A.N, S.slot_node, c->A.D,
+                     sigma_diag, S.alu);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -775,13 +797,13 @@ extern "C" int fx_precond_setup(fx_context *c, const int32_t *Iarray, const doub
   const bool symbolic = (kind != c->precond_kind) || (kind == 1 && (c->ssor.ncolor == 0 || c->ssor_ncolor_in != ncolor_in));
   if (symbolic) { free_precond(c); c->precond_kind = kind; }
   if (kind == 3) {
-    if (c->ord.kind != 0 && set_ordering(c, 0, nullptr)) return FX_ERROR_RUNTIME;  // block-Jacobi: natural numbering
+    if (c->ord.kind > 0 && set_ordering(c, 0, nullptr)) return FX_ERROR_RUNTIME;  // block-Jacobi: natural numbering
     if (ensure_solver(c)) return FX_ERROR_RUNTIME;
     if (diag_setup(c, sigma_diag)) return FX_ERROR_RUNTIME;
   } else {
     if (symbolic) {
       c->ssor_ncolor_in = ncolor_in;
-      if (ssor_setup_symbolic(c, ncolor_in)) return FX_ERROR_RUNTIME;  // also switches the solver numbering
+      if (ssor_setup_symbolic(c, ncolor_in)) return FX_ERROR_RUNTIME;
     }
     if (ensure_solver(c)) return FX_ERROR_RUNTIME;
     if (ssor_setup_numeric(c, sigma_diag)) return FX_ERROR_RUNTIME;
@@ -804,28 +826,32 @@ static int precond_apply(fx_context *c, const double *r, double *z, bool want_do
     if (want_dot) *nparts = g;
   } else if (c->precond_kind == 1) {
     SsorDev &S = c->ssor;
+    const bool full = (c->ord.kind == 1);  // Krylov vectors already colour-major: sweep in place on z
+    const int32_t *sn = full ? (const int32_t *)nullptr : S.slot_node;
+    double *zsweep = full ? z : S.zs, *znat = full ? (double *)nullptr : z;
     for (int col = 0; col < S.ncolor; col++) {
       const int s0 = S.color_slice[col], s1 = S.color_slice[col + 1];
       if (s1 <= s0) continue;
-      if (c->pipe_ssor)
+      // pipelined row loop (116 VGPRs, 4 waves/SIMD) only where the colour fits in one resident round
+      if (c->pipe_ssor && (s1 - s0) <= c->pipe_max_slices)
         hipLaunchKernelGGL((k_ssor_color<true, true>), dim3((s1 - s0 + 3) / 4), dim3(FX_BLOCK), 0, c->stream, s0, s1,
-                           S.L.pair_ptr, S.L.val2, S.L.col2, S.alu, r, z, (double *)nullptr, gate_status(c));
+                           S.L.pair_ptr, S.L.val2, S.L.col2, sn, S.alu, r, zsweep, znat, (double *)nullptr, gate_status(c));
       else
         hipLaunchKernelGGL((k_ssor_color<true, false>), dim3((s1 - s0 + 3) / 4), dim3(FX_BLOCK), 0, c->stream, s0, s1,
-                           S.L.pair_ptr, S.L.val2, S.L.col2, S.alu, r, z, (double *)nullptr, gate_status(c));
+                           S.L.pair_ptr, S.L.val2, S.L.col2, sn, S.alu, r, zsweep, znat, (double *)nullptr, gate_status(c));
     }
     int off = 0;
     for (int col = S.ncolor - 1; col >= 0; col--) {
       const int s0 = S.color_slice[col], s1 = S.color_slice[col + 1];
       if (s1 <= s0) continue;
       const int g = (s1 - s0 + 3) / 4;
-      if (c->pipe_ssor)
+      if (c->pipe_ssor && (s1 - s0) <= c->pipe_max_slices)
         hipLaunchKernelGGL((k_ssor_color<false, true>), dim3(g), dim3(FX_BLOCK), 0, c->stream, s0, s1, S.U.pair_ptr, S.U.val2,
-                           S.U.col2, S.alu, r, z, want_dot ? c->partials + off : (double *)nullptr,
+                           S.U.col2, sn, S.alu, r, zsweep, znat, want_dot ? c->partials + off : (double *)nullptr,
                            gate_status(c));
       else
         hipLaunchKernelGGL((k_ssor_color<false, false>), dim3(g), dim3(FX_BLOCK), 0, c->stream, s0, s1, S.U.pair_ptr, S.U.val2,
-                           S.U.col2, S.alu, r, z, want_dot ? c->partials + off : (double *)nullptr,
+                           S.U.col2, sn, S.alu, r, zsweep, znat, want_dot ? c->partials + off : (double *)nullptr,
                            gate_status(c));
       if (want_dot) off += g;
     }
@@ -885,6 +911,8 @@ static int krylov_begin(fx_context *c, int method, int maxit, double tol) {
   c->k_method = method; c->k_maxit = maxit; c->k_it = 1;
   if (krylov_init_state(c, maxit, tol)) return FX_ERROR_RUNTIME;
   HIP_TRY(hipMemsetAsync(c->W[2], 0, (size_t)c->wlen * 8, c->stream));  // P
+  if (c->precond_kind == 1)  // padding blocks multiply (value 0) x (the row's own stale entry): keep that entry finite
+    HIP_TRY(hipMemsetAsync(c->ssor.zs, 0, (size_t)3 * c->ssor.nslots * 8, c->stream));
   if (method == 2) HIP_TRY(hipMemsetAsync(c->W[6], 0, (size_t)c->wlen * 8, c->stream));  // V
   // r0 = b - A x0 (CG :120 / BiCGSTAB :107) ; ||b||^2 (:123-129 / :115-121)
   if (spmv(c, 1, 0, X, B, R, nullptr, 0)) return FX_ERROR_RUNTIME;

@@ -47,6 +47,7 @@ struct Bell {
   int64_t npairs = 0;
   int32_t *pair_ptr = nullptr;  // nslices+1
   double2 *val2 = nullptr;      // npairs*9*64
+  void *val2_base = nullptr;    // allocation holding val2 (placement experiments: FX_VAL2_PAD)
   int2 *col2 = nullptr;         // npairs*64
   int2 *src2 = nullptr;         // npairs*64: source block codes 3*idx+{0 D,1 AL,2 AU}, -1 padding (kept for numeric refresh)
   int32_t *slot_row = nullptr;  // nslots: 0-based node id of the slot, -1 = padding slot (may be null = identity)
@@ -78,6 +79,9 @@ struct SsorDev {
   std::vector<int32_t> color_slice;  // slice range per colour: [color_slice[c], color_slice[c+1])
   Bell L, U;                         // strictly-lower / strictly-upper parts in colour-slot order
   double *alu = nullptr;             // LU of the diagonal blocks, [slice][e][lane] layout
+  int32_t nslots = 0;                // colour-major slots (each colour padded to a 64 multiple)
+  int32_t *slot_node = nullptr;      // device: slot -> 0-based node, -1 = padding
+  double *zs = nullptr;              // private sweep vector, 3*nslots, colour-major
   std::vector<int32_t> perm;         // new -> old (1-based), as the reference's perm(:)
   std::vector<int32_t> colorindex;   // COLORindex(0:ncolor)
 };
@@ -125,8 +129,13 @@ struct fx_context {
   SsorDev ssor;
   bool precond_valid = false;
   int ssor_ncolor_in = 0;
-  // software-pipelined row loop: measured on MI355X at 10M DOF -- SSOR colour sweeps 2.31 -> 2.03 ms (few waves
-  // per SIMD, latency-bound), SpMV 1.19 -> 1.30 ms (116 VGPRs halve the occupancy) => on for SSOR only.
+  // SSOR numbering mode: 0 = Krylov vectors natural, sweep vector colour-major (hybrid);
+  //                      1 = the whole Krylov loop in colour-major numbering.  FX_SSOR_MODE overrides.
+  int ssor_mode = 0;
+  int pipe_max_slices = 4096;  // = 256 CUs x 4 SIMDs x 4 waves: what stays resident at 116 VGPRs
+  // software-pipelined row loop: measured on MI355X at 10M DOF -- with the sweep vector in the OLD numbering
+  // it took the SSOR apply from 2.31 to 2.03 ms; with the colour-major sweep vector it is neutral (1.87 ms
+  // either way); on the SpMV it costs occupancy (116 VGPRs): 1.19 -> 1.30 ms.  Kept for the small colours.
   bool pipe_spmv = false, pipe_ssor = true;  // FX_PIPE_SPMV / FX_PIPE_SSOR override
   // work vectors (3*NP each)
   double *W[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

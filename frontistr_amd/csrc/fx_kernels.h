@@ -263,19 +263,25 @@ __global__ __launch_bounds__(FX_BLOCK) void k_diag_apply(int32_t nrows, const do
 }
 
 // K7: one colour of the multicolour block SSOR sweep (hecmw_precond_SSOR_33.f90:300-352
-// forward, :355-410 backward).  Vectors stay in the OLD numbering (the reference indexes ZP
-// through perm); rows of one colour are independent.
-//   FWD: z_i = D~_i^-1 ( r_i - sum_{j in L(i)} L_ij z_j )      (reads r for the own row: the
-//        reference's ZP=R copy is folded away, earlier colours are already final in z)
-//   BWD: z_i = z_i - D~_i^-1 sum_{j in U(i)} U_ij z_j           (+ partial of r.z when asked)
+// forward, :355-410 backward).  Rows of one colour are independent.
+// The sweep works on a private vector zs in COLOUR-MAJOR slot numbering (each colour a
+// contiguous range, natural node order inside it), so the 13+13 neighbour gathers of
+// adjacent lanes hit adjacent entries and use full cache lines; the Krylov vectors r, z stay
+// in the natural numbering (where the SpMV gathers are best) and are touched only through
+// the row's own 24 bytes: r_i is read from r[node], the final z_i is written to z[node] by
+// the backward sweep.  (The reference keeps ZP in the old numbering and indexes it through
+// perm -- same arithmetic, different addresses.)
+//   FWD: zs_i = D~_i^-1 ( r_i - sum_{j in L(i)} L_ij zs_j )
+//   BWD: zs_i = zs_i - D~_i^-1 sum_{j in U(i)} U_ij zs_j ;  z[node_i] = zs_i  (+ partial of r.z)
 template <bool FWD, bool PIPE>
 __global__ __launch_bounds__(FX_BLOCK) void k_ssor_color(int32_t slice0, int32_t slice1,
                                                          const int32_t *__restrict__ pair_ptr,
                                                          const double2 *__restrict__ val2,
                                                          const int2 *__restrict__ col2,
+                                                         const int32_t *__restrict__ slot_node,
                                                          const double *__restrict__ alu,
-                                                         const double *__restrict__ r, double *__restrict__ z,
-                                                         double *__restrict__ partials,
+                                                         const double *__restrict__ r, double *__restrict__ zs,
+                                                         double *__restrict__ z, double *__restrict__ partials,
                                                          const int32_t *__restrict__ gate) {
   if (gate && *gate != 0) return;
   const int vb = xcd_block(blockIdx.x, gridDim.x);
@@ -283,17 +289,18 @@ __global__ __launch_bounds__(FX_BLOCK) void k_ssor_color(int32_t slice0, int32_t
   const int lane = threadIdx.x & 63;
   double d[1] = {0.0};
   if (slice < slice1) {
-    const int row = slice * 64 + lane;  // slot space: every slot is a row (padding rows are all-zero)
+    const int slot = slice * 64 + lane;
+    const int node = slot_node ? slot_node[slot] : slot;  // null: r and z already live in slot numbering
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    bell_row_sweep<PIPE>(pair_ptr[slice], pair_ptr[slice + 1], val2, col2, lane, z, s0, s1, s2);
-    {
+    bell_row_sweep<PIPE>(pair_ptr[slice], pair_ptr[slice + 1], val2, col2, lane, zs, s0, s1, s2);
+    if (node >= 0) {
       double u[9];
       const size_t base = (size_t)slice * 576 + lane;
 #pragma unroll
       for (int e = 0; e < 9; e++) u[e] = alu[base + (size_t)e * 64];
-      double *zi = z + (size_t)3 * row;
+      double *zi = zs + (size_t)3 * slot;
+      const double *ri = r + (size_t)3 * node;
       if (FWD) {
-        const double *ri = r + (size_t)3 * row;
         double x1 = ri[0] - s0, x2 = ri[1] - s1, x3 = ri[2] - s2;
         lusolve33_dev(u, x1, x2, x3);
         zi[0] = x1; zi[1] = x2; zi[2] = x3;
@@ -301,10 +308,11 @@ __global__ __launch_bounds__(FX_BLOCK) void k_ssor_color(int32_t slice0, int32_t
         lusolve33_dev(u, s0, s1, s2);
         const double x1 = zi[0] - s0, x2 = zi[1] - s1, x3 = zi[2] - s2;
         zi[0] = x1; zi[1] = x2; zi[2] = x3;
-        if (partials) {
-          const double *ri = r + (size_t)3 * row;
-          d[0] = ri[0] * x1 + ri[1] * x2 + ri[2] * x3;
+        if (z) {
+          double *zn = z + (size_t)3 * node;
+          zn[0] = x1; zn[1] = x2; zn[2] = x3;
         }
+        if (partials) d[0] = ri[0] * x1 + ri[1] * x2 + ri[2] * x3;
       }
     }
   }
