@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--n", type=int, default=149, help="elements per edge per GPU (149 -> 150^3 nodes = 10.125M DOF)")
-    ap.add_argument("--precond", type=int, default=1, help="1 SSOR (config 3), 3 block-Jacobi (config 2)")
+    ap.add_argument("--precond", type=int, default=1, help="1 SSOR (config 3), 3 block-Jacobi (config 2), 10 ILU(0)")
     ap.add_argument("--method", type=int, default=1, help="1 CG, 2 BiCGSTAB")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-n", type=int, default=69)
@@ -154,7 +154,7 @@ def main():
     alg = spmv_algorithmic_bytes(N, nb)
     achieved = alg / (ms_spmv * 1e-3) / 1e9
     # streamed bytes of one SSOR apply: L and U blocks (values + column ids), ALU twice, r once, z r/w twice
-    if a.precond == 1:
+    if a.precond in (1, 10):
         prec_bytes = 76 * (st["L_blocks"] + st["U_blocks"]) + 2 * 72 * N + 24 * N + 4 * 24 * N
     else:
         prec_bytes = 72 * N + 48 * N
@@ -176,7 +176,7 @@ def main():
         "config": {
             "workload": "synthetic %d^3-node linear-elastic C3D8 cube per GPU (%.3fM DOF/GPU, %.2fM DOF total), %s + %s, fp64"
                         % (a.n + 1, 3 * N / 1e6, 3 * N * world / 1e6, {1: "CG", 2: "BiCGSTAB"}[a.method],
-                           {1: "SSOR(1) multicolour", 3: "block-Jacobi"}[a.precond]),
+                           {1: "SSOR(1) multicolour", 3: "block-Jacobi", 10: "ILU(0) level-scheduled"}[a.precond]),
             "decomposition": "x".join(str(d) for d in decomposition(world)),
             "ncolor": st["ncolor"],
             "block_rows": N, "blocks": nb,

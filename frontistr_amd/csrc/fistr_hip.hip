@@ -190,6 +190,7 @@ static void free_precond(fx_context *c) {
   dev_free(c->diag.alu);
   bell_free(c->ssor.L); bell_free(c->ssor.U);
   dev_free(c->ssor.alu); dev_free(c->ssor.slot_node); dev_free(c->ssor.zs);
+  dev_free(c->ssor.lu_D); dev_free(c->ssor.lu_AL); dev_free(c->ssor.lu_AU);
   c->ssor = SsorDev();
   c->precond_valid = false;
   c->precond_kind = 0;
@@ -298,10 +299,11 @@ static int bell_build2(fx_context *c, Bell &b, int32_t nslots, const std::vector
   return 0;
 }
 
-static int bell_fill_values(fx_context *c, Bell &b) {
+static int bell_fill_values(fx_context *c, Bell &b, const double *D = nullptr, const double *AL = nullptr,
+                            const double *AU = nullptr) {
   if (b.nslices == 0) return 0;
   hipLaunchKernelGGL(k_bell_fill, dim3((b.nslices + 3) / 4), dim3(FX_BLOCK), 0, c->stream, b.nslices, b.pair_ptr,
-                     b.src2, c->A.D, c->A.AL, c->A.AU, b.val2);
+                     b.src2, D ? D : c->A.D, AL ? AL : c->A.AL, AU ? AU : c->A.AU, b.val2);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -774,6 +776,94 @@ static int ssor_setup_numeric(fx_context *c, double sigma_diag) {
   return 0;
 }
 
+// hecmw_precond_BILU_33_setup / FORM_ILU0_33 (hecmw_precond_BILU_33.f90:34-88, :185-362) by dependency
+// levels.  The level structure reuses the SSOR machinery: "colours" = levels, a private level-major
+// sweep vector, BELL copies of the strictly lower / upper FACTOR blocks; the apply (:90-157) is then the
+// same pair of sweeps as SSOR's, forward over ascending levels, backward over descending ones.
+static int ilu_setup_symbolic(fx_context *c) {
+  const int32_t N = c->A.N;
+  SsorDev &S = c->ssor;
+  const int32_t *iL = c->h_indexL.data(), *jL = c->h_itemL.data(), *iU = c->h_indexU.data(), *jU = c->h_itemU.data();
+  std::vector<int32_t> level((size_t)N, 0);
+  int32_t nlev = 0;
+  for (int32_t i = 0; i < N; i++) {  // rows in natural order: every k in L(i) is < i
+    int32_t l = 0;
+    for (int32_t j = iL[i]; j < iL[i + 1]; j++) l = std::max(l, level[jL[j] - 1]);
+    level[i] = l + 1;
+    nlev = std::max(nlev, l + 1);
+  }
+  std::vector<int32_t> cnt((size_t)nlev + 1, 0);
+  for (int32_t i = 0; i < N; i++) cnt[level[i]]++;
+  // slot order: level by level, natural order inside a level, each level padded to a 64 multiple
+  std::vector<int32_t> start((size_t)nlev + 2, 0);
+  for (int32_t l = 1; l <= nlev; l++) start[l + 1] = start[l] + (cnt[l] + 63) / 64 * 64;
+  const int32_t nslots = start[nlev + 1];
+  std::vector<int32_t> slot_row((size_t)nslots, -1), fillpos(start.begin(), start.end());
+  for (int32_t i = 0; i < N; i++) slot_row[fillpos[level[i]]++] = i;
+  std::vector<int32_t> slot_of((size_t)N);
+  for (int32_t sl = 0; sl < nslots; sl++)
+    if (slot_row[sl] >= 0) slot_of[slot_row[sl]] = sl;
+  S.ncolor = nlev;
+  S.color_slice.assign((size_t)nlev + 1, 0);
+  S.slot_start.assign((size_t)nlev + 1, 0);
+  for (int32_t l = 1; l <= nlev; l++) { S.color_slice[l] = start[l + 1] / 64; S.slot_start[l] = start[l + 1]; }
+  S.nslots = nslots;
+  dev_free(S.slot_node); dev_free(S.zs);
+  if (dev_alloc(&S.slot_node, (size_t)nslots) || dev_alloc(&S.zs, (size_t)3 * nslots)) return FX_ERROR_RUNTIME;
+  HIP_TRY(hipMemcpy(S.slot_node, slot_row.data(), (size_t)nslots * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(S.zs, 0, (size_t)3 * nslots * 8));
+  if (c->ord.kind > 0 && set_ordering(c, 0, nullptr)) return FX_ERROR_RUNTIME;
+  const int32_t *so = slot_of.data(), *sr = slot_row.data();
+  auto countL = [=](int32_t slot) { const int32_t r = sr[slot]; return r < 0 ? 0 : iL[r + 1] - iL[r]; };
+  auto countU = [=](int32_t slot) {
+    const int32_t r = sr[slot];
+    if (r < 0) return 0;
+    int32_t k = 0;
+    for (int32_t j = iU[r]; j < iU[r + 1]; j++) k += (jU[j] <= N);
+    return k;
+  };
+  auto fillL = [=](int32_t slot, std::vector<BellEntry> &e) {  // ascending columns (:104-111)
+    const int32_t r = sr[slot];
+    for (int32_t j = iL[r]; j < iL[r + 1]; j++) e.push_back({3 * j + 1, so[jL[j] - 1]});
+  };
+  auto fillU = [=](int32_t slot, std::vector<BellEntry> &e) {  // descending columns (:133 `do j= ieU, isU, -1`)
+    const int32_t r = sr[slot];
+    for (int32_t j = iU[r + 1] - 1; j >= iU[r]; j--)
+      if (jU[j] <= N) e.push_back({3 * j + 2, so[jU[j] - 1]});
+  };
+  if (bell_build2(c, S.L, nslots, &slot_row, countL, fillL)) return FX_ERROR_RUNTIME;
+  if (bell_build2(c, S.U, nslots, &slot_row, countU, fillU)) return FX_ERROR_RUNTIME;
+  dev_free(S.alu);
+  if (dev_alloc(&S.alu, (size_t)(nslots / 64) * 576)) return FX_ERROR_RUNTIME;
+  return 0;
+}
+
+static int ilu_setup_numeric(fx_context *c, double sigma_diag) {
+  SsorDev &S = c->ssor;
+  const DevCSR &A = c->A;
+  dev_free(S.lu_D); dev_free(S.lu_AL); dev_free(S.lu_AU);
+  if (dev_alloc(&S.lu_D, (size_t)9 * A.N) || dev_alloc(&S.lu_AL, (size_t)9 * A.NPL) || dev_alloc(&S.lu_AU, (size_t)9 * A.NPU))
+    return FX_ERROR_RUNTIME;
+  HIP_TRY(hipMemcpyAsync(S.lu_AL, A.AL, (size_t)9 * A.NPL * 8, hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(S.lu_AU, A.AU, (size_t)9 * A.NPU * 8, hipMemcpyDeviceToDevice, c->stream));
+  hipLaunchKernelGGL(k_dlu_natural, dim3((A.N + 255) / 256), dim3(256), 0, c->stream, A.N, A.D, sigma_diag, S.lu_D);
+  for (int32_t l = 1; l <= S.ncolor; l++) {
+    const int32_t s0 = S.slot_start[l - 1], s1 = S.slot_start[l];
+    if (l == 1 || s1 <= s0) continue;  // level 1 rows have no lower blocks
+    hipLaunchKernelGGL(k_ilu0_factor_level, dim3((s1 - s0 + 127) / 128), dim3(128), 0, c->stream, s0, s1, S.slot_node, A.N,
+                       A.indexL, A.itemL, A.indexU, A.itemU, S.lu_D, S.lu_AL, S.lu_AU);
+  }
+  HIP_TRY(hipGetLastError());
+  if (bell_fill_values(c, S.L, S.lu_D, S.lu_AL, S.lu_AU) || bell_fill_values(c, S.U, S.lu_D, S.lu_AL, S.lu_AU)) return FX_ERROR_RUNTIME;
+  const int nslots = S.nslots;
+  hipLaunchKernelGGL(k_alu_setup, dim3((nslots + 255) / 256), dim3(256), 0, c->stream, nslots, A.N, S.slot_node, A.D, sigma_diag,
+                     S.alu);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  dev_free(S.lu_D); dev_free(S.lu_AL); dev_free(S.lu_AU);  // the sweeps only stream the BELL copies
+  return 0;
+}
+
 extern "C" int fx_precond_setup(fx_context *c, const int32_t *Iarray, const double *Rarray) {
   HIP_TRY(hipSetDevice(c->device));
   if (!c->have_values) { g_fx_error = "fx_precond_setup: no matrix values resident"; return FX_ERROR_RUNTIME; }
@@ -790,16 +880,22 @@ extern "C" int fx_precond_setup(fx_context *c, const int32_t *Iarray, const doub
   switch (precond) {
     case 1: case 2: kind = 1; break;
     case 3: kind = 3; break;
+    case 10: kind = 10; break;
     default:
-      g_fx_error = "PRECOND=" + std::to_string(precond) + " is not on the GPU hot path yet (1,2 SSOR and 3 DIAG are)";
+      g_fx_error = "PRECOND=" + std::to_string(precond) + " is not on the GPU hot path (1,2 SSOR, 3 DIAG, 10 ILU(0) are)";
       return FX_ERROR_INCONS_PC;
   }
-  const bool symbolic = (kind != c->precond_kind) || (kind == 1 && (c->ssor.ncolor == 0 || c->ssor_ncolor_in != ncolor_in));
+  const bool symbolic = (kind != c->precond_kind) || (kind == 1 && (c->ssor.ncolor == 0 || c->ssor_ncolor_in != ncolor_in)) ||
+                        (kind == 10 && c->ssor.ncolor == 0);
   if (symbolic) { free_precond(c); c->precond_kind = kind; }
   if (kind == 3) {
     if (c->ord.kind > 0 && set_ordering(c, 0, nullptr)) return FX_ERROR_RUNTIME;  // block-Jacobi: natural numbering
     if (ensure_solver(c)) return FX_ERROR_RUNTIME;
     if (diag_setup(c, sigma_diag)) return FX_ERROR_RUNTIME;
+  } else if (kind == 10) {
+    if (symbolic && ilu_setup_symbolic(c)) return FX_ERROR_RUNTIME;
+    if (ensure_solver(c)) return FX_ERROR_RUNTIME;
+    if (ilu_setup_numeric(c, sigma_diag)) return FX_ERROR_RUNTIME;
   } else {
     if (symbolic) {
       c->ssor_ncolor_in = ncolor_in;
@@ -824,8 +920,13 @@ static int precond_apply(fx_context *c, const double *r, double *z, bool want_do
     hipLaunchKernelGGL(k_diag_apply, dim3(g), dim3(FX_BLOCK), 0, c->stream, N, c->diag.alu, r, z,
                        want_dot ? c->partials : (double *)nullptr, gate_status(c));
     if (want_dot) *nparts = g;
-  } else if (c->precond_kind == 1) {
+  } else if (c->precond_kind == 1 || c->precond_kind == 10) {
     SsorDev &S = c->ssor;
+    if (want_dot) {  // fused r.z partials need one slot per backward block; fall back to a separate dot otherwise
+      int64_t tot = 0;
+      for (int col = 0; col < S.ncolor; col++) tot += (S.color_slice[col + 1] - S.color_slice[col] + 3) / 4;
+      if (tot > c->max_partials) want_dot = false;
+    }
     const bool full = (c->ord.kind == 1);  // Krylov vectors already colour-major: sweep in place on z
     const int32_t *sn = full ? (const int32_t *)nullptr : S.slot_node;
     double *zsweep = full ? z : S.zs, *znat = full ? (double *)nullptr : z;
@@ -911,7 +1012,7 @@ static int krylov_begin(fx_context *c, int method, int maxit, double tol) {
   c->k_method = method; c->k_maxit = maxit; c->k_it = 1;
   if (krylov_init_state(c, maxit, tol)) return FX_ERROR_RUNTIME;
   HIP_TRY(hipMemsetAsync(c->W[2], 0, (size_t)c->wlen * 8, c->stream));  // P
-  if (c->precond_kind == 1)  // padding blocks multiply (value 0) x (the row's own stale entry): keep that entry finite
+  if (c->precond_kind == 1 || c->precond_kind == 10)  // padding blocks multiply (value 0) x (the row's own stale entry): keep that entry finite
     HIP_TRY(hipMemsetAsync(c->ssor.zs, 0, (size_t)3 * c->ssor.nslots * 8, c->stream));
   if (method == 2) HIP_TRY(hipMemsetAsync(c->W[6], 0, (size_t)c->wlen * 8, c->stream));  // V
   // r0 = b - A x0 (CG :120 / BiCGSTAB :107) ; ||b||^2 (:123-129 / :115-121)
@@ -1157,7 +1258,7 @@ extern "C" int fx_solve_resident(fx_context *c, int32_t *Iarray, double *Rarray,
     memset(info, 0, sizeof *info);
     info->iterations = s.iter;
     info->method = method; info->precond = precond;
-    info->ncolor = (c->precond_kind == 1) ? c->ssor.ncolor : 0;
+    info->ncolor = (c->precond_kind == 1 || c->precond_kind == 10) ? c->ssor.ncolor : 0;  // SSOR colours / ILU levels
     info->resid = s.resid;
     info->rel_resid = resid2;
     info->time_setup = t_setup; info->time_sol = t_sol;

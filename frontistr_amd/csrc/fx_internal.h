@@ -82,6 +82,8 @@ struct SsorDev {
   int32_t nslots = 0;                // colour-major slots (each colour padded to a 64 multiple)
   int32_t *slot_node = nullptr;      // device: slot -> 0-based node, -1 = padding
   double *zs = nullptr;              // private sweep vector, 3*nslots, colour-major
+  double *lu_D = nullptr, *lu_AL = nullptr, *lu_AU = nullptr;  // ILU(0): factor values in the reference CSR layout
+  std::vector<int32_t> slot_start;   // ILU(0): first slot of each level (ncolor+1)
   std::vector<int32_t> perm;         // new -> old (1-based), as the reference's perm(:)
   std::vector<int32_t> colorindex;   // COLORindex(0:ncolor)
 };

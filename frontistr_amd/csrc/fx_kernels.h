@@ -320,6 +320,82 @@ __global__ __launch_bounds__(FX_BLOCK) void k_ssor_color(int32_t slice0, int32_t
 }
 
 // ------------------------------------------------------------------------
+// K9: block ILU(0) (hecmw_precond_BILU_33.f90).  The reference factorises and substitutes
+// strictly sequentially (FORM_ILU0_33 :185-362, apply :90-157).  Here rows are grouped into
+// dependency levels (level(i) = 1 + max level of the rows in L(i)); rows of one level are
+// independent, so each level is one launch and every row sees exactly the operands, in exactly
+// the order, the sequential loop gives it -- same factors, same iteration counts.
+// ------------------------------------------------------------------------
+
+// LU of the (sigma-scaled) diagonal blocks in the natural [9*i] layout (ILU1a33 :1493-1528).
+// In the reference the Schur update of the diagonal block (:309-319) never executes (row i is
+// not in its own IW1/IW2 lists), so Dlu0 depends on D only.
+__global__ void k_dlu_natural(int32_t n, const double *__restrict__ D, double sigma_diag, double *__restrict__ Dlu) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double a[9];
+#pragma unroll
+  for (int e = 0; e < 9; e++) a[e] = D[(size_t)9 * i + e];
+  a[0] *= sigma_diag; a[4] *= sigma_diag; a[8] *= sigma_diag;
+  lu33_dev(a);
+#pragma unroll
+  for (int e = 0; e < 9; e++) Dlu[(size_t)9 * i + e] = a[e];
+}
+
+__device__ __forceinline__ int32_t item_find(const int32_t *item, int32_t lo, int32_t hi, int32_t val) {
+  while (lo < hi) {
+    const int32_t mid = (lo + hi) >> 1;
+    const int32_t v = item[mid];
+    if (v < val) lo = mid + 1;
+    else if (v > val) hi = mid;
+    else return mid;
+  }
+  return -1;
+}
+
+// One level of FORM_ILU0_33 (:254-345): A_ij -= A_ik * Dk^-1 * A_kj for k in L(i), j in U(k) and in
+// the pattern of row i (j /= i), k ascending as in the reference.  ILU1b33 (:1538-1596) inlined.
+__global__ void k_ilu0_factor_level(int32_t slot0, int32_t slot1, const int32_t *__restrict__ slot_node, int32_t N,
+                                    const int32_t *__restrict__ indexL, const int32_t *__restrict__ itemL,
+                                    const int32_t *__restrict__ indexU, const int32_t *__restrict__ itemU,
+                                    const double *__restrict__ Dlu, double *__restrict__ ALlu, double *__restrict__ AUlu) {
+  const int s = slot0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= slot1) return;
+  const int i = slot_node[s];
+  if (i < 0) return;
+  const int32_t iL0 = indexL[i], iL1 = indexL[i + 1], iU0 = indexU[i], iU1 = indexU[i + 1];
+  for (int32_t kk = iL0; kk < iL1; kk++) {
+    const int32_t k = itemL[kk] - 1;
+    double dk[9], aik[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) { dk[e] = Dlu[(size_t)9 * k + e]; aik[e] = ALlu[(size_t)9 * kk + e]; }
+    for (int32_t jj = indexU[k]; jj < indexU[k + 1]; jj++) {
+      const int32_t j = itemU[jj] - 1;
+      if (j >= N || j == i) continue;  // halo columns only ever multiply zeros; j == i: see k_dlu_natural
+      double *dst;
+      if (j < i) {
+        const int32_t pos = item_find(itemL, iL0, iL1, j + 1);
+        if (pos < 0) continue;
+        dst = ALlu + (size_t)9 * pos;
+      } else {
+        const int32_t pos = item_find(itemU, iU0, iU1, j + 1);
+        if (pos < 0) continue;
+        dst = AUlu + (size_t)9 * pos;
+      }
+      const double *akj = AUlu + (size_t)9 * jj;
+#pragma unroll
+      for (int col = 0; col < 3; col++) {
+        double x1 = akj[col], x2 = akj[3 + col], x3 = akj[6 + col];
+        lusolve33_dev(dk, x1, x2, x3);
+        dst[col] -= aik[0] * x1 + aik[1] * x2 + aik[2] * x3;
+        dst[3 + col] -= aik[3] * x1 + aik[4] * x2 + aik[5] * x3;
+        dst[6 + col] -= aik[6] * x1 + aik[7] * x2 + aik[8] * x3;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------
 // K3/K4: vector kernels (3*nn_internal entries), grid-stride, partial sums per block.
 // ------------------------------------------------------------------------
 __global__ __launch_bounds__(FX_BLOCK) void k_dot(int64_t n, const double *__restrict__ x,

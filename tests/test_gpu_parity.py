@@ -25,7 +25,7 @@ from conftest import golden_matrix, load_golden
 pytestmark = pytest.mark.gpu
 
 DECKS = ["cube4", "cube3s", "exA_A361"]
-GPU_CONFIGS = [(1, 3, 1), (1, 1, 4), (2, 3, 1), (2, 1, 4)]   # (method, precond, ref threads)
+GPU_CONFIGS = [(1, 3, 1), (1, 1, 4), (2, 3, 1), (2, 1, 4), (1, 10, 1), (2, 10, 1)]   # (method, precond, ref threads)
 
 
 @pytest.fixture(scope="module")
@@ -76,7 +76,7 @@ def test_matvec(hip, oracle, deck):
 
 
 @pytest.mark.parametrize("deck", DECKS)
-@pytest.mark.parametrize("pc", [3, 1])
+@pytest.mark.parametrize("pc", [3, 1, 10])
 def test_precond_apply(hip, oracle, deck, pc):
     A = golden_matrix(load_golden(deck))
     m = to_hecmat(hip, A)
@@ -118,11 +118,13 @@ def test_solve_matches_reference_golden(hip, deck, meth, pc, thr):
     check_solve(ctx.info, ctx.history, m.X, it_ref, h_ref, x_ref, meth, printed=True, whole=(deck != "exA_A361"))
     assert m.Iarray[80] == 1 and m.Iarray[81] == 0 and m.Iarray[96] == 0 and m.Iarray[97] == 0
     if pc == 1:
-        assert ctx.info.ncolor >= 10
+        assert ctx.info.ncolor >= 10                 # colours of the reference's multicolour ordering
+    if pc == 10:
+        assert ctx.info.ncolor >= 2                  # dependency levels of the ILU(0) sweeps
     ctx.close()
 
 
-@pytest.mark.parametrize("meth,pc", [(1, 3), (1, 1), (2, 3), (2, 1)])
+@pytest.mark.parametrize("meth,pc", [(1, 3), (1, 1), (2, 3), (2, 1), (1, 10), (2, 10)])
 def test_solve_larger_cube_vs_oracle(hip, oracle, meth, pc):
     """20^3-element cube (27.8k DOF): iteration-for-iteration against the oracle with the
     reference's multicolour ordering."""
@@ -159,7 +161,7 @@ def test_error_codes(hip):
         hip.hecmw_solve(None, m, ctx=ctx)
     assert e.value.code == hip.HECMW_SOLVER_ERROR_ZERO_DIAG
     m = to_hecmat(hip, A)
-    m.Iarray[2] = 10                            # ILU(0): not on the GPU hot path yet -> E-1001
+    m.Iarray[2] = 11                            # ILU(1): outside the GPU hot path -> E-1001
     with pytest.raises(hip.HecmwSolverError) as e:
         hip.hecmw_solve(None, m, ctx=ctx)
     assert e.value.code == hip.HECMW_SOLVER_ERROR_INCONS_PC
