@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--n", type=int, default=149, help="elements per edge per GPU (149 -> 150^3 nodes = 10.125M DOF)")
+    ap.add_argument("--elems", dest="n", type=int, default=149, help="elements per edge per GPU (149 -> 150^3 nodes = 10.125M DOF)")
     ap.add_argument("--precond", type=int, default=1, help="1 SSOR (config 3), 3 block-Jacobi (config 2), 10 ILU(0)")
     ap.add_argument("--method", type=int, default=1, help="1 CG, 2 BiCGSTAB")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -92,9 +92,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libfistr_hip has no CPU path")
-    torch.cuda.set_device(local_rank)
+    # FX_BENCH_TRANSPORT=gloo: rehearsal mode for boxes with fewer GPUs than ranks (ranks share devices,
+    # halos / reductions go through the library's host-callback transport).  Default: RCCL over xGMI.
+    transport = os.environ.get("FX_BENCH_TRANSPORT", "rccl")
+    dev = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if transport == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
 
     def barrier():
         if world > 1:
@@ -102,7 +109,7 @@ def main():
         torch.cuda.synchronize()
 
     t_setup0 = time.time()
-    ctx = hip.SolverContext(device=local_rank)
+    ctx = hip.SolverContext(device=dev)
     E, NU = 210000.0, 0.3
     if world == 1:
         mesh = CubeMesh(a.n)
@@ -110,14 +117,15 @@ def main():
         coord, conn, load, bc = mesh.coord, mesh.conn, mesh.load(), mesh.dirichlet()
     else:
         from frontistr_amd.partition import cube_subdomain
-        if rank == 0:
-            uid = torch.tensor(list(hip.comm_unique_id()), dtype=torch.uint8, device="cuda")
-        else:
-            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        dist.broadcast(uid, 0)
-        ctx.comm_init(bytes(uid.cpu().tolist()), rank, world)
         sub = cube_subdomain(a.n + 1, decomposition(world), rank)
         hm = sub.hecmesh(hip)
+        if transport == "gloo":
+            from frontistr_amd.comm import attach_host_callbacks
+            attach_host_callbacks(ctx, hm, hip.lib())
+        else:
+            uid = torch.tensor(list(hip.comm_unique_id()) if rank == 0 else [0] * 128, dtype=torch.uint8, device="cuda")
+            dist.broadcast(uid, 0)
+            ctx.comm_init(bytes(uid.cpu().tolist()), rank, world)
         coord, conn, load, bc = sub.coord, sub.conn, sub.load(), sub.dirichlet()
     hm.elem_node_item = conn.ravel()
     m = hip.hecmw_mat_con(hm, hip.hecmwST_matrix())
@@ -144,7 +152,7 @@ def main():
     assert status == 0 and it == a.warmup + a.steps + 1, (status, it)
     assert np.isfinite(resid)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if transport == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -162,8 +170,11 @@ def main():
 
     out = {
         "metric": "CG iterations/sec + SpMV achieved HBM GB/s, 10M-DOF 3x3-block mesh",
-        "value": a.steps / dt,
-        "unit": "CG iterations/s",
+        # weak scaling: every rank advances its own 10.125M-DOF subdomain by K iterations, so the job
+        # processed world*K subdomain-iterations (N=1: plain CG iterations/s on the 10M-DOF mesh)
+        "value": world * a.steps / dt,
+        "unit": "CG iterations/s" if world == 1 else "CG iterations/s x subdomains (10.125M-DOF subdomain-iterations/s, summed over GPUs)",
+        "global_iterations_per_s": a.steps / dt,
         "n_gpus": world,
         "steps": a.steps,
         "warmup": a.warmup,
@@ -178,6 +189,7 @@ def main():
                         % (a.n + 1, 3 * N / 1e6, 3 * N * world / 1e6, {1: "CG", 2: "BiCGSTAB"}[a.method],
                            {1: "SSOR(1) multicolour", 3: "block-Jacobi", 10: "ILU(0) level-scheduled"}[a.precond]),
             "decomposition": "x".join(str(d) for d in decomposition(world)),
+            "transport": "none" if world == 1 else transport,
             "ncolor": st["ncolor"],
             "block_rows": N, "blocks": nb,
         },

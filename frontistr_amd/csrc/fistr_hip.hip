@@ -870,6 +870,7 @@ extern "C" int fx_precond_setup(fx_context *c, const int32_t *Iarray, const doub
   const int precond = Iarray[2], iterpremax = Iarray[4], ncolor_in = Iarray[33] > 0 ? Iarray[33] : 10;
   double sigma_diag = Rarray[1];
   if (sigma_diag < 0.0) sigma_diag = 1.0;  // auto mode starts from 1 (hecmw_solver_Iterative.f90:68-73)
+  c->iterpremax = iterpremax;
   if (iterpremax <= 0) {
     free_precond(c);
     if (ensure_solver(c)) return FX_ERROR_RUNTIME;
@@ -912,7 +913,7 @@ extern "C" int fx_precond_setup(fx_context *c, const int32_t *Iarray, const doub
 // z = M^-1 r  (hecmw_precond_apply hecmw_precond.f90:75-123 with iterPREmax = 1; the
 // ZP/Z prologue is folded into the kernels).  want_dot: leave partials of r.z.
 // Returns the number of partials written (0 if none).
-static int precond_apply(fx_context *c, const double *r, double *z, bool want_dot, int *nparts) {
+static int precond_apply_once(fx_context *c, const double *r, double *z, bool want_dot, int *nparts) {
   const int32_t N = c->ord.nslots;
   *nparts = 0;
   if (c->precond_kind == 3) {
@@ -959,6 +960,27 @@ static int precond_apply(fx_context *c, const double *r, double *z, bool want_do
     *nparts = off;
   } else {  // iterPREmax <= 0: Z = R (hecmw_precond.f90:89-94)
     hipLaunchKernelGGL(k_copy, dim3(grid_for(3 * (int64_t)N)), dim3(256), 0, c->stream, (int64_t)3 * N, r, z);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+static int spmv(fx_context *c, int mode, int dot, double *x, const double *b, double *y, const int32_t *gate, int32_t gate_val);
+
+// hecmw_precond_33_apply (33/hecmw_precond_33.f90:74-115): iterPREmax additive-Schwarz sweeps,
+//   Z = 0; ZP = R; repeat { ZP <- M^-1 ZP; Z += ZP; ZP = R - A Z }.
+// The common iterPREmax = 1 case is the single fused sweep.
+static int precond_apply(fx_context *c, const double *r, double *z, bool want_dot, int *nparts) {
+  if (c->iterpremax <= 1 || c->precond_kind == 0) return precond_apply_once(c, r, z, want_dot, nparts);
+  *nparts = 0;  // r.z is taken by a separate dot afterwards
+  int np;
+  double *zp = c->W[8], *dz = c->W[9];
+  const int64_t n3 = (int64_t)3 * c->ord.nslots;
+  if (precond_apply_once(c, r, z, false, &np)) return FX_ERROR_RUNTIME;
+  for (int it = 2; it <= c->iterpremax; it++) {
+    if (spmv(c, 1, 0, z, r, zp, gate_status(c), 0)) return FX_ERROR_RUNTIME;  // ZP = R - A Z (halo update of Z inside)
+    if (precond_apply_once(c, zp, dz, false, &np)) return FX_ERROR_RUNTIME;
+    hipLaunchKernelGGL(k_axpy_plain, dim3(grid_for(n3)), dim3(256), 0, c->stream, n3, 1.0, dz, z);
   }
   HIP_TRY(hipGetLastError());
   return 0;
@@ -1134,6 +1156,7 @@ extern "C" int fx_krylov_begin(fx_context *c, const int32_t *Iarray, const doubl
   HIP_TRY(hipSetDevice(c->device));
   if (!c->have_values || !c->precond_valid) { g_fx_error = "fx_krylov_begin: matrix / preconditioner not resident"; return FX_ERROR_RUNTIME; }
   if (Iarray[1] != 1 && Iarray[1] != 2) { g_fx_error = "METHOD must be 1 (CG) or 2 (BiCGSTAB)"; return FX_ERROR_INCONS_PC; }
+  c->iterpremax = Iarray[4];
   const int e = krylov_begin(c, Iarray[1], Iarray[0], Rarray[0]);
   if (e) return e;
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1173,7 +1196,7 @@ extern "C" int fx_solve_resident(fx_context *c, int32_t *Iarray, double *Rarray,
   const int maxit = Iarray[0], precond = Iarray[2], method2 = Iarray[7], iterpremax = Iarray[4];
   int method = Iarray[1];
   const double tol = Rarray[0];
-  if (iterpremax > 1) { g_fx_error = "iterPREmax > 1 (additive Schwarz sweeps) is not on the GPU hot path yet"; return FX_ERROR_UNSUPPORTED; }
+  c->iterpremax = iterpremax;
   int ret = 0, np;
   double t0 = now_s();
   // hecmw_solve_check_zerorhs (:242-278): warning 2002, X = 0, the solve continues
@@ -1262,11 +1285,11 @@ extern "C" int fx_solve_resident(fx_context *c, int32_t *Iarray, double *Rarray,
     info->resid = s.resid;
     info->rel_resid = resid2;
     info->time_setup = t_setup; info->time_sol = t_sol;
-    const int nh = std::max(0, std::min({(int)hist_len, s.iter, maxit}));
+    const int nh = std::max(0, std::min((int)hist_len, (int)s.n_hist));
     info->n_hist = hist ? nh : 0;
   }
   if (hist && hist_len > 0) {
-    const int nh = std::max(0, std::min({(int)hist_len, s.iter, maxit}));
+    const int nh = std::max(0, std::min((int)hist_len, (int)s.n_hist));
     if (nh > 0) HIP_TRY(hipMemcpy(hist, c->hist, (size_t)nh * 8, hipMemcpyDeviceToHost));
   }
   return ret;

@@ -102,7 +102,8 @@ struct KrylovState {
   int32_t n_indef;
   int32_t maxit;
   int32_t error;        // 3001 set while running (reference sets error and falls out of the DO)
-  int32_t pad[2];
+  int32_t n_hist;       // residual-history lines written (the ITERLOG lines the reference would have printed)
+  int32_t pad[1];
 };
 
 struct HaloDev {
@@ -140,7 +141,8 @@ struct fx_context {
   // either way); on the SpMV it costs occupancy (116 VGPRs): 1.19 -> 1.30 ms.  Kept for the small colours.
   bool pipe_spmv = false, pipe_ssor = true;  // FX_PIPE_SPMV / FX_PIPE_SSOR override
   // work vectors (3*NP each)
-  double *W[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  double *W[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int iterpremax = 1;  // additive-Schwarz sweeps of hecmw_precond_33_apply
   int32_t wlen = 0;
   // reductions
   double *partials = nullptr;  // 3 * max_partials

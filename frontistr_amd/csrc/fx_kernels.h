@@ -598,6 +598,7 @@ __global__ void k_scalar(const double *__restrict__ partials, int32_t nparts, in
     }
     if (OP == OP_RESID) {
       if (hist) hist[it - 1] = resid;
+      st->n_hist = it;
       if (resid <= st->tol) {
         if (it % recompute_every == 0) { st->status = 1; return; }
         st->need_verify = 1;

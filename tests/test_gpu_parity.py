@@ -142,6 +142,33 @@ def test_solve_larger_cube_vs_oracle(hip, oracle, meth, pc):
     ctx.close()
 
 
+@pytest.mark.parametrize("meth,pc,ipm", [(1, 1, 2), (1, 3, 2), (2, 10, 2), (1, 1, 0), (1, 1, 3)])
+def test_additive_schwarz_sweeps(hip, oracle, meth, pc, ipm):
+    """iterPREmax /= 1: hecmw_precond_33_apply's outer loop (33/hecmw_precond_33.f90:92-114) and the
+    no-preconditioner case iterPREmax = 0 (hecmw_precond.f90:89-94).  Two block-Jacobi sweeps make an
+    indefinite preconditioner: the reference then stops with W-3003 after 3 sign flips of rho
+    (hecmw_solver_CG.f90:173-179) -- the same must happen here, at the same iteration."""
+    from oracle.refrun import default_params
+    g = load_golden("cube3s")
+    A = golden_matrix(g)
+    I, R = default_params(method=meth, precond=pc, iterpremax=ipm)
+    o = oracle.solve_iterative(A, I, R, nthreads=4)
+    m = to_hecmat(hip, A)
+    m.Iarray[0] = 10000; m.Iarray[1] = meth; m.Iarray[2] = pc; m.Iarray[4] = ipm
+    ctx = hip.SolverContext()
+    code = hip.hecmw_solve(None, m, ctx=ctx)
+    assert code == o["code"]
+    if code == 0:
+        whole = ipm > 0          # unpreconditioned CG on this badly scaled system is rounding-dominated
+        check_solve(ctx.info, ctx.history, m.X, o["iter"], o["history"], o["X"], meth, printed=False, whole=whole)
+    else:
+        assert code == hip.HECMW_SOLVER_ERROR_DIVERGE_PC and ctx.info.iterations == o["iter"]
+        assert m.Iarray[81] == 1 and m.Iarray[80] == 0
+        n = len(ctx.history)
+        assert n == o["iter"] - 1 and np.allclose(ctx.history, o["history"][:n], rtol=1e-9)
+    ctx.close()
+
+
 def test_error_codes(hip):
     g = load_golden("cube4")
     A = golden_matrix(g)
