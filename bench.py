@@ -44,7 +44,7 @@ def spmv_algorithmic_bytes(N, nb):
     return 72 * nb + 4 * (nb - N) + 2 * 4 * (N + 1) + 24 * N + 24 * N
 
 
-def cpu_baseline(hip, n_sample, iters, cores):
+def cpu_baseline(hip, n_sample, iters, cores, method=1, precond=1):
     """Reference CG + multicolour SSOR on a (n_sample+1)^3-node cube, `iters` iterations."""
     from frontistr_amd.mesh import CubeMesh
     from oracle import refrun
@@ -60,7 +60,7 @@ def cpu_baseline(hip, n_sample, iters, cores):
     ctx.download_matrix(m)          # the sample system is exactly what the GPU path assembled
     ctx.close()
     A = refrun.BSR(m.N, m.NP, m.indexL, m.itemL, m.indexU, m.itemU, m.D, m.AL, m.AU, m.B)
-    I, R = refrun.default_params(method=1, precond=1, maxit=iters, tol=1e-30, iterlog=0, timelog=1)
+    I, R = refrun.default_params(method=method, precond=precond, maxit=iters, tol=1e-30, iterlog=0, timelog=1)
     wd = "/dev/shm" if os.path.isdir("/dev/shm") else None
     r = refrun.run_solve(A, I, R, threads=cores, workdir=wd, timeout=900)
     if "t_per_iter" not in r or r["t_per_iter"] <= 0:
@@ -209,7 +209,7 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cores = max(1, min(len(os.sched_getaffinity(0)), 16))
         try:
-            cb = cpu_baseline(hip, a.cpu_sample_n, a.cpu_sample_iters, cores)
+            cb = cpu_baseline(hip, a.cpu_sample_n, a.cpu_sample_iters, cores, a.method, a.precond)
         except Exception as e:  # the baseline is reporting only; never fail the bench on it
             cb = None
             out["cpu_baseline_error"] = repr(e)
@@ -218,7 +218,7 @@ def main():
             out["cpu_baseline"] = {
                 "value": (1.0 / cb["per_iter"]) * scale, "unit": "CG iterations/s", "cores": cores,
                 "kind": "reference",
-                "sample": "HEC-MW reference (flang -fopenmp, OMP_NUM_THREADS=%d) CG+SSOR multicolour on a %d^3-node cube "
+                "sample": "HEC-MW reference (flang -fopenmp, OMP_NUM_THREADS=%d), same METHOD/PRECOND as the GPU run, on a %d^3-node cube "
                           "(%.2fM DOF), %d iterations: %.4f s/iter measured = %.2f it/s; value = that rate scaled by DOF "
                           "ratio %.4f to the %.2fM-DOF workload"
                           % (cores, a.cpu_sample_n + 1, cb["ndof"] / 1e6, a.cpu_sample_iters, cb["per_iter"],
