@@ -167,6 +167,13 @@ def main():
     else:
         prec_bytes = 72 * N + 48 * N
     bell_pad = 2.0 * st["M_pairs"] * 64 / max(nb, 1) - 1.0
+    traffic, traffic_src = None, None
+    try:  # PMC-measured HBM bytes per launch exist only for profiled workloads (committed under profiles/)
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["k_spmv"].get(str(N))
+        if tj and world == 1:
+            traffic, traffic_src = tj["traffic_bytes"], tj["source"]
+    except Exception:
+        pass
 
     out = {
         "metric": "CG iterations/sec + SpMV achieved HBM GB/s, 10M-DOF 3x3-block mesh",
@@ -196,7 +203,7 @@ def main():
         "roofline": {
             "bound": "hbm", "kernel": "k_spmv (BELL-64 3x3-block SpMV)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes": alg, "ms_per_launch": ms_spmv,
             "bell_padding_frac": bell_pad,
             "precond_apply": {"ms": ms_prec, "algorithmic_bytes": prec_bytes,
