@@ -231,10 +231,30 @@ def build_variant(name, drivers, omp, jobs, provides, uses, overrides=None, defi
     return exes
 
 
+def build_partitioner(jobs):
+    objdir = os.path.join(OUT, "obj_part")
+    os.makedirs(objdir, exist_ok=True)
+    lib = os.path.join(OUT, "obj_serial", "libhecmw_c.a")
+    if not os.path.exists(lib):
+        print("[part] needs the serial variant first (libhecmw_c.a)")
+        return
+    pdir = os.path.join(REF, "hecmw1/tools/partitioner")
+    srcs = [os.path.join(pdir, n) for n in sorted(os.listdir(pdir)) if n.endswith(".c")]
+    objs = []
+    for c in srcs:
+        o = objname(objdir, c)
+        run([GCC, "-O2", "-DHECMW_SERIAL", "-fcommon", "-w", "-I", os.path.join(REF, "hecmw1/src/common"), "-I", pdir,
+             "-c", c, "-o", o])
+        objs.append(o)
+    exe = os.path.join(OUT, "hecmw_part1")
+    run([GCC, "-o", exe] + objs + [lib, "-lm"])
+    print(f"[part] linked {exe}", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--jobs", type=int, default=4)
-    ap.add_argument("--only", choices=["solve", "fem", "shim"], default=None)
+    ap.add_argument("--only", choices=["solve", "fem", "shim", "part"], default=None)
     a = ap.parse_args()
     if not os.path.isdir(REF):
         print(f"reference not present at {REF}; oracle/_ref left as is")
@@ -251,6 +271,10 @@ def main():
         build_variant("omp", [solve], True, a.jobs, provides, uses)
     if a.only in (None, "fem") and os.path.exists(fem):
         build_variant("fem", [fem], False, a.jobs, provides, uses)
+    # The reference partitioner (hecmw1/tools/partitioner, plain C): fixture generator for the
+    # HECMW-DIST reader and the multi-rank tests (METHOD=RCB; METIS is absent in this image).
+    if a.only in (None, "part"):
+        build_partitioner(a.jobs)
     # Integration check of the drop-in boundary: the SAME driver, but `hecmw_solve` now comes from
     # frontistr_amd/shim/hecmw_solver_hip.f90 (module hecmw_solver) -> libfistr_hip.so.  The reference's
     # derived types and every other module are the reference's own objects.

@@ -10,14 +10,27 @@ import numpy as np  # noqa: E402
 
 def main():
     mode, rank, world, port, m, meth, pc, out = sys.argv[1:9]
-    rank, world, m, meth, pc = int(rank), int(world), int(m), int(meth), int(pc)
+    rank, world, meth, pc = int(rank), int(world), int(meth), int(pc)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from frontistr_amd.partition import cube_subdomain
     from frontistr_amd.comm import NeighborExchange
-    dims = {2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}[world]
-    sub = cube_subdomain(m, dims, rank)
+    if m.startswith("dist:"):
+        # subdomain written by the REFERENCE partitioner (HECMW-DIST file), deck of the synthetic cube:
+        # !BOUNDARY FIX,1,3,0.0 and !CLOAD TOP,1,1.0 through the node groups of the file
+        from frontistr_amd.hecmw_dist import read_dist
+        sub = read_dist("%s.%d" % (m[5:], rank))
+        fix = sub.group("FIX")
+        bc = (np.repeat(fix, 3).astype(np.int32), np.tile(np.array([1, 2, 3], dtype=np.int32), fix.size),
+              np.zeros(3 * fix.size))
+        load = np.zeros(3 * sub.n_node)
+        load[3 * (sub.group("TOP") - 1)] = 1.0
+        sub.dirichlet = lambda: bc
+        sub.load = lambda: load
+    else:
+        dims = {2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}[world]
+        sub = cube_subdomain(int(m), dims, rank)
     E, NU = 210000.0, 0.3
     if mode == "oracle":
         from oracle import pyoracle as po

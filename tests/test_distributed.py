@@ -114,3 +114,49 @@ def test_distributed_oracle_localized_ssor_converges(oracle, tmp_path):
     xs = ser["X"].reshape(-1, 3)
     for r in res:
         assert np.abs(r["X"].reshape(-1, 3) - xs[r["gid"]]).max() < 1e-7 * np.abs(xs).max()
+
+
+# ---- subdomains produced by the reference partitioner (HECMW-DIST fixtures) ---------------------------
+
+def dist_prefix():
+    return os.path.join(ROOT, "tests", "golden", "dist_cube4", "cube_p")
+
+
+def serial_cube4(oracle, meth, pc):
+    from frontistr_amd.mesh import CubeMesh
+    from oracle.refrun import default_params
+    mesh = CubeMesh(4)
+    A = oracle.assemble(1, mesh.coord, mesh.conn, 210000.0, 0.3, bc=mesh.dirichlet(), load=mesh.load())
+    I, R = default_params(method=meth, precond=pc)
+    return oracle.solve_iterative(A, I, R, nthreads=4)
+
+
+def test_dist_reader_on_reference_partitioner_files():
+    """hecmw_part1 (RCB, 4 domains) output: tables are mutually consistent and cover the mesh."""
+    from frontistr_amd.hecmw_dist import read_dist
+    subs = [read_dist("%s.%d" % (dist_prefix(), r)) for r in range(4)]
+    assert sum(s.nn_internal for s in subs) == 125 and all(s.PETOT == 4 for s in subs)
+    owner = {}
+    for s in subs:
+        assert s.my_rank == subs.index(s) and s.flag_parttype == 1 and s.n_dof == 3
+        assert np.all(s.node_ID[:s.nn_internal, 1] == s.my_rank)            # internal nodes first
+        assert np.all(s.node_ID[s.nn_internal:, 1] != s.my_rank)
+        for g in s.global_id[:s.nn_internal]:
+            owner[int(g)] = s.my_rank
+        assert tuple(s.materials["M1"]) == (210000.0, 0.3)
+    assert len(owner) == 125
+    for s in subs:
+        for q, pe in enumerate(s.neighbor_pe):
+            imp = s.global_id[s.import_item[s.import_index[q]:s.import_index[q + 1]] - 1]
+            t = subs[pe]
+            k = list(t.neighbor_pe).index(s.my_rank)
+            exp = t.global_id[t.export_item[t.export_index[k]:t.export_index[k + 1]] - 1]
+            assert np.array_equal(imp, exp)
+        assert (s.conn.min(axis=1) <= s.nn_internal).all()
+
+
+@pytest.mark.parametrize("meth", [1, 2])
+def test_reference_partition_oracle_block_jacobi_equals_serial(oracle, tmp_path, meth):
+    res = run_world("oracle", 4, "dist:" + dist_prefix(), meth, 3, tmp_path)
+    ser = serial_cube4(oracle, meth, 3)
+    check_against_serial(res, ser, meth)

@@ -6,7 +6,7 @@ the multi-GPU path this test cannot reach.)"""
 import numpy as np
 import pytest
 
-from test_distributed import check_against_serial, run_world, serial_reference
+from test_distributed import check_against_serial, dist_prefix, run_world, serial_cube4, serial_reference
 
 pytestmark = pytest.mark.gpu
 
@@ -59,3 +59,10 @@ print('rccl ok', ctx.info.iterations)
     p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        text=True, timeout=600)
     assert p.returncode == 0 and "rccl ok" in p.stdout, p.stdout[-3000:]
+
+
+def test_hip_on_reference_partitioner_files(oracle, tmp_path):
+    """configs[3] plumbing: 4 ranks read the HECMW-DIST files hecmw_part1 wrote and solve through the
+    library; the field equals the serial solve of the undecomposed mesh."""
+    res = run_world("hip", 4, "dist:" + dist_prefix(), 1, 3, tmp_path)
+    check_against_serial(res, serial_cube4(oracle, 1, 3), 1)
