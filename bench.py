@@ -166,7 +166,7 @@ def main():
         prec_bytes = 76 * (st["L_blocks"] + st["U_blocks"]) + 2 * 72 * N + 24 * N + 4 * 24 * N
     else:
         prec_bytes = 72 * N + 48 * N
-    bell_pad = 2.0 * st["M_pairs"] * 64 / max(nb, 1) - 1.0
+    bell_pad = st["M_pairs"] * 64.0 / max(nb, 1) - 1.0   # M_pairs counts block positions
     traffic, traffic_src = None, None
     try:  # PMC-measured HBM bytes per launch exist only for profiled workloads (committed under profiles/)
         tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["k_spmv"].get(str(N))

@@ -245,7 +245,7 @@ static int bell_build2(fx_context *c, Bell &b, int32_t nslots, const std::vector
         w = std::max(w, k);
         nb += k;
       }
-      pair_ptr[s + 1] = (w + 1) / 2;
+      pair_ptr[s + 1] = w;  // block positions of the slice (pairs + an optional single last block)
       blocks_per_slice[s] = nb;
     }
   });
@@ -253,30 +253,28 @@ static int bell_build2(fx_context *c, Bell &b, int32_t nslots, const std::vector
   b.nblocks = 0;
   for (int32_t s = 0; s < b.nslices; s++) {
     tot += pair_ptr[s + 1];
-    if (tot > INT32_MAX) { g_fx_error = "BELL: pair count overflows int32"; return FX_ERROR_RUNTIME; }
+    if (tot > INT32_MAX) { g_fx_error = "BELL: block-position count overflows int32"; return FX_ERROR_RUNTIME; }
     pair_ptr[s + 1] = (int32_t)tot;
     b.nblocks += blocks_per_slice[s];
   }
   b.npairs = tot;
-  std::vector<int2> col2((size_t)tot * 64), src2((size_t)tot * 64);
+  std::vector<int32_t> col2((size_t)tot * 64), src2((size_t)tot * 64);
   parallel_for(b.nslices, [&](int64_t s0, int64_t s1) {
     std::vector<BellEntry> ent;
     for (int64_t s = s0; s < s1; s++) {
-      const int32_t p0 = pair_ptr[s], p1 = pair_ptr[s + 1];
+      const int32_t h0 = pair_ptr[s], h1 = pair_ptr[s + 1];
+      const int32_t npair2 = ((h1 - h0) >> 1) << 1;
       for (int l = 0; l < 64; l++) {
         const int64_t slot = s * 64 + l;
         ent.clear();
         const int32_t self = (int32_t)std::min<int64_t>(slot, (int64_t)b.nslices * 64 - 1);  // always a valid vector slot
         if (slot < nslots && (!slot_row || (*slot_row)[slot] >= 0)) fill((int32_t)slot, ent);
-        for (int32_t p = p0; p < p1; p++) {
-          const size_t k = (size_t)(p - p0) * 2;
-          int2 cc, ss;
-          cc.x = k < ent.size() ? ent[k].col : self;
-          ss.x = k < ent.size() ? ent[k].src : -1;
-          cc.y = k + 1 < ent.size() ? ent[k + 1].col : self;
-          ss.y = k + 1 < ent.size() ? ent[k + 1].src : -1;
-          col2[(size_t)p * 64 + l] = cc;
-          src2[(size_t)p * 64 + l] = ss;
+        for (int32_t k = 0; k < h1 - h0; k++) {
+          const int32_t cc = (size_t)k < ent.size() ? ent[k].col : self;
+          const int32_t ss = (size_t)k < ent.size() ? ent[k].src : -1;
+          const size_t idx = k < npair2 ? (size_t)(h0 + (k & ~1)) * 64 + (size_t)l * 2 + (k & 1) : (size_t)(h0 + k) * 64 + l;
+          col2[idx] = cc;
+          src2[idx] = ss;
         }
       }
     }
@@ -288,13 +286,13 @@ static int bell_build2(fx_context *c, Bell &b, int32_t nslots, const std::vector
     size_t pad = 0;
     if (const char *e = getenv("FX_VAL2_PAD")) pad = (size_t)atoll(e);
     char *base = nullptr;
-    if (dev_alloc(&base, (size_t)tot * 576 * 16 + pad)) return FX_ERROR_RUNTIME;
+    if (dev_alloc(&base, (size_t)tot * 576 * 8 + pad)) return FX_ERROR_RUNTIME;
     b.val2_base = base;
-    b.val2 = (double2 *)(base + pad);
+    b.val2 = (double *)(base + pad);
   }
   HIP_TRY(hipMemcpyAsync(b.pair_ptr, pair_ptr.data(), pair_ptr.size() * 4, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(b.col2, col2.data(), col2.size() * sizeof(int2), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(b.src2, src2.data(), src2.size() * sizeof(int2), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(b.col2, col2.data(), col2.size() * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(b.src2, src2.data(), src2.size() * 4, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));  // host staging vectors die here
   return 0;
 }

@@ -34,25 +34,28 @@ struct DevCSR {
 // ---------------------------------------------------------------------------
 // BELL-64: sliced block-ELL, the layout every sweep kernel streams.
 //   slot  = 64*slice + lane; one thread owns one block row.
-//   slice s holds pairs [pair_ptr[s], pair_ptr[s+1]) of 3x3 blocks; for pair p
-//   and block element e (row-major, 0..8) the two values of lane l sit in one
-//   16-byte word:  val2[(p*9 + e)*64 + l] = (block 2p, block 2p+1)[e]
-//   and the two column node ids (0-based) in one 8-byte word: col2[p*64 + l].
+//   slice s holds block positions [pair_ptr[s], pair_ptr[s+1]) ("halves": one 3x3 block per lane
+//   each), consumed two at a time: for the pair starting at position h and block element e
+//   (row-major, 0..8) the two values of lane l sit in one 16-byte word
+//       ((double2*)(val + h*576))[e*64 + l] = (block h, block h+1)[e]
+//   and the two column ids (0-based vector slots) in one 8-byte word ((int2*)(col + h*64))[l].
+//   An odd last position of a slice is stored alone (val[h*576 + e*64 + l], col[h*64 + l]):
+//   hex-mesh rows have 27 blocks, pair padding would waste 1/27 of the stream.
 //   => every wave-level load is 1 KiB (values) / 512 B (columns), fully coalesced,
 //   and a lane never needs a cross-lane reduction.
 //   Padding blocks carry value 0 and the row's own column (always a valid address).
 // ---------------------------------------------------------------------------
 struct Bell {
   int32_t nslots = 0, nslices = 0;
-  int64_t npairs = 0;
-  int32_t *pair_ptr = nullptr;  // nslices+1
-  double2 *val2 = nullptr;      // npairs*9*64
+  int64_t npairs = 0;           // total block positions (halves) over all slices
+  int32_t *pair_ptr = nullptr;  // nslices+1, in halves
+  double *val2 = nullptr;       // npairs*9*64 doubles
   void *val2_base = nullptr;    // allocation holding val2 (placement experiments: FX_VAL2_PAD)
-  int2 *col2 = nullptr;         // npairs*64
-  int2 *src2 = nullptr;         // npairs*64: source block codes 3*idx+{0 D,1 AL,2 AU}, -1 padding (kept for numeric refresh)
+  int *col2 = nullptr;          // npairs*64
+  int *src2 = nullptr;          // npairs*64: source block codes 3*idx+{0 D,1 AL,2 AU}, -1 padding (kept for numeric refresh)
   int32_t *slot_row = nullptr;  // nslots: 0-based node id of the slot, -1 = padding slot (may be null = identity)
   int64_t nblocks = 0;          // real (non padding) blocks
-  size_t bytes() const { return (size_t)npairs * 64 * (9 * 16 + 8) + (size_t)(nslices + 1) * 4; }
+  size_t bytes() const { return (size_t)npairs * 64 * (9 * 8 + 4) + (size_t)(nslices + 1) * 4; }
 };
 
 // Solver numbering.  All Krylov vectors and the BELL structures live in "slot" space:

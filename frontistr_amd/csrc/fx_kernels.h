@@ -56,36 +56,34 @@ __device__ __forceinline__ void block_sum_store(double (&v)[NV], double *out, in
 // src code: 3*idx + which (0 = D, 1 = AL, 2 = AU), idx 0-based block; -1 = padding.
 // Run once per numeric refresh (Iarray(97)); reads 72 B segments, writes coalesced.
 // ------------------------------------------------------------------------
-__global__ void k_bell_fill(int32_t nslices, const int32_t *__restrict__ pair_ptr,
-                            const int2 *__restrict__ src2, const double *__restrict__ D,
-                            const double *__restrict__ AL, const double *__restrict__ AU,
-                            double2 *__restrict__ val2) {
+__global__ void k_bell_fill(int32_t nslices, const int32_t *__restrict__ half_ptr, const int32_t *__restrict__ src,
+                            const double *__restrict__ D, const double *__restrict__ AL,
+                            const double *__restrict__ AU, double *__restrict__ val) {
   const int slice = blockIdx.x * (FX_BLOCK / 64) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (slice >= nslices) return;
-  const int p0 = pair_ptr[slice], p1 = pair_ptr[slice + 1];
-  for (int p = p0; p < p1; p++) {
-    const int2 s = src2[(size_t)p * 64 + lane];
-    double a[9], b[9];
+  const int h0 = half_ptr[slice], h1 = half_ptr[slice + 1];
+  const int npair2 = ((h1 - h0) >> 1) << 1;  // blocks stored as 16-byte pairs; an odd last block is stored alone
+  for (int k = 0; k < h1 - h0; k++) {
+    const bool paired = k < npair2;
+    const size_t hb = (size_t)(h0 + (paired ? (k & ~1) : k));
+    const int sc = paired ? src[hb * 64 + lane * 2 + (k & 1)] : src[hb * 64 + lane];
+    double a[9];
 #pragma unroll
-    for (int e = 0; e < 9; e++) { a[e] = 0.0; b[e] = 0.0; }
-    if (s.x >= 0) {
-      const int w = s.x % 3;
-      const double *base = (w == 0 ? D : (w == 1 ? AL : AU)) + (size_t)9 * (s.x / 3);
+    for (int e = 0; e < 9; e++) a[e] = 0.0;
+    if (sc >= 0) {
+      const int w = sc % 3;
+      const double *base = (w == 0 ? D : (w == 1 ? AL : AU)) + (size_t)9 * (sc / 3);
 #pragma unroll
       for (int e = 0; e < 9; e++) a[e] = base[e];
     }
-    if (s.y >= 0) {
-      const int w = s.y % 3;
-      const double *base = (w == 0 ? D : (w == 1 ? AL : AU)) + (size_t)9 * (s.y / 3);
 #pragma unroll
-      for (int e = 0; e < 9; e++) b[e] = base[e];
+    for (int e = 0; e < 9; e++) {
+      if (paired) val[hb * 576 + (size_t)(e * 64 + lane) * 2 + (k & 1)] = a[e];
+      else val[hb * 576 + (size_t)e * 64 + lane] = a[e];
     }
-#pragma unroll
-    for (int e = 0; e < 9; e++) val2[((size_t)p * 9 + e) * 64 + lane] = make_double2(a[e], b[e]);
   }
 }
-
 
 // ------------------------------------------------------------------------
 // The row loop shared by SpMV and the SSOR sweeps:  s += sum_k A_k * x[col_k] over the
@@ -109,14 +107,34 @@ __device__ __forceinline__ int2 ld_stream(const int2 *p) {
   return make_int2(v.x, v.y);
 }
 
+__device__ __forceinline__ double ld_stream(const double *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ int ld_stream(const int *p) { return __builtin_nontemporal_load(p); }
+
+// An odd last block of the slice is stored alone (8-byte words) instead of padding the pair:
+// rows of a hex mesh have 27 blocks, so pair padding alone would cost 1/27 = 3.7 % of the stream.
+__device__ __forceinline__ void bell_tail_block(const double *__restrict__ vt, const int *__restrict__ ct,
+                                                const double *__restrict__ x, double &s0, double &s1, double &s2) {
+  const int cc = ld_stream(ct);
+  double a[9];
+#pragma unroll
+  for (int e = 0; e < 9; e++) a[e] = ld_stream(vt + e * 64);
+  const double *xa = x + (size_t)3 * cc;
+  const double xa0 = xa[0], xa1 = xa[1], xa2 = xa[2];
+  s0 += a[0] * xa0 + a[1] * xa1 + a[2] * xa2;
+  s1 += a[3] * xa0 + a[4] * xa1 + a[5] * xa2;
+  s2 += a[6] * xa0 + a[7] * xa1 + a[8] * xa2;
+}
+
 template <bool PIPE>
-__device__ __forceinline__ void bell_row_sweep(int p0, int p1, const double2 *__restrict__ val2,
-                                               const int2 *__restrict__ col2, int lane,
+__device__ __forceinline__ void bell_row_sweep(int h0, int h1, const double *__restrict__ val,
+                                               const int *__restrict__ col, int lane,
                                                const double *__restrict__ x, double &s0, double &s1, double &s2) {
-  const int np = p1 - p0;
+  const int np = (h1 - h0) >> 1;
+  if ((h1 - h0) & 1)
+    bell_tail_block(val + (size_t)(h0 + 2 * np) * 576 + lane, col + (size_t)(h0 + 2 * np) * 64 + lane, x, s0, s1, s2);
   if (np <= 0) return;
-  const double2 *v = val2 + (size_t)p0 * 576 + lane;
-  const int2 *c = col2 + (size_t)p0 * 64 + lane;
+  const double2 *v = (const double2 *)(val + (size_t)h0 * 576) + lane;
+  const int2 *c = (const int2 *)(col + (size_t)h0 * 64) + lane;
   if (!PIPE) {
     for (int i = 0; i < np; i++, v += 576, c += 64) {
       const int2 cc = ld_stream(c);
@@ -184,8 +202,8 @@ __device__ __forceinline__ void bell_row_sweep(int p0, int p1, const double2 *__
 template <int MODE, int DOT, bool PIPE>
 __global__ __launch_bounds__(FX_BLOCK) void k_spmv(int32_t nslices, int32_t nrows,
                                                    const int32_t *__restrict__ pair_ptr,
-                                                   const double2 *__restrict__ val2,
-                                                   const int2 *__restrict__ col2,
+                                                   const double *__restrict__ val2,
+                                                   const int *__restrict__ col2,
                                                    const double *__restrict__ x, const double *__restrict__ b,
                                                    double *__restrict__ y, double *__restrict__ partials,
                                                    const int32_t *__restrict__ gate, int32_t gate_val) {
@@ -290,8 +308,8 @@ __global__ __launch_bounds__(FX_BLOCK) void k_diag_apply(int32_t nrows, const do
 template <bool FWD, bool PIPE>
 __global__ __launch_bounds__(FX_BLOCK) void k_ssor_color(int32_t slice0, int32_t slice1,
                                                          const int32_t *__restrict__ pair_ptr,
-                                                         const double2 *__restrict__ val2,
-                                                         const int2 *__restrict__ col2,
+                                                         const double *__restrict__ val2,
+                                                         const int *__restrict__ col2,
                                                          const int32_t *__restrict__ slot_node,
                                                          const double *__restrict__ alu,
                                                          const double *__restrict__ r, double *__restrict__ zs,
