@@ -158,6 +158,8 @@ extern "C" int fx_create(int device, fx_context **out) {
   if (const char *e = getenv("FX_PIPE_SSOR")) c->pipe_ssor = atoi(e) != 0;
   if (const char *e = getenv("FX_SSOR_MODE")) c->ssor_mode = atoi(e);
   if (const char *e = getenv("FX_PIPE_MAX_SLICES")) c->pipe_max_slices = atoi(e);
+  if (const char *e = getenv("FX_SSOR_BS")) c->ssor_bs = (atoi(e) == 64) ? 64 : 256;
+  if (const char *e = getenv("FX_SPMV_BS")) c->spmv_bs = (atoi(e) == 64) ? 64 : 256;
   if (dev_alloc(&c->red_out, 16)) return FX_ERROR_RUNTIME;
   *out = c;
   return 0;
@@ -417,7 +419,7 @@ static int ensure_work(fx_context *c) {
     HIP_TRY(hipMemsetAsync(c->Xs, 0, (size_t)len * 8, c->stream));
     c->wlen = len;
   }
-  const int32_t need = c->ord.nslots / FX_BLOCK + 4096 + 8;  // per-block partials of the largest grid + one slot per colour
+  const int32_t need = c->ord.nslots / 64 + 4096 + 8;  // per-block partials of the largest grid + one slot per colour
   if (c->max_partials < need) {
     dev_free(c->partials);
     if (dev_alloc(&c->partials, (size_t)need * 3)) return FX_ERROR_RUNTIME;
@@ -620,16 +622,21 @@ static int spmv(fx_context *c, int mode, int dot, double *x, const double *b, do
                 int32_t gate_val) {
   if (halo_update(c, x)) return FX_ERROR_RUNTIME;
   const Bell &M = c->M;
-  const dim3 g((M.nslices + 3) / 4), blk(FX_BLOCK);
+  const int bs = c->spmv_bs;
+  const dim3 g((M.nslices + bs / 64 - 1) / (bs / 64)), blk(bs);
   double *part = c->partials;
-#define SPMV_LAUNCH(MODE, DOT)                                                                                       \
-  do {                                                                                                               \
-    if (c->pipe_spmv)                                                                                                \
-      hipLaunchKernelGGL((k_spmv<MODE, DOT, true>), g, blk, 0, c->stream, M.nslices, c->ord.nslots, M.pair_ptr, M.val2, M.col2, x, \
-                         b, y, part, gate, gate_val);                                                                \
-    else                                                                                                             \
-      hipLaunchKernelGGL((k_spmv<MODE, DOT, false>), g, blk, 0, c->stream, M.nslices, c->ord.nslots, M.pair_ptr, M.val2, M.col2, x, \
-                         b, y, part, gate, gate_val);                                                                \
+#define SPMV_LAUNCH3(MODE, DOT, PIPE, B)                                                                              \
+  hipLaunchKernelGGL((k_spmv<MODE, DOT, PIPE, B>), g, blk, 0, c->stream, M.nslices, c->ord.nslots, M.pair_ptr, M.val2, \
+                     M.col2, x, b, y, part, gate, gate_val)
+#define SPMV_LAUNCH(MODE, DOT)                                     \
+  do {                                                             \
+    if (c->pipe_spmv) {                                            \
+      if (bs == 64) SPMV_LAUNCH3(MODE, DOT, true, 64);             \
+      else SPMV_LAUNCH3(MODE, DOT, true, 256);                     \
+    } else {                                                       \
+      if (bs == 64) SPMV_LAUNCH3(MODE, DOT, false, 64);            \
+      else SPMV_LAUNCH3(MODE, DOT, false, 256);                    \
+    }                                                              \
   } while (0)
   if (mode == 0 && dot == 0) SPMV_LAUNCH(0, 0);
   else if (mode == 0 && dot == 1) SPMV_LAUNCH(0, 1);
@@ -637,10 +644,11 @@ static int spmv(fx_context *c, int mode, int dot, double *x, const double *b, do
   else if (mode == 1 && dot == 2) SPMV_LAUNCH(1, 2);
   else { g_fx_error = "spmv: bad mode"; return FX_ERROR_RUNTIME; }
 #undef SPMV_LAUNCH
+#undef SPMV_LAUNCH3
   HIP_TRY(hipGetLastError());
   return 0;
 }
-static inline int spmv_nparts(fx_context *c) { return (c->M.nslices + 3) / 4; }
+static inline int spmv_nparts(fx_context *c) { return (c->M.nslices + c->spmv_bs / 64 - 1) / (c->spmv_bs / 64); }
 
 template <int OP>
 static int scalar_stage(fx_context *c, int nparts, int stride, int recompute_every) {
@@ -923,38 +931,45 @@ static int precond_apply_once(fx_context *c, const double *r, double *z, bool wa
     SsorDev &S = c->ssor;
     if (want_dot) {  // fused r.z partials need one slot per backward block; fall back to a separate dot otherwise
       int64_t tot = 0;
-      for (int col = 0; col < S.ncolor; col++) tot += (S.color_slice[col + 1] - S.color_slice[col] + 3) / 4;
+      for (int col = 0; col < S.ncolor; col++) tot += (S.color_slice[col + 1] - S.color_slice[col]) / (c->ssor_bs / 64) + 1;
       if (tot > c->max_partials) want_dot = false;
     }
     const bool full = (c->ord.kind == 1);  // Krylov vectors already colour-major: sweep in place on z
     const int32_t *sn = full ? (const int32_t *)nullptr : S.slot_node;
     double *zsweep = full ? z : S.zs, *znat = full ? (double *)nullptr : z;
+    // Workgroup size per colour: 64-thread groups (one slice each) spread a colour evenly over the 256 CUs
+    // (a 150^3 colour has 5276 slices = 5.2 four-slice groups per CU: a 6-vs-5 imbalance); FX_SSOR_BS overrides.
+    const int bs = c->ssor_bs;
+    const int spb = bs / 64;
+#define SSOR_LAUNCH(FWD, B, g, s0, s1, part)                                                                          \
+  do {                                                                                                                \
+    if (c->pipe_ssor && (s1 - s0) <= c->pipe_max_slices)                                                              \
+      hipLaunchKernelGGL((k_ssor_color<FWD, true, B>), dim3(g), dim3(B), 0, c->stream, s0, s1, BL.pair_ptr, BL.val2,  \
+                         BL.col2, sn, S.alu, r, zsweep, znat, part, gate_status(c));                                  \
+    else                                                                                                              \
+      hipLaunchKernelGGL((k_ssor_color<FWD, false, B>), dim3(g), dim3(B), 0, c->stream, s0, s1, BL.pair_ptr, BL.val2, \
+                         BL.col2, sn, S.alu, r, zsweep, znat, part, gate_status(c));                                  \
+  } while (0)
     for (int col = 0; col < S.ncolor; col++) {
       const int s0 = S.color_slice[col], s1 = S.color_slice[col + 1];
       if (s1 <= s0) continue;
-      // pipelined row loop (116 VGPRs, 4 waves/SIMD) only where the colour fits in one resident round
-      if (c->pipe_ssor && (s1 - s0) <= c->pipe_max_slices)
-        hipLaunchKernelGGL((k_ssor_color<true, true>), dim3((s1 - s0 + 3) / 4), dim3(FX_BLOCK), 0, c->stream, s0, s1,
-                           S.L.pair_ptr, S.L.val2, S.L.col2, sn, S.alu, r, zsweep, znat, (double *)nullptr, gate_status(c));
-      else
-        hipLaunchKernelGGL((k_ssor_color<true, false>), dim3((s1 - s0 + 3) / 4), dim3(FX_BLOCK), 0, c->stream, s0, s1,
-                           S.L.pair_ptr, S.L.val2, S.L.col2, sn, S.alu, r, zsweep, znat, (double *)nullptr, gate_status(c));
+      const Bell &BL = S.L;
+      const int g = (s1 - s0 + spb - 1) / spb;
+      if (bs == 64) SSOR_LAUNCH(true, 64, g, s0, s1, (double *)nullptr);
+      else SSOR_LAUNCH(true, 256, g, s0, s1, (double *)nullptr);
     }
     int off = 0;
     for (int col = S.ncolor - 1; col >= 0; col--) {
       const int s0 = S.color_slice[col], s1 = S.color_slice[col + 1];
       if (s1 <= s0) continue;
-      const int g = (s1 - s0 + 3) / 4;
-      if (c->pipe_ssor && (s1 - s0) <= c->pipe_max_slices)
-        hipLaunchKernelGGL((k_ssor_color<false, true>), dim3(g), dim3(FX_BLOCK), 0, c->stream, s0, s1, S.U.pair_ptr, S.U.val2,
-                           S.U.col2, sn, S.alu, r, zsweep, znat, want_dot ? c->partials + off : (double *)nullptr,
-                           gate_status(c));
-      else
-        hipLaunchKernelGGL((k_ssor_color<false, false>), dim3(g), dim3(FX_BLOCK), 0, c->stream, s0, s1, S.U.pair_ptr, S.U.val2,
-                           S.U.col2, sn, S.alu, r, zsweep, znat, want_dot ? c->partials + off : (double *)nullptr,
-                           gate_status(c));
+      const Bell &BL = S.U;
+      const int g = (s1 - s0 + spb - 1) / spb;
+      double *part = want_dot ? c->partials + off : (double *)nullptr;
+      if (bs == 64) SSOR_LAUNCH(false, 64, g, s0, s1, part);
+      else SSOR_LAUNCH(false, 256, g, s0, s1, part);
       if (want_dot) off += g;
     }
+#undef SSOR_LAUNCH
     *nparts = off;
   } else {  // iterPREmax <= 0: Z = R (hecmw_precond.f90:89-94)
     hipLaunchKernelGGL(k_copy, dim3(grid_for(3 * (int64_t)N)), dim3(256), 0, c->stream, (int64_t)3 * N, r, z);
@@ -1327,13 +1342,7 @@ extern "C" int fx_matvec(fx_context *c, const fx_matrix_view *m, const fx_comm_v
   if (halo_update(c, c->W[6])) return FX_ERROR_RUNTIME;
   if (commtime) { HIP_TRY(hipStreamSynchronize(c->stream)); *commtime += now_s() - t0; }
   HIP_TRY(hipMemsetAsync(c->W[7], 0, (size_t)c->wlen * 8, c->stream));
-  {
-    const Bell &M = c->M;
-    hipLaunchKernelGGL((k_spmv<0, 0, false>), dim3((M.nslices + 3) / 4), dim3(FX_BLOCK), 0, c->stream, M.nslices, c->ord.nslots,
-                       M.pair_ptr, M.val2, M.col2, c->W[6], (const double *)nullptr, c->W[7], c->partials,
-                       (const int32_t *)nullptr, 0);
-    HIP_TRY(hipGetLastError());
-  }
+  if (spmv(c, 0, 0, c->W[6], nullptr, c->W[7], nullptr, 0)) return FX_ERROR_RUNTIME;  // (the halo update above made it current; a second one is idempotent)
   if (from_slots(c, c->W[7], c->W[5])) return FX_ERROR_RUNTIME;
   HIP_TRY(hipMemcpyAsync(y, c->W[5], (size_t)3 * c->A.N * 8, hipMemcpyDeviceToHost, c->stream));
   if (from_slots(c, c->W[6], c->W[4])) return FX_ERROR_RUNTIME;

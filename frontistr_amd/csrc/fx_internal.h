@@ -138,11 +138,14 @@ struct fx_context {
   // SSOR numbering mode: 0 = Krylov vectors natural, sweep vector colour-major (hybrid);
   //                      1 = the whole Krylov loop in colour-major numbering.  FX_SSOR_MODE overrides.
   int ssor_mode = 0;
-  int pipe_max_slices = 4096;  // = 256 CUs x 4 SIMDs x 4 waves: what stays resident at 116 VGPRs
-  // software-pipelined row loop: measured on MI355X at 10M DOF -- with the sweep vector in the OLD numbering
-  // it took the SSOR apply from 2.31 to 2.03 ms; with the colour-major sweep vector it is neutral (1.87 ms
-  // either way); on the SpMV it costs occupancy (116 VGPRs): 1.19 -> 1.30 ms.  Kept for the small colours.
-  bool pipe_spmv = false, pipe_ssor = true;  // FX_PIPE_SPMV / FX_PIPE_SSOR override
+  int ssor_bs = 64;            // workgroup size of the colour sweeps: 64 (default) or 256. Measured 10M DOF: 1.78 -> 1.61 ms per apply
+  int pipe_max_slices = 1 << 30;  // colours with more slices use the plain row loop (with 64-thread groups: pipelined everywhere wins, 1.61 vs 1.64/1.69 ms)
+  int spmv_bs = 256;              // workgroup size of the SpMV (FX_SPMV_BS)
+  // software-pipelined row loop (2-deep: values + gathers of pair i+1 and ids of pair i+2 in flight while pair i
+  // is multiplied; 116 VGPRs, 4 waves/SIMD).  Measured on MI355X at 10.1M DOF with the final layout (odd-tail BELL,
+  // non-temporal stream loads): SpMV 1.14-1.17 -> 1.105-1.11 ms; colour sweeps 1.685 -> 1.61 ms per apply.
+  // (With the earlier padded layout it cost the SpMV 1.19 -> 1.30 ms: re-measure when the layout changes.)
+  bool pipe_spmv = true, pipe_ssor = true;  // FX_PIPE_SPMV / FX_PIPE_SSOR override
   // work vectors (3*NP each)
   double *W[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int iterpremax = 1;  // additive-Schwarz sweeps of hecmw_precond_33_apply

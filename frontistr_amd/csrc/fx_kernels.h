@@ -29,10 +29,10 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-template <int NV>
+template <int NV, int BS = FX_BLOCK>
 __device__ __forceinline__ void block_sum_store(double (&v)[NV], double *out, int stride, int slot = -1) {
   if (slot < 0) slot = blockIdx.x;
-  __shared__ double sm[NV][FX_BLOCK / 64];
+  __shared__ double sm[NV][BS / 64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < NV; i++) {
@@ -45,7 +45,7 @@ __device__ __forceinline__ void block_sum_store(double (&v)[NV], double *out, in
     for (int i = 0; i < NV; i++) {
       double s = 0.0;
 #pragma unroll
-      for (int k = 0; k < FX_BLOCK / 64; k++) s += sm[i][k];
+      for (int k = 0; k < BS / 64; k++) s += sm[i][k];
       out[(size_t)i * stride + slot] = s;
     }
   }
@@ -199,8 +199,8 @@ __device__ __forceinline__ void bell_row_sweep(int h0, int h1, const double *__r
 // DOT  0: none  1: partial of x.y (p.q in CG)  2: partial of y.y (||r||^2 after matresid)
 // `gate` (may be null): device status word; the kernel is a no-op unless *gate == gate_val.
 // ------------------------------------------------------------------------
-template <int MODE, int DOT, bool PIPE>
-__global__ __launch_bounds__(FX_BLOCK) void k_spmv(int32_t nslices, int32_t nrows,
+template <int MODE, int DOT, bool PIPE, int BS>
+__global__ __launch_bounds__(BS) void k_spmv(int32_t nslices, int32_t nrows,
                                                    const int32_t *__restrict__ pair_ptr,
                                                    const double *__restrict__ val2,
                                                    const int *__restrict__ col2,
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(FX_BLOCK) void k_spmv(int32_t nslices, int32_t nrow
                                                    const int32_t *__restrict__ gate, int32_t gate_val) {
   if (gate && *gate != gate_val) return;
   const int vb = xcd_block(blockIdx.x, gridDim.x);
-  const int slice = vb * (FX_BLOCK / 64) + (threadIdx.x >> 6);
+  const int slice = vb * (BS / 64) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   double y0 = 0.0, y1 = 0.0, y2 = 0.0;
   const int row = slice * 64 + lane;
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(FX_BLOCK) void k_spmv(int32_t nslices, int32_t nrow
     if (DOT == 1) d[0] = x[(size_t)3 * row] * y0 + x[(size_t)3 * row + 1] * y1 + x[(size_t)3 * row + 2] * y2;
     if (DOT == 2) d[0] = y0 * y0 + y1 * y1 + y2 * y2;
   }
-  if (DOT != 0) block_sum_store<1>(d, partials, 0, vb);
+  if (DOT != 0) block_sum_store<1, BS>(d, partials, 0, vb);
 }
 
 // ------------------------------------------------------------------------
@@ -305,8 +305,8 @@ __global__ __launch_bounds__(FX_BLOCK) void k_diag_apply(int32_t nrows, const do
 // perm -- same arithmetic, different addresses.)
 //   FWD: zs_i = D~_i^-1 ( r_i - sum_{j in L(i)} L_ij zs_j )
 //   BWD: zs_i = zs_i - D~_i^-1 sum_{j in U(i)} U_ij zs_j ;  z[node_i] = zs_i  (+ partial of r.z)
-template <bool FWD, bool PIPE>
-__global__ __launch_bounds__(FX_BLOCK) void k_ssor_color(int32_t slice0, int32_t slice1,
+template <bool FWD, bool PIPE, int BS>
+__global__ __launch_bounds__(BS) void k_ssor_color(int32_t slice0, int32_t slice1,
                                                          const int32_t *__restrict__ pair_ptr,
                                                          const double *__restrict__ val2,
                                                          const int *__restrict__ col2,
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(FX_BLOCK) void k_ssor_color(int32_t slice0, int32_t
                                                          const int32_t *__restrict__ gate) {
   if (gate && *gate != 0) return;
   const int vb = xcd_block(blockIdx.x, gridDim.x);
-  const int slice = slice0 + vb * (FX_BLOCK / 64) + (threadIdx.x >> 6);
+  const int slice = slice0 + vb * (BS / 64) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   double d[1] = {0.0};
   if (slice < slice1) {
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(FX_BLOCK) void k_ssor_color(int32_t slice0, int32_t
       }
     }
   }
-  if (!FWD && partials) block_sum_store<1>(d, partials, 0, vb);
+  if (!FWD && partials) block_sum_store<1, BS>(d, partials, 0, vb);
 }
 
 // ------------------------------------------------------------------------
