@@ -557,7 +557,14 @@ enum ScalarOp {
 __device__ __forceinline__ double reduce_partials(const double *partials, int n) {
   __shared__ double sm[1024 / 64];
   double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) s += partials[i];
+  int i = threadIdx.x;
+  const int st = blockDim.x;
+  for (; i + 7 * st < n; i += 8 * st) {  // 8 independent loads in flight per thread, fixed summation order
+    const double a0 = partials[i], a1 = partials[i + st], a2 = partials[i + 2 * st], a3 = partials[i + 3 * st];
+    const double a4 = partials[i + 4 * st], a5 = partials[i + 5 * st], a6 = partials[i + 6 * st], a7 = partials[i + 7 * st];
+    s += ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+  }
+  for (; i < n; i += st) s += partials[i];
   s = wave_sum(s);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   __syncthreads();
