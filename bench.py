@@ -159,6 +159,7 @@ def main():
     # roofline of the dominant kernel, timed live with HIP events on the solver stream
     ms_spmv = ctx.matvec_resident_ms(20)
     ms_prec = ctx.precond_apply_ms(10)
+    stream_gbs = ctx.stream_ceiling_gbs(5)       # on-box read-streaming ceiling
     alg = spmv_algorithmic_bytes(N, nb)
     achieved = alg / (ms_spmv * 1e-3) / 1e9
     # streamed bytes of one SSOR apply: L and U blocks (values + column ids), ALU twice, r once, z r/w twice
@@ -203,6 +204,7 @@ def main():
         "roofline": {
             "bound": "hbm", "kernel": "k_spmv (BELL-64 3x3-block SpMV)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "measured_stream_ceiling": stream_gbs, "frac_of_measured_ceiling": achieved / stream_gbs,
             "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes": alg, "ms_per_launch": ms_spmv,
             "bell_padding_frac": bell_pad,

@@ -1432,6 +1432,26 @@ extern "C" int fx_debug_state(fx_context *c, double out[16]) {
   return 0;
 }
 
+// Measured read-streaming rate of this device over the resident value array of M (GB/s).
+extern "C" int fx_stream_ceiling(fx_context *c, int nrepeat, double *gbs) {
+  HIP_TRY(hipSetDevice(c->device));
+  if (ensure_solver(c)) return FX_ERROR_RUNTIME;
+  const int64_t n2 = (int64_t)c->M.npairs * 576 / 2;  // double2 words
+  if (n2 <= 0) { g_fx_error = "fx_stream_ceiling: no matrix resident"; return FX_ERROR_RUNTIME; }
+  const int g = 256 * 8;  // 8 workgroups per CU, grid-stride
+  hipLaunchKernelGGL(k_stream_read, dim3(g), dim3(FX_BLOCK), 0, c->stream, n2, (const double2 *)c->M.val2, c->partials);
+  HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  for (int i = 0; i < nrepeat; i++)
+    hipLaunchKernelGGL(k_stream_read, dim3(g), dim3(FX_BLOCK), 0, c->stream, n2, (const double2 *)c->M.val2, c->partials);
+  HIP_TRY(hipEventRecord(c->ev1, c->stream));
+  HIP_TRY(hipEventSynchronize(c->ev1));
+  HIP_TRY(hipGetLastError());
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  *gbs = (double)n2 * 16.0 * nrepeat / (ms * 1e-3) / 1e9;
+  return 0;
+}
+
 // Sizes of the resident structures (for the algorithmic-bytes accounting of bench.py).
 // out[0] N, [1] NP, [2] NPL, [3] NPU, [4] M.npairs, [5] M.nblocks, [6] M.nslices,
 // [7] ssor.ncolor, [8] L.npairs, [9] L.nblocks, [10] U.npairs, [11] U.nblocks, [12] ssor slices

@@ -233,6 +233,11 @@ class SolverContext:
         _chk(lib().fx_precond_apply_resident(self.h, nrepeat, C.byref(ms)))
         return ms.value
 
+    def stream_ceiling_gbs(self, nrepeat=5):
+        out = C.c_double(0)
+        _chk(lib().fx_stream_ceiling(self.h, nrepeat, C.byref(out)))
+        return out.value
+
     def stats(self):
         out = (C.c_int64 * 16)()
         _chk(lib().fx_get_stats(self.h, out))

@@ -124,6 +124,9 @@ int fx_precond_apply_resident(fx_context *ctx, int nrepeat, float *ms_per_call);
 int fx_precond_apply_host(fx_context *ctx, const double *r, double *z);   /* z = M^-1 r, 3*NP doubles */
 /* out[0..12]: N NP NPL NPU | M pairs, blocks, slices | ncolor | L pairs, blocks | U pairs, blocks | slices */
 int fx_get_stats(fx_context *ctx, int64_t out[16]);
+/* measured read-streaming rate (GB/s) of this device over the resident matrix values: the on-box
+ * ceiling reported beside the 8 TB/s vendor peak */
+int fx_stream_ceiling(fx_context *ctx, int nrepeat, double *gbs);
 /* diagnostics: rho rho1 beta c1 alpha omega c2 cg0 cg1 dnrm2 bnrm2 resid tol iter status need_verify */
 int fx_debug_state(fx_context *ctx, double out[16]);
 int fx_dot_host(fx_context *ctx, const double *x, const double *y, double *result);
