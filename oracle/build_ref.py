@@ -254,7 +254,7 @@ def build_partitioner(jobs):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--jobs", type=int, default=4)
-    ap.add_argument("--only", choices=["solve", "fem", "shim", "part"], default=None)
+    ap.add_argument("--only", choices=["solve", "fem", "nl", "shim", "part"], default=None)
     a = ap.parse_args()
     if not os.path.isdir(REF):
         print(f"reference not present at {REF}; oracle/_ref left as is")
@@ -271,6 +271,11 @@ def main():
         build_variant("omp", [solve], True, a.jobs, provides, uses)
     if a.only in (None, "fem") and os.path.exists(fem):
         build_variant("fem", [fem], False, a.jobs, provides, uses)
+    # Nonlinear (elastoplastic) element path + load-step loop; OpenMP build so that PRECOND=1 is the
+    # multicolour SSOR the GPU path is compared with (run with OMP_NUM_THREADS>=2).
+    nl = os.path.join(HERE, "ref_nl_driver.f90")
+    if a.only in (None, "nl") and os.path.exists(nl):
+        build_variant("omp", [nl], True, a.jobs, provides, uses, exe_name="ref_nl")
     # The reference partitioner (hecmw1/tools/partitioner, plain C): fixture generator for the
     # HECMW-DIST reader and the multi-rank tests (METHOD=RCB; METIS is absent in this image).
     if a.only in (None, "part"):

@@ -1171,3 +1171,5 @@ void orc_assemble_c3d8(int elemopt, int32_t NP, int32_t n_elem, const double *co
     orc_mat_ass_elem(NP, indexL, itemL, indexU, itemU, D, AL, AU, 8, nod, stiff);
   }
 }
+
+#include "fstr_nl_oracle.c" /* nonlinear C3D8 B-bar path (same translation unit: shares the element helpers) */

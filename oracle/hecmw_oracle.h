@@ -102,6 +102,40 @@ void orc_assemble_c3d8(int elemopt, int32_t NP, int32_t n_elem, const double *co
                        const int32_t *itemL, const int32_t *indexU, const int32_t *itemU, double *D,
                        double *AL, double *AU);
 
+/* ---- Nonlinear (elastoplastic) C3D8 B-bar path: restated in fstr_nl_oracle.c ---- */
+typedef struct {
+  double E, nu;
+  int32_t plastic; /* 0: ELASTIC, 1: Mises elastoplastic */
+  int32_t harden;  /* 0 BILINEAR 1 MULTILINEAR 2 SWIFT 3 RAMBERG-OSGOOD (fifth digit of mtype) */
+  int32_t nlgeom;  /* 0 INFINITE 1 TOTALLAG 2 UPDATELAG */
+  int32_t ntab;
+  double plconst[3]; /* M_PLCONST1..3 */
+  const double *tab; /* ntab rows (yield stress, plastic strain) */
+} orc_material;
+typedef struct { /* tGaussStatus members, flat over (element, quadrature point) */
+  double *stress, *strain, *stress_bak, *strain_bak; /* [n_elem*8*6] */
+  double *plstrain, *fstat;                           /* [n_elem*8]  fstat = fstatus(1) */
+  int32_t *istat;                                     /* [n_elem*8]  istatus(1) */
+} orc_gauss_state;
+void orc_nl_reset_latch(void);
+int orc_nl_latch(void);
+double orc_curr_yield(const orc_material *m, double pstrain);
+double orc_harden_coeff(const orc_material *m, double pstrain);
+void orc_elastoplastic_matrix(const orc_material *m, const double *stress, int istat, double extval1, double *D);
+void orc_backward_euler(const orc_material *m, double *stress, double plstrain, int32_t *istat, double *fstat1);
+void orc_stf_c3d8bbar_nl(const orc_material *m, const double *ecoord, const double *u, const double *stress,
+                         const int32_t *istat, const double *fstat, double *stiff);
+void orc_update_c3d8bbar(const orc_material *m, const double *ecoord, const double *u, const double *du,
+                         double *stress, double *strain, const double *stress_bak, const double *strain_bak,
+                         const double *plstrain, int32_t *istat, double *fstat, double *qf);
+void orc_nl_stiffness(const orc_material *m, int32_t NP, int32_t n_elem, const double *coord, const int32_t *conn,
+                      const double *unode, const double *dunode, const orc_gauss_state *st,
+                      const int32_t *indexL, const int32_t *itemL, const int32_t *indexU, const int32_t *itemU,
+                      double *D, double *AL, double *AU);
+void orc_nl_update(const orc_material *m, int32_t n_node, int32_t n_elem, const double *coord, const int32_t *conn,
+                   const double *unode, const double *dunode, orc_gauss_state *st, double *qforce);
+void orc_nl_commit(const orc_material *m, int32_t n_elem, orc_gauss_state *st);
+
 #ifdef __cplusplus
 }
 #endif

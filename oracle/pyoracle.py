@@ -187,3 +187,174 @@ def assemble(elemopt, coord, conn, E, nu, bc=None, load=None):
             lib().orc_mat_ass_bc(NP, _ip(indexL), _ip(itemL), _ip(indexU), _ip(itemU), _dp(D), _dp(AL),
                                  _dp(AU), _dp(B), int(n_), int(d_), C.c_double(v_))
     return BSR(NP, NP, indexL, itemL, indexU, itemU, D, AL[:9 * itemL.size], AU[:9 * itemU.size], B)
+
+
+# ---------------------------------------------------------------- nonlinear (elastoplastic) path
+class _Material(C.Structure):
+    _fields_ = [("E", C.c_double), ("nu", C.c_double), ("plastic", C.c_int32), ("harden", C.c_int32),
+                ("nlgeom", C.c_int32), ("ntab", C.c_int32), ("plconst", C.c_double * 3), ("tab", C.c_void_p)]
+
+
+class _GaussState(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("stress", "strain", "stress_bak", "strain_bak", "plstrain", "fstat", "istat")]
+
+
+def cmaterial(mat):
+    """mat: refrun.Material-like (E, nu, plastic, harden, plconst, table, nlgeom)."""
+    tab = np.ascontiguousarray(mat.table, dtype=np.float64).reshape(-1, 2)
+    s = _Material(mat.E, mat.nu, int(mat.plastic), mat.harden, mat.nlgeom, tab.shape[0],
+                  (C.c_double * 3)(*mat.plconst), _p(tab) if tab.size else None)
+    s._keep = tab
+    return s
+
+
+def new_state(n_elem):
+    """tGaussStatus after fstr_init_gauss (mechgauss.f90:37-71), flat arrays."""
+    st = {k: np.zeros((n_elem, 8, 6)) for k in ("stress", "strain", "stress_bak", "strain_bak")}
+    st["plstrain"] = np.zeros((n_elem, 8))
+    st["fstat"] = np.zeros((n_elem, 8))
+    st["istat"] = np.zeros((n_elem, 8), dtype=np.int32)
+    return st
+
+
+def cstate(st):
+    s = _GaussState(*[_p(st[k]) for k in ("stress", "strain", "stress_bak", "strain_bak", "plstrain", "fstat", "istat")])
+    s._keep = st
+    return s
+
+
+def nl_reset_latch():
+    lib().orc_nl_reset_latch()
+
+
+def curr_yield(mat, p):
+    lib().orc_curr_yield.restype = C.c_double
+    cm = cmaterial(mat)
+    return lib().orc_curr_yield(C.byref(cm), C.c_double(p))
+
+
+def harden_coeff(mat, p):
+    lib().orc_harden_coeff.restype = C.c_double
+    cm = cmaterial(mat)
+    return lib().orc_harden_coeff(C.byref(cm), C.c_double(p))
+
+
+def elastoplastic_matrix(mat, stress, istat, extval1):
+    cm = cmaterial(mat)
+    D = np.zeros((6, 6))
+    s = np.ascontiguousarray(stress, dtype=np.float64)
+    lib().orc_elastoplastic_matrix(C.byref(cm), _dp(s), int(istat), C.c_double(extval1), _dp(D))
+    return D
+
+
+def backward_euler(mat, stress, plstrain, istat, fstat1):
+    cm = cmaterial(mat)
+    s = np.ascontiguousarray(stress, dtype=np.float64).copy()
+    ist, fs = C.c_int32(int(istat)), C.c_double(float(fstat1))
+    lib().orc_backward_euler(C.byref(cm), _dp(s), C.c_double(plstrain), C.byref(ist), C.byref(fs))
+    return s, ist.value, fs.value
+
+
+def nl_elements(mat, coord, conn, unode, dunode, state):
+    """STF (u+du) -> Update -> STF again, element by element, as oracle/ref_nl_driver.f90 mode 1.
+    The latch is reset first (a fresh process).  Returns ke_before, qf, ke_after, new state."""
+    nl_reset_latch()
+    cm = cmaterial(mat)
+    coord = np.ascontiguousarray(coord, dtype=np.float64)
+    ne = conn.shape[0]
+    st = {k: np.ascontiguousarray(v).copy() for k, v in state.items()}
+    ke0, ke1, qf = np.zeros((ne, 24, 24)), np.zeros((ne, 24, 24)), np.zeros((ne, 24))
+    U = np.asarray(unode).reshape(-1, 3)
+    DU = np.asarray(dunode).reshape(-1, 3)
+
+    def stf(out):
+        for e in range(ne):
+            nd = conn[e] - 1
+            ec = np.ascontiguousarray(coord[nd]); ut = np.ascontiguousarray(U[nd] + DU[nd])
+            lib().orc_stf_c3d8bbar_nl(C.byref(cm), _dp(ec), _dp(ut), _dp(st["stress"][e]), _ip(st["istat"][e]),
+                                      _dp(st["fstat"][e]), _dp(out[e]))
+    stf(ke0)
+    for e in range(ne):
+        nd = conn[e] - 1
+        ec = np.ascontiguousarray(coord[nd]); u = np.ascontiguousarray(U[nd]); du = np.ascontiguousarray(DU[nd])
+        lib().orc_update_c3d8bbar(C.byref(cm), _dp(ec), _dp(u), _dp(du), _dp(st["stress"][e]), _dp(st["strain"][e]),
+                                  _dp(st["stress_bak"][e]), _dp(st["strain_bak"][e]), _dp(st["plstrain"][e]),
+                                  _ip(st["istat"][e]), _dp(st["fstat"][e]), _dp(qf[e]))
+    stf(ke1)
+    return ke0, qf, ke1, st
+
+
+class NonlinearModel:
+    """Mesh-level restatement: fstr_StiffMatrix + fstr_AddBC, fstr_UpdateNewton + fstr_Update_NDForce,
+    fstr_UpdateState, and the fstr_Newton / fstr_solve_NLGEOM control flow around them."""
+
+    def __init__(self, mat, coord, conn):
+        from .refrun import BSR
+        self.mat, self.cm = mat, cmaterial(mat)
+        self.coord = np.ascontiguousarray(coord, dtype=np.float64)
+        self.conn = np.ascontiguousarray(conn, dtype=np.int32)
+        self.NP, self.ne = self.coord.shape[0], self.conn.shape[0]
+        iL, tL, iU, tU = mat_con(self.NP, self.conn)
+        self.m = BSR(self.NP, self.NP, iL, tL, iU, tU, np.zeros(9 * self.NP), np.zeros(9 * max(tL.size, 1)),
+                     np.zeros(9 * max(tU.size, 1)))
+        self.state = new_state(self.ne)
+        self.unode = np.zeros(3 * self.NP)
+        self.dunode = np.zeros(3 * self.NP)
+        self.qforce = np.zeros(3 * self.NP)
+        nl_reset_latch()
+
+    def stiffness(self):
+        m, cs = self.m, cstate(self.state)
+        lib().orc_nl_stiffness(C.byref(self.cm), self.NP, self.ne, _dp(self.coord), _ip(self.conn), _dp(self.unode),
+                               _dp(self.dunode), C.byref(cs), _ip(m.indexL), _ip(m.itemL), _ip(m.indexU),
+                               _ip(m.itemU), _dp(m.D), _dp(m.AL), _dp(m.AU))
+
+    def add_bc(self, node, dof, val):
+        m = self.m
+        for n_, d_, v_ in zip(node, dof, val):
+            lib().orc_mat_ass_bc(self.NP, _ip(m.indexL), _ip(m.itemL), _ip(m.indexU), _ip(m.itemU), _dp(m.D),
+                                 _dp(m.AL), _dp(m.AU), _dp(m.B), int(n_), int(d_), C.c_double(v_))
+
+    def update(self):
+        cs = cstate(self.state)
+        lib().orc_nl_update(C.byref(self.cm), self.NP, self.ne, _dp(self.coord), _ip(self.conn), _dp(self.unode),
+                            _dp(self.dunode), C.byref(cs), _dp(self.qforce))
+
+    def commit(self):
+        cs = cstate(self.state)
+        lib().orc_nl_commit(C.byref(self.cm), self.ne, C.byref(cs))
+
+    def run_steps(self, bc_node, bc_dof, bc_val, cload, nsub, max_iter, converg, I, R, nthreads=2):
+        """fstr_solve_NLGEOM.f90:100-121 + fstr_Newton (fstr_solve_NonLinear.f90:29-167)."""
+        log = []
+        I = np.ascontiguousarray(I, dtype=np.int32).copy()
+        bc_idx = 3 * (np.asarray(bc_node, dtype=np.int64) - 1) + np.asarray(bc_dof, dtype=np.int64) - 1
+        for sub in range(1, nsub + 1):
+            f1, f2 = (sub - 1) / nsub, sub / nsub
+            self.dunode[:] = 0.0
+            GL = cload * f2
+            self.m.B[:] = GL - self.qforce
+            for it in range(1, max_iter + 1):
+                self.stiffness()
+                self.add_bc(bc_node, bc_dof, bc_val * (f2 - f1) if it == 1 else np.zeros(len(bc_val)))
+                I[96] = 2 if it == 1 else 1
+                self.m.X[:] = 0.0
+                r = solve_iterative(self.m, I, R, nthreads=nthreads)
+                I = r["Iarray"]
+                X = r["X"]
+                self.dunode += X
+                self.update()
+                self.m.B[:] = GL - self.qforce
+                self.m.B[bc_idx] = 0.0
+                res = np.sqrt(np.dot(self.m.B, self.m.B))
+                xnrm = np.sqrt(np.dot(X, X))
+                qnrm = np.sqrt(np.dot(self.qforce, self.qforce))
+                if qnrm < 1e-8:
+                    qnrm = 1.0
+                dunrm = xnrm if it == 1 else np.sqrt(np.dot(self.dunode, self.dunode))
+                log.append((sub, it, r["iter"], res, xnrm, qnrm, dunrm))
+                if I[80] == 1 and (res / qnrm < converg or xnrm / dunrm < converg):
+                    break
+            self.unode += self.dunode
+            self.commit()
+        return np.array(log)

@@ -184,3 +184,101 @@ def run_fem(coord, conn, E, nu, bc_node, bc_dof, bc_val, B0, elemopt=1, workdir=
             ke = np.fromfile(f, dtype=np.float64, count=576).reshape(24, 24).T.copy()
             t = float(np.fromfile(f, dtype=np.float64, count=1)[0])
     return BSR(N, NP, indexL, itemL, indexU, itemU, D, AL, AU, B), ke, t
+
+
+MAGIC_NL = 1179209292
+
+
+class Material:
+    """What fstr_ctrl_get_ELASTICITY / fstr_ctrl_get_PLASTICITY leave in tMaterial for an isotropic
+    Mises material (fstr_ctrl_material.f90:60-106, :341-480).  harden: 0 BILINEAR, 1 MULTILINEAR,
+    2 SWIFT, 3 RAMBERG-OSGOOD; table rows = (yield stress, plastic strain); nlgeom: 0 INFINITE,
+    1 TOTALLAG (KIRCHHOFF), 2 UPDATELAG (default of !PLASTIC)."""
+
+    def __init__(self, E, nu, plastic=False, harden=0, plconst=(0.0, 0.0, 0.0), table=None, nlgeom=2):
+        self.E, self.nu, self.plastic, self.harden = float(E), float(nu), bool(plastic), int(harden)
+        self.plconst = tuple(float(v) for v in plconst)
+        self.table = np.zeros((0, 2)) if table is None else np.ascontiguousarray(table, dtype=np.float64).reshape(-1, 2)
+        self.nlgeom = int(nlgeom)
+
+
+def _write_nl_head(f, mode, mat, coord, conn, bc_node, bc_dof, bc_val, cload, nsub, max_iter, converg, I, R):
+    n_node, n_elem = coord.shape[0], conn.shape[0]
+    np.array([MAGIC_NL, mode, n_node, n_elem, len(bc_node), nsub, max_iter, mat.harden, mat.table.shape[0],
+              mat.nlgeom, int(mat.plastic)], dtype=np.int32).tofile(f)
+    np.array([mat.E, mat.nu, *mat.plconst, converg], dtype=np.float64).tofile(f)
+    mat.table.tofile(f)
+    I.astype(np.int32).tofile(f)
+    R.astype(np.float64).tofile(f)
+    np.ascontiguousarray(coord, dtype=np.float64).tofile(f)
+    np.ascontiguousarray(conn, dtype=np.int32).tofile(f)
+    np.ascontiguousarray(bc_node, dtype=np.int32).tofile(f)
+    np.ascontiguousarray(bc_dof, dtype=np.int32).tofile(f)
+    np.ascontiguousarray(bc_val, dtype=np.float64).tofile(f)
+    np.ascontiguousarray(cload, dtype=np.float64).tofile(f)
+
+
+def run_nl_elements(mat, coord, conn, unode, dunode, state, workdir=None):
+    """Reference STF_C3D8Bbar (before the first update), Update_C3D8Bbar, STF_C3D8Bbar again, element
+    by element.  state: dict of stress_bak strain_bak stress strain (ne,8,6), plstrain fstat (ne,8),
+    istat (ne,8) int32.  Returns ke_before, qf, ke_after (row-major (ne,24,24)) and the new state."""
+    exe = os.path.join(REFDIR, "ref_nl")
+    if not os.path.exists(exe):
+        raise FileNotFoundError(exe)
+    ne = conn.shape[0]
+    I, R = default_params()
+    z = np.zeros(0)
+    with tempfile.TemporaryDirectory(dir=workdir) as td:
+        fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        with open(fin, "wb") as f:
+            _write_nl_head(f, 1, mat, coord, conn, z, z, z, np.zeros(coord.size), 1, 1, 1e-6, I, R)
+            np.ascontiguousarray(unode, dtype=np.float64).tofile(f)
+            np.ascontiguousarray(dunode, dtype=np.float64).tofile(f)
+            for k in ("stress_bak", "strain_bak", "stress", "strain", "plstrain", "fstat"):
+                np.ascontiguousarray(state[k], dtype=np.float64).tofile(f)
+            np.ascontiguousarray(state["istat"], dtype=np.int32).tofile(f)
+        p = subprocess.run([exe, fin, fout], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                           env=dict(os.environ, OMP_NUM_THREADS="1"))
+        if p.returncode != 0 or not os.path.exists(fout):
+            raise RuntimeError("ref_nl failed: " + p.stdout)
+        with open(fout, "rb") as f:
+            ke0 = np.fromfile(f, dtype=np.float64, count=576 * ne).reshape(ne, 24, 24).transpose(0, 2, 1).copy()
+            qf = np.fromfile(f, dtype=np.float64, count=24 * ne).reshape(ne, 24)
+            ke1 = np.fromfile(f, dtype=np.float64, count=576 * ne).reshape(ne, 24, 24).transpose(0, 2, 1).copy()
+            out = dict(state)
+            out["stress"] = np.fromfile(f, dtype=np.float64, count=48 * ne).reshape(ne, 8, 6)
+            out["strain"] = np.fromfile(f, dtype=np.float64, count=48 * ne).reshape(ne, 8, 6)
+            out["fstat"] = np.fromfile(f, dtype=np.float64, count=8 * ne).reshape(ne, 8)
+            out["istat"] = np.fromfile(f, dtype=np.int32, count=8 * ne).reshape(ne, 8)
+    return ke0, qf, ke1, out
+
+
+def run_nl_steps(mat, coord, conn, bc_node, bc_dof, bc_val, cload, nsub, max_iter, converg, I, R,
+                 threads=2, workdir=None, timeout=None):
+    """Reference load-step loop (see oracle/ref_nl_driver.f90).  Returns dict(log, unode, qforce, state)."""
+    exe = os.path.join(REFDIR, "ref_nl")
+    if not os.path.exists(exe):
+        raise FileNotFoundError(exe)
+    ne, nn = conn.shape[0], coord.shape[0]
+    with tempfile.TemporaryDirectory(dir=workdir) as td:
+        fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        with open(fin, "wb") as f:
+            _write_nl_head(f, 2, mat, coord, conn, bc_node, bc_dof, bc_val, cload, nsub, max_iter, converg, I, R)
+        p = subprocess.run([exe, fin, fout], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                           env=dict(os.environ, OMP_NUM_THREADS=str(threads)), timeout=timeout)
+        if p.returncode != 0 or not os.path.exists(fout):
+            raise RuntimeError("ref_nl failed: " + p.stdout[-2000:])
+        with open(fout, "rb") as f:
+            nlog = int(np.fromfile(f, dtype=np.int32, count=1)[0])
+            log = np.fromfile(f, dtype=np.float64, count=7 * nlog).reshape(nlog, 7)
+            out = {"log": log, "stdout": p.stdout}
+            out["unode"] = np.fromfile(f, dtype=np.float64, count=3 * nn)
+            out["qforce"] = np.fromfile(f, dtype=np.float64, count=3 * nn)
+            st = {}
+            st["stress"] = np.fromfile(f, dtype=np.float64, count=48 * ne).reshape(ne, 8, 6)
+            st["strain"] = np.fromfile(f, dtype=np.float64, count=48 * ne).reshape(ne, 8, 6)
+            st["plstrain"] = np.fromfile(f, dtype=np.float64, count=8 * ne).reshape(ne, 8)
+            st["fstat"] = np.fromfile(f, dtype=np.float64, count=8 * ne).reshape(ne, 8)
+            st["istat"] = np.fromfile(f, dtype=np.int32, count=8 * ne).reshape(ne, 8)
+            out["state"] = st
+    return out

@@ -1,0 +1,117 @@
+"""Oracle (CPU restatement, oracle/fstr_nl_oracle.c) of the nonlinear C3D8 B-bar path against the
+reference routines themselves (oracle/_ref/ref_nl, built from /root/reference by oracle/build_ref.py)
+where that binary exists, and against the committed fixtures it produced (tests/golden/nl_*.npz)
+everywhere.  SURVEY §8(f)-2."""
+import os
+
+import numpy as np
+import pytest
+
+from frontistr_amd.mesh import CubeMesh
+from oracle import pyoracle, refrun
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TABLE = [[450, 0], [608, 0.05], [679, 0.1], [732, 0.2], [752, 0.3], [766, 0.4], [780, 0.5]]   # tutorial/05_plastic_cylinder
+
+
+def materials():
+    return {
+        "elastic_ul": refrun.Material(206900.0, 0.29, plastic=False, nlgeom=2),
+        "elastic_tl": refrun.Material(206900.0, 0.29, plastic=False, nlgeom=1),
+        "mises_multilinear_ul": refrun.Material(206900.0, 0.29, plastic=True, harden=1, table=TABLE, nlgeom=2),
+        "mises_bilinear_ul": refrun.Material(1.0e5, 0.3, plastic=True, harden=0, plconst=(1000.0, 2.0e3, 0.0), nlgeom=2),
+        "mises_swift_tl": refrun.Material(1.0e5, 0.3, plastic=True, harden=2, plconst=(0.01, 2000.0, 0.2), nlgeom=1),
+        "mises_ramberg_inf": refrun.Material(1.0e5, 0.3, plastic=True, harden=3, plconst=(0.005, 800.0, 5.0), nlgeom=0),
+    }
+
+
+def element_case(name, seed=0):
+    """A 2x2x2 skewed block with random displacement, increment and history (some points plastic)."""
+    mat = materials()[name]
+    m = CubeMesh(2, skew=0.12)
+    rng = np.random.default_rng(seed)
+    unode = 0.02 * rng.standard_normal(m.ndof)
+    dunode = 0.01 * rng.standard_normal(m.ndof)
+    st = pyoracle.new_state(m.n_elem)
+    scale = 300.0 if mat.plastic else 100.0
+    st["stress_bak"] = scale * rng.standard_normal((m.n_elem, 8, 6))
+    st["strain_bak"] = 1e-3 * rng.standard_normal((m.n_elem, 8, 6))
+    st["stress"] = st["stress_bak"] + 10 * rng.standard_normal((m.n_elem, 8, 6))
+    st["strain"] = st["strain_bak"].copy()
+    if mat.plastic:
+        st["plstrain"] = np.abs(0.02 * rng.standard_normal((m.n_elem, 8)))
+        st["fstat"] = st["plstrain"] + np.abs(0.005 * rng.standard_normal((m.n_elem, 8)))
+        st["istat"] = (rng.random((m.n_elem, 8)) < 0.5).astype(np.int32)
+    return mat, m, unode, dunode, st
+
+
+def check_elements(got, want):
+    ke0, qf, ke1, st = got
+    rke0, rqf, rke1, rst = want
+    for a, b, tag in ((ke0, rke0, "ke before"), (qf, rqf, "qf"), (ke1, rke1, "ke after"),
+                      (st["stress"], rst["stress"], "stress"), (st["strain"], rst["strain"], "strain"),
+                      (st["fstat"], rst["fstat"], "fstat")):
+        np.testing.assert_allclose(a, b, rtol=1e-11, atol=1e-11 * np.abs(b).max(), err_msg=tag)
+    assert np.array_equal(st["istat"], rst["istat"])
+
+
+@pytest.mark.parametrize("name", list(materials()))
+def test_elements_vs_golden(name):
+    mat, m, unode, dunode, st = element_case(name)
+    g = np.load(os.path.join(GOLD, "nl_elements_%s.npz" % name))
+    want = (g["ke0"], g["qf"], g["ke1"], {k: g[k] for k in ("stress", "strain", "fstat", "istat")})
+    check_elements(pyoracle.nl_elements(mat, m.coord, m.conn, unode, dunode, st), want)
+    # the reference's latched MatlMatrix flag: after the first update the tangent of a plastic point is elastic
+    if mat.plastic and st["istat"].any():
+        assert np.abs(g["ke0"] - g["ke1"]).max() > 1e-3 * np.abs(g["ke0"]).max()
+
+
+@pytest.mark.skipif(not refrun.have_ref("ref_nl"), reason="oracle/_ref/ref_nl not built (no /root/reference)")
+@pytest.mark.parametrize("name", list(materials()))
+def test_elements_vs_reference(name):
+    mat, m, unode, dunode, st = element_case(name, seed=3)
+    want = refrun.run_nl_elements(mat, m.coord, m.conn, unode, dunode, st)
+    check_elements(pyoracle.nl_elements(mat, m.coord, m.conn, unode, dunode, st), want)
+
+
+def step_case(name):
+    mat = materials()[name]
+    m = CubeMesh(3, skew=0.1)
+    bn, bd, bv = m.dirichlet()
+    tn = np.repeat(m.top_nodes, 3).astype(np.int32)
+    td = np.tile(np.array([1, 2, 3], dtype=np.int32), m.top_nodes.size)
+    tv = np.tile(np.array([0.06, 0.0, 0.12]), m.top_nodes.size)
+    bc = (np.concatenate([bn, tn]), np.concatenate([bd, td]), np.concatenate([bv, tv]))
+    cload = np.zeros(m.ndof)
+    cload[3 * (m.conn[13, 6] - 1) + 1] = 50.0          # a nodal load on an interior node as well
+    I, R = refrun.default_params(method=1, precond=3, tol=1e-10, iterlog=0, timelog=0)
+    return mat, m, bc, cload, I, R
+
+
+STEP_CASES = ["mises_multilinear_ul", "mises_bilinear_ul", "elastic_tl"]
+# Newton tolerance per case: the reference's latched elastic tangent converges linearly, so the
+# plastic decks either stop on a loose CONVERG (multilinear) or run into max_iter (bilinear).
+STEP_CONVERG = {"mises_multilinear_ul": 5e-2, "mises_bilinear_ul": 1e-6, "elastic_tl": 1e-6}
+
+
+def check_steps(model, log, want):
+    wl = want["log"]
+    assert log.shape[0] == wl.shape[0]
+    assert np.array_equal(log[:, :2], wl[:, :2])                      # same Newton iteration counts per substep
+    np.testing.assert_allclose(log[:, 3:], wl[:, 3:], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(model.unode, want["unode"], rtol=0, atol=1e-9 * np.abs(want["unode"]).max())
+    s = want["stress"]
+    np.testing.assert_allclose(model.state["stress"], s, rtol=0, atol=1e-8 * np.abs(s).max())
+    np.testing.assert_allclose(model.state["plstrain"], want["plstrain"], rtol=0, atol=1e-10)
+    assert np.array_equal(model.state["istat"], want["istat"])
+
+
+@pytest.mark.parametrize("name", STEP_CASES)
+def test_load_steps_vs_golden(name):
+    mat, m, bc, cload, I, R = step_case(name)
+    g = np.load(os.path.join(GOLD, "nl_steps_%s.npz" % name))
+    model = pyoracle.NonlinearModel(mat, m.coord, m.conn)
+    log = model.run_steps(*bc, cload, 3, 12, STEP_CONVERG[name], I, R, nthreads=2)
+    check_steps(model, log, g)
+    if mat.plastic:
+        assert g["plstrain"].max() > 1e-3
