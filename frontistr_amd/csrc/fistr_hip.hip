@@ -13,6 +13,7 @@
 
 #include "fx_assemble.h"
 #include "fx_kernels.h"
+#include "fx_nonlinear.h"
 
 namespace fxo {
 struct Graph {
@@ -171,6 +172,7 @@ static void bell_free(Bell &b) {
   b = Bell();
 }
 
+static void nl_free(fx_context *c);  // fx_nonlinear_host.h
 static void free_matrix(fx_context *c) {
   DevCSR &A = c->A;
   dev_free(A.indexL); dev_free(A.itemL); dev_free(A.indexU); dev_free(A.itemU);
@@ -202,6 +204,7 @@ extern "C" void fx_destroy(fx_context *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  nl_free(c);
   free_precond(c);
   free_matrix(c);
   dev_free(c->halo.export_item); dev_free(c->halo.import_item);
@@ -1466,3 +1469,4 @@ extern "C" int fx_get_stats(fx_context *c, int64_t out[16]) {
 }
 
 #include "fx_assemble_host.h"
+#include "fx_nonlinear_host.h"

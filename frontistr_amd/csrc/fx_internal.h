@@ -118,6 +118,35 @@ struct HaloDev {
   int32_t n_export = 0, n_import = 0;
 };
 
+// Material of the nonlinear path as the kernels take it (one isotropic Mises material per context).
+struct NlMat {
+  double E, nu, pl[3];
+  int32_t plastic, harden, nlgeom, ntab;
+  const double *tab;  // device, ntab rows (yield stress, plastic strain)
+};
+
+// fstr_solid members of the nonlinear static loop (m_fstr.f90:560-700) for one TYPE=361 B-bar group, resident.
+struct NlDev {
+  bool ready = false;
+  int32_t n_elem = 0, n_bc = 0;
+  NlMat mat = {};
+  double *tab = nullptr;
+  double *coord = nullptr;
+  int32_t *conn = nullptr;
+  // tGaussStatus (mechgauss.f90:13-22), flat over (element, quadrature point)
+  double *stress = nullptr, *strain = nullptr, *stress_bak = nullptr, *strain_bak = nullptr;  // 6 per point
+  double *plstrain = nullptr, *fstat = nullptr;                                               // 1 per point
+  int32_t *istat = nullptr;
+  double *unode = nullptr, *dunode = nullptr, *qforce = nullptr, *GL = nullptr;  // 3*NP
+  uint8_t *bc_flag = nullptr;   // prescribed dofs of the current step (3*NP)
+  double *bc_val = nullptr;     // their values (3*NP)
+  int32_t *bc_node = nullptr, *bc_dof = nullptr;
+  double *bc_v = nullptr;
+  int32_t bc_cap = 0;
+  int32_t *err = nullptr;
+  int latch = 0;  // MatlMatrix's saved `flag` (calMatMatrix.f90:39): set by the first elastoplastic stress update
+};
+
 struct fx_context {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -171,6 +200,7 @@ struct fx_context {
   void *cb_user = nullptr;
   double *h_send = nullptr, *h_recv = nullptr;  // pinned staging
   HaloDev halo;
+  NlDev nl;
   // timing
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };

@@ -1,0 +1,317 @@
+// Host entry points of the nonlinear path (included at the end of fistr_hip.hip): the steps of
+// fstr_Newton (fstr_solve_NonLinear.f90:29-167) either side of the linear solve, on resident state.
+#pragma once
+
+static void nl_free(fx_context *c) {
+  NlDev &n = c->nl;
+  dev_free(n.tab); dev_free(n.coord); dev_free(n.conn);
+  dev_free(n.stress); dev_free(n.strain); dev_free(n.stress_bak); dev_free(n.strain_bak);
+  dev_free(n.plstrain); dev_free(n.fstat); dev_free(n.istat);
+  dev_free(n.unode); dev_free(n.dunode); dev_free(n.qforce); dev_free(n.GL);
+  dev_free(n.bc_flag); dev_free(n.bc_val); dev_free(n.bc_node); dev_free(n.bc_dof); dev_free(n.bc_v); dev_free(n.err);
+  n = NlDev();
+}
+
+// fstr_solid / tGaussStatus set-up for one TYPE=361 B-bar group with one material (fstr_setup.f90:325-400,
+// fstr_init_gauss mechgauss.f90:37-71): zero state, zero displacement.
+extern "C" int fx_nl_init(fx_context *c, const fx_mesh_view *mesh, const fx_material_view *mat) {
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->have_profile) { g_fx_error = "fx_nl_init: upload the profile first (fx_upload FX_UP_PROFILE)"; return FX_ERROR_RUNTIME; }
+  if (mesh->n_node != c->A.NP) { g_fx_error = "fx_nl_init: mesh/profile size mismatch"; return FX_ERROR_RUNTIME; }
+  if (mat->harden < 0 || mat->harden > 3 || mat->nlgeom < 0 || mat->nlgeom > 2) {
+    g_fx_error = "fx_nl_init: only Mises yield with BILINEAR/MULTILINEAR/SWIFT/RAMBERG-OSGOOD hardening is on the hot path";
+    return FX_ERROR_UNSUPPORTED;
+  }
+  if (mat->plastic && mat->harden == 1 && (mat->ntab < 1 || !mat->tab)) { g_fx_error = "fx_nl_init: MULTILINEAR hardening needs a table"; return FX_ERROR_RUNTIME; }
+  for (int64_t k = 0; k < (int64_t)8 * mesh->n_elem; k++)
+    if (mesh->conn[k] < 1 || mesh->conn[k] > mesh->n_node) { g_fx_error = "fx_nl_init: node id out of range"; return FX_ERROR_RUNTIME; }
+  nl_free(c);
+  NlDev &n = c->nl;
+  n.n_elem = mesh->n_elem;
+  const size_t np3 = (size_t)3 * c->A.NP, npt = (size_t)8 * mesh->n_elem;
+  if (dev_alloc(&n.coord, np3) || dev_alloc(&n.conn, npt) || dev_alloc(&n.stress, 6 * npt) || dev_alloc(&n.strain, 6 * npt) ||
+      dev_alloc(&n.stress_bak, 6 * npt) || dev_alloc(&n.strain_bak, 6 * npt) || dev_alloc(&n.plstrain, npt) ||
+      dev_alloc(&n.fstat, npt) || dev_alloc(&n.istat, npt) || dev_alloc(&n.unode, np3) || dev_alloc(&n.dunode, np3) ||
+      dev_alloc(&n.qforce, np3) || dev_alloc(&n.GL, np3) || dev_alloc(&n.bc_flag, np3) || dev_alloc(&n.bc_val, np3) ||
+      dev_alloc(&n.err, 1) || dev_alloc(&n.tab, (size_t)2 * std::max(mat->ntab, 1)))
+    return FX_ERROR_RUNTIME;
+  HIP_TRY(hipMemcpyAsync(n.coord, mesh->coord, np3 * 8, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(n.conn, mesh->conn, npt * 4, hipMemcpyHostToDevice, c->stream));
+  if (mat->ntab > 0) HIP_TRY(hipMemcpyAsync(n.tab, mat->tab, (size_t)2 * mat->ntab * 8, hipMemcpyHostToDevice, c->stream));
+  for (double *p : {n.stress, n.strain, n.stress_bak, n.strain_bak}) HIP_TRY(hipMemsetAsync(p, 0, 6 * npt * 8, c->stream));
+  for (double *p : {n.plstrain, n.fstat}) HIP_TRY(hipMemsetAsync(p, 0, npt * 8, c->stream));
+  HIP_TRY(hipMemsetAsync(n.istat, 0, npt * 4, c->stream));
+  for (double *p : {n.unode, n.dunode, n.qforce, n.GL, n.bc_val}) HIP_TRY(hipMemsetAsync(p, 0, np3 * 8, c->stream));
+  HIP_TRY(hipMemsetAsync(n.bc_flag, 0, np3, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  n.mat.E = mat->E; n.mat.nu = mat->nu;
+  for (int i = 0; i < 3; i++) n.mat.pl[i] = mat->plconst[i];
+  n.mat.plastic = mat->plastic ? 1 : 0; n.mat.harden = mat->harden; n.mat.nlgeom = mat->nlgeom; n.mat.ntab = mat->ntab;
+  n.mat.tab = n.tab;
+  n.latch = 0;
+  n.ready = true;
+  return 0;
+}
+
+#define NL_READY(name)                                                                              \
+  HIP_TRY(hipSetDevice(c->device));                                                                 \
+  if (!c->nl.ready) { g_fx_error = name ": call fx_nl_init first"; return FX_ERROR_RUNTIME; }
+
+template <int G>
+static void nl_launch_stiffness(fx_context *c, double *Kout) {
+  NlDev &n = c->nl;
+  const DevCSR &A = c->A;
+  hipLaunchKernelGGL((k_nl_stiffness<G>), dim3((n.n_elem + FXN_EPB - 1) / FXN_EPB), dim3(FXN_BLOCK), 0, c->stream, n.n_elem, n.coord,
+                     n.conn, n.unode, n.dunode, n.mat, n.latch, n.stress, n.fstat, n.istat, A.indexL, A.itemL, A.indexU, A.itemU, A.D,
+                     A.AL, A.AU, Kout, n.err);
+}
+template <int G>
+static void nl_launch_update(fx_context *c, double *qf_out) {
+  NlDev &n = c->nl;
+  hipLaunchKernelGGL((k_nl_update<G>), dim3((n.n_elem + FXN_EPB - 1) / FXN_EPB), dim3(FXN_BLOCK), 0, c->stream, n.n_elem, n.coord,
+                     n.conn, n.unode, n.dunode, n.mat, n.stress, n.strain, n.stress_bak, n.strain_bak, n.plstrain, n.fstat, n.istat,
+                     n.qforce, qf_out);
+}
+
+// fstr_StiffMatrix + fstr_AddBC (fstr_StiffMatrix.f90:18-212, fstr_AddBC.f90:17-190): tangent of the current
+// state (u = unode + dunode) into the resident D/AL/AU, then Dirichlet elimination with the given increments
+// against the resident right-hand side.  The prescribed dofs are remembered for fx_nl_update.
+extern "C" int fx_nl_stiffness(fx_context *c, int32_t n_bc, const int32_t *bc_node, const int32_t *bc_dof, const double *bc_val,
+                               float *ms_assemble) {
+  NL_READY("fx_nl_stiffness");
+  NlDev &n = c->nl;
+  DevCSR &A = c->A;
+  for (int32_t k = 0; k < n_bc; k++)
+    if (bc_node[k] < 1 || bc_node[k] > A.NP) { g_fx_error = "fx_nl_stiffness: BC node id out of range"; return FX_ERROR_RUNTIME; }
+  HIP_TRY(hipMemsetAsync(n.err, 0, 4, c->stream));
+  HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  HIP_TRY(hipMemsetAsync(A.D, 0, (size_t)9 * A.NP * 8, c->stream));  // hecmw_mat_clear
+  HIP_TRY(hipMemsetAsync(A.AL, 0, (size_t)9 * A.NPL * 8, c->stream));
+  HIP_TRY(hipMemsetAsync(A.AU, 0, (size_t)9 * A.NPU * 8, c->stream));
+  if (n.mat.nlgeom == 0) nl_launch_stiffness<0>(c, nullptr);
+  else if (n.mat.nlgeom == 1) nl_launch_stiffness<1>(c, nullptr);
+  else nl_launch_stiffness<2>(c, nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemsetAsync(n.bc_flag, 0, (size_t)3 * A.NP, c->stream));
+  HIP_TRY(hipMemsetAsync(n.bc_val, 0, (size_t)3 * A.NP * 8, c->stream));
+  n.n_bc = n_bc;
+  if (n_bc > 0) {
+    if (n_bc > n.bc_cap) {
+      dev_free(n.bc_node); dev_free(n.bc_dof); dev_free(n.bc_v);
+      if (dev_alloc(&n.bc_node, (size_t)n_bc) || dev_alloc(&n.bc_dof, (size_t)n_bc) || dev_alloc(&n.bc_v, (size_t)n_bc)) return FX_ERROR_RUNTIME;
+      n.bc_cap = n_bc;
+    }
+    HIP_TRY(hipMemcpyAsync(n.bc_node, bc_node, (size_t)n_bc * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(n.bc_dof, bc_dof, (size_t)n_bc * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(n.bc_v, bc_val, (size_t)n_bc * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_bc_mark, dim3((n_bc + 255) / 256), dim3(256), 0, c->stream, n_bc, n.bc_node, n.bc_dof, n.bc_v, n.bc_flag, n.bc_val);
+    const dim3 g((A.NP + 255) / 256);
+    hipLaunchKernelGGL((k_bc_apply<1>), g, dim3(256), 0, c->stream, A.NP, A.indexL, A.itemL, A.indexU, A.itemU, A.D, A.AL, A.AU, A.B,
+                       n.bc_flag, n.bc_val);
+    hipLaunchKernelGGL((k_bc_apply<2>), g, dim3(256), 0, c->stream, A.NP, A.indexL, A.itemL, A.indexU, A.itemU, A.D, A.AL, A.AU, A.B,
+                       n.bc_flag, n.bc_val);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipEventRecord(c->ev1, c->stream));
+  int32_t herr = 0;
+  HIP_TRY(hipMemcpyAsync(&herr, n.err, 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (ms_assemble) HIP_TRY(hipEventElapsedTime(ms_assemble, c->ev0, c->ev1));
+  if (herr == 2) { g_fx_error = "###ERROR### : cannot find connectivity (element not covered by the profile)"; return FX_ERROR_RUNTIME; }
+  c->have_values = true;
+  c->bell_valid = false;
+  c->precond_valid = false;
+  return 0;
+}
+
+static int nl_dot(fx_context *c, const double *x, const double *y, double *out) {  // hecmw_InnerProduct_R over the internal dofs
+  if (c->max_partials < 4096 + 8) {
+    dev_free(c->partials);
+    if (dev_alloc(&c->partials, (size_t)(4096 + 8) * 3)) return FX_ERROR_RUNTIME;
+    c->max_partials = 4096 + 8;
+  }
+  const int64_t len = (int64_t)3 * c->A.N;
+  const int np = grid_for(len, FX_BLOCK, 2048);
+  hipLaunchKernelGGL(k_dot, dim3(np), dim3(FX_BLOCK), 0, c->stream, len, x, y, c->partials, (const int32_t *)nullptr, 0);
+  HIP_TRY(hipGetLastError());
+  double tmp;
+  return host_sum(c, np, 0, out, &tmp);
+}
+
+static int nl_halo_natural(fx_context *c, double *v) {  // hecmw_update_3_R on a vector in the reference numbering
+  if (!multi_rank(c)) return 0;
+  if (ensure_solver(c)) return FX_ERROR_RUNTIME;
+  if (to_slots(c, v, c->W[6]) || halo_update(c, c->W[6]) || from_slots(c, c->W[6], v)) return FX_ERROR_RUNTIME;
+  return 0;
+}
+
+// Start of a substep (fstr_Newton :63-68, fstr_ass_load.f90:64-91,:273): dunode = 0, GL = load at the end of the
+// increment (host, 3*NP, may be NULL = no nodal load), B = GL - QFORCE.
+extern "C" int fx_nl_begin_substep(fx_context *c, const double *GL) {
+  NL_READY("fx_nl_begin_substep");
+  NlDev &n = c->nl;
+  const size_t np3 = (size_t)3 * c->A.NP;
+  HIP_TRY(hipMemsetAsync(n.dunode, 0, np3 * 8, c->stream));
+  if (GL) HIP_TRY(hipMemcpyAsync(n.GL, GL, np3 * 8, hipMemcpyHostToDevice, c->stream));
+  else HIP_TRY(hipMemsetAsync(n.GL, 0, np3 * 8, c->stream));
+  hipLaunchKernelGGL(k_nl_residual, dim3(grid_for((int64_t)np3)), dim3(256), 0, c->stream, (int64_t)np3, n.GL, n.qforce,
+                     (const uint8_t *)nullptr, c->A.B);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// After the solve (fstr_Newton :92-122): dunode += X, fstr_UpdateNewton, fstr_Update_NDForce, and the four
+// norms of the convergence test: out = {|B|^2, |X|^2, |QFORCE|^2, |dunode|^2} over the internal dofs.
+extern "C" int fx_nl_update(fx_context *c, double out[4], float *ms_update) {
+  NL_READY("fx_nl_update");
+  NlDev &n = c->nl;
+  const int64_t np3 = (int64_t)3 * c->A.NP;
+  hipLaunchKernelGGL(k_axpy_plain, dim3(grid_for(np3)), dim3(256), 0, c->stream, np3, 1.0, c->A.X, n.dunode);
+  HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  HIP_TRY(hipMemsetAsync(n.qforce, 0, (size_t)np3 * 8, c->stream));
+  if (n.mat.nlgeom == 0) nl_launch_update<0>(c, nullptr);
+  else if (n.mat.nlgeom == 1) nl_launch_update<1>(c, nullptr);
+  else nl_launch_update<2>(c, nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(c->ev1, c->stream));
+  if (n.mat.plastic) n.latch = 1;  // MatlMatrix(..., isEp=1) has now been called (calMatMatrix.f90:43-45)
+  if (nl_halo_natural(c, n.qforce)) return FX_ERROR_RUNTIME;
+  hipLaunchKernelGGL(k_nl_residual, dim3(grid_for(np3)), dim3(256), 0, c->stream, np3, n.GL, n.qforce, n.bc_flag, c->A.B);
+  HIP_TRY(hipGetLastError());
+  if (nl_halo_natural(c, c->A.B)) return FX_ERROR_RUNTIME;
+  if (out) {
+    if (nl_dot(c, c->A.B, c->A.B, out + 0) || nl_dot(c, c->A.X, c->A.X, out + 1) || nl_dot(c, n.qforce, n.qforce, out + 2) ||
+        nl_dot(c, n.dunode, n.dunode, out + 3))
+      return FX_ERROR_RUNTIME;
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (ms_update) HIP_TRY(hipEventElapsedTime(ms_update, c->ev0, c->ev1));
+  return 0;
+}
+
+// End of a converged substep (fstr_Newton :156-162): unode += dunode, fstr_UpdateState.
+extern "C" int fx_nl_commit(fx_context *c) {
+  NL_READY("fx_nl_commit");
+  NlDev &n = c->nl;
+  const int64_t np3 = (int64_t)3 * c->A.NP, npt = (int64_t)8 * n.n_elem;
+  hipLaunchKernelGGL(k_axpy_plain, dim3(grid_for(np3)), dim3(256), 0, c->stream, np3, 1.0, n.dunode, n.unode);
+  hipLaunchKernelGGL(k_nl_commit, dim3(grid_for(6 * npt)), dim3(256), 0, c->stream, npt, n.mat.plastic, n.fstat, n.plstrain, n.stress,
+                     n.strain, n.stress_bak, n.strain_bak);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+static int nl_copy_state(fx_context *c, const fx_nl_state_view *s, bool to_device) {
+  NlDev &n = c->nl;
+  const size_t np3 = (size_t)3 * c->A.NP * 8, npt = (size_t)8 * n.n_elem;
+  struct { void *h; void *d; size_t bytes; } f[] = {
+      {s->stress, n.stress, 6 * npt * 8}, {s->strain, n.strain, 6 * npt * 8}, {s->stress_bak, n.stress_bak, 6 * npt * 8},
+      {s->strain_bak, n.strain_bak, 6 * npt * 8}, {s->plstrain, n.plstrain, npt * 8}, {s->fstat, n.fstat, npt * 8},
+      {s->istat, n.istat, npt * 4}, {s->unode, n.unode, np3}, {s->dunode, n.dunode, np3}, {s->qforce, n.qforce, np3}};
+  for (auto &e : f) {
+    if (!e.h) continue;
+    if (to_device) HIP_TRY(hipMemcpyAsync(e.d, e.h, e.bytes, hipMemcpyHostToDevice, c->stream));
+    else HIP_TRY(hipMemcpyAsync(e.h, e.d, e.bytes, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+extern "C" int fx_nl_get_state(fx_context *c, fx_nl_state_view *s) {
+  NL_READY("fx_nl_get_state");
+  s->latch = c->nl.latch;
+  return nl_copy_state(c, s, false);
+}
+extern "C" int fx_nl_set_state(fx_context *c, const fx_nl_state_view *s) {
+  NL_READY("fx_nl_set_state");
+  if (s->latch >= 0) c->nl.latch = s->latch ? 1 : 0;
+  return nl_copy_state(c, s, true);
+}
+
+// Element-level outputs of the two kernels (tests): tangents ke (n_elem x 24 x 24 row-major) of the current state
+// with u = unode + dunode, or the stress update with per-element internal forces qf (n_elem x 24), no scatter.
+extern "C" int fx_nl_element_tangents(fx_context *c, double *ke) {
+  NL_READY("fx_nl_element_tangents");
+  NlDev &n = c->nl;
+  double *d = nullptr;
+  if (dev_alloc(&d, (size_t)576 * n.n_elem)) return FX_ERROR_RUNTIME;
+  if (n.mat.nlgeom == 0) nl_launch_stiffness<0>(c, d);
+  else if (n.mat.nlgeom == 1) nl_launch_stiffness<1>(c, d);
+  else nl_launch_stiffness<2>(c, d);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(ke, d, (size_t)576 * n.n_elem * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  dev_free(d);
+  return 0;
+}
+extern "C" int fx_nl_element_update(fx_context *c, double *qf) {
+  NL_READY("fx_nl_element_update");
+  NlDev &n = c->nl;
+  double *d = nullptr;
+  if (dev_alloc(&d, (size_t)24 * n.n_elem)) return FX_ERROR_RUNTIME;
+  if (n.mat.nlgeom == 0) nl_launch_update<0>(c, d);
+  else if (n.mat.nlgeom == 1) nl_launch_update<1>(c, d);
+  else nl_launch_update<2>(c, d);
+  HIP_TRY(hipGetLastError());
+  if (n.mat.plastic) n.latch = 1;
+  HIP_TRY(hipMemcpyAsync(qf, d, (size_t)24 * n.n_elem * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  dev_free(d);
+  return 0;
+}
+
+// One substep of fstr_Newton (fstr_solve_NonLinear.f90:29-167) around fx_solve_resident.
+//   factor0/factor1: load factors at the start / end of the increment (fstr_solve_NLGEOM.f90:112-115);
+//   bc_val, cload: values at load factor 1.  log: 7 doubles per Newton iteration
+//   (iter, linear-solver iterations, solver return code, |B|, |X|, |QFORCE|, |dunode|).
+// Returns 0 when the substep converged, FX_ERROR_NOCONV_MAXIT when max_iter ran out (the reference cuts back;
+// the state is committed as fstr_Newton's caller would after its last iteration only on convergence).
+extern "C" int fx_newton_substep(fx_context *c, double factor0, double factor1, int32_t n_bc, const int32_t *bc_node,
+                                 const int32_t *bc_dof, const double *bc_val, const double *cload, int32_t max_iter, double converg,
+                                 int32_t *Iarray, double *Rarray, double *log, int32_t *n_iter, int commit_unconverged) {
+  NL_READY("fx_newton_substep");
+  const size_t np3 = (size_t)3 * c->A.NP;
+  std::vector<double> gl, inc((size_t)std::max(n_bc, 1)), zero((size_t)std::max(n_bc, 1), 0.0);
+  if (cload) {
+    gl.resize(np3);
+    for (size_t i = 0; i < np3; i++) gl[i] = cload[i] * factor1;
+  }
+  for (int32_t k = 0; k < n_bc; k++) inc[k] = bc_val[k] * (factor1 - factor0);
+  int e = fx_nl_begin_substep(c, cload ? gl.data() : nullptr);
+  if (e) return e;
+  bool done = false;
+  int32_t it = 0;
+  for (it = 1; it <= max_iter; it++) {
+    e = fx_nl_stiffness(c, n_bc, bc_node, bc_dof, it == 1 ? inc.data() : zero.data(), nullptr);
+    if (e) return e;
+    Iarray[96] = (it == 1) ? 2 : 1;  // Iarray(97): force / need numerical factorisation (:82-86)
+    HIP_TRY(hipMemsetAsync(c->A.X, 0, np3 * 8, c->stream));
+    fx_solve_info info;
+    memset(&info, 0, sizeof info);
+    const int code = fx_solve_resident(c, Iarray, Rarray, &info, nullptr, 0);
+    if (code < 0 || code == FX_ERROR_ZERO_DIAG || code == FX_ERROR_INCONS_PC) return code;
+    double nrm[4];
+    e = fx_nl_update(c, nrm, nullptr);
+    if (e) return e;
+    const double res = sqrt(nrm[0]), xnrm = sqrt(nrm[1]);
+    double qnrm = sqrt(nrm[2]);
+    if (qnrm < 1.0e-8) qnrm = 1.0;
+    const double dunrm = (it == 1) ? xnrm : sqrt(nrm[3]);
+    if (log) {
+      double *l = log + (size_t)7 * (it - 1);
+      l[0] = it; l[1] = info.iterations; l[2] = code; l[3] = res; l[4] = xnrm; l[5] = qnrm; l[6] = dunrm;
+    }
+    if (Iarray[80] == 1) {  // hecmw_mat_get_flag_converged (:132-135)
+      if (res / qnrm < converg) done = true;
+      if (xnrm / dunrm < converg) done = true;
+    }
+    if (done) break;
+  }
+  if (n_iter) *n_iter = std::min(it, max_iter);
+  if (done || commit_unconverged) {
+    e = fx_nl_commit(c);
+    if (e) return e;
+  }
+  return done ? 0 : FX_ERROR_NOCONV_MAXIT;
+}

@@ -157,6 +157,54 @@ int fx_assemble_c3d8(fx_context *ctx, const fx_mesh_view *mesh, double E, double
 int fx_element_stiffness_c3d8(fx_context *ctx, int elemopt, const double *ecoord, double E, double nu,
                               double *stiff);
 
+/* ---- nonlinear static loop: the steps of fstr_Newton either side of the solve -------------
+ * (fistr1/src/analysis/static/fstr_solve_NonLinear.f90:29-167).  One TYPE=361 group with the
+ * B-bar formulation (the reference's default for NLSTATIC, fstr_setup.f90:366-368) and one
+ * isotropic material: ELASTIC or Mises elastoplastic (!PLASTIC, YIELD=MISES) with BILINEAR /
+ * MULTILINEAR / SWIFT / RAMBERG-OSGOOD isotropic hardening, INFINITE / TOTALLAG (KIRCHHOFF) /
+ * UPDATELAG kinematics.  Everything stays resident: gauss-point history, unode/dunode, QFORCE. */
+typedef struct fx_material_view { /* tMaterial after fstr_ctrl_get_ELASTICITY/_PLASTICITY (fstr_ctrl_material.f90:60-106, :341-480) */
+  double E, nu;         /* M_YOUNGS, M_POISSON */
+  int32_t plastic;      /* 0: mtype ELASTIC; 1: elastoplastic, Mises */
+  int32_t harden;       /* fifth digit of mtype: 0 BILINEAR 1 MULTILINEAR 2 SWIFT 3 RAMBERG-OSGOOD */
+  int32_t nlgeom;       /* nlgeom_flag: 0 INFINITE 1 TOTALLAG 2 UPDATELAG */
+  int32_t ntab;         /* MULTILINEAR: rows of the MC_YIELD table */
+  double plconst[3];    /* M_PLCONST1..3 */
+  const double *tab;    /* ntab rows (yield stress, plastic strain) */
+} fx_material_view;
+typedef struct fx_nl_state_view { /* host arrays, any may be NULL (skipped).  tGaussStatus members (mechgauss.f90:13-22) */
+  double *stress, *strain, *stress_bak, *strain_bak; /* n_elem*8*6 */
+  double *plstrain, *fstat;                           /* n_elem*8: plstrain, fstatus(1) */
+  int32_t *istat;                                     /* n_elem*8: istatus(1) */
+  double *unode, *dunode, *qforce;                    /* 3*NP: fstrSOLID%unode, %dunode, %QFORCE */
+  int32_t latch; /* MatlMatrix's saved flag (calMatMatrix.f90:39); set_state: <0 leaves it */
+} fx_nl_state_view;
+/* fstr_solid / gauss-point set-up (zero state).  Needs a profile (fx_upload FX_UP_PROFILE). */
+int fx_nl_init(fx_context *ctx, const fx_mesh_view *mesh, const fx_material_view *mat);
+/* fstr_Newton :63-68 + fstr_ass_load: dunode = 0, GL (3*NP, may be NULL), B = GL - QFORCE. */
+int fx_nl_begin_substep(fx_context *ctx, const double *GL);
+/* fstr_StiffMatrix (fstr_StiffMatrix.f90:18-212) + fstr_AddBC (fstr_AddBC.f90:17-190) with the
+ * given increments of the prescribed dofs; result in the resident D/AL/AU/B. */
+int fx_nl_stiffness(fx_context *ctx, int32_t n_bc, const int32_t *bc_node, const int32_t *bc_dof,
+                    const double *bc_val, float *ms_assemble);
+/* dunode += X, fstr_UpdateNewton (fstr_Update.f90:25-293), fstr_Update_NDForce
+ * (fstr_Residual.f90:23-71); out = {|B|^2,|X|^2,|QFORCE|^2,|dunode|^2} (may be NULL). */
+int fx_nl_update(fx_context *ctx, double out[4], float *ms_update);
+/* unode += dunode, fstr_UpdateState (fstr_Update.f90:296-345). */
+int fx_nl_commit(fx_context *ctx);
+int fx_nl_get_state(fx_context *ctx, fx_nl_state_view *s);
+int fx_nl_set_state(fx_context *ctx, const fx_nl_state_view *s);
+/* element-level outputs of the two kernels, no scatter (tests): ke n_elem*24*24, qf n_elem*24 */
+int fx_nl_element_tangents(fx_context *ctx, double *ke);
+int fx_nl_element_update(fx_context *ctx, double *qf);
+/* One substep of fstr_Newton around fx_solve_resident.  log: 7 doubles per Newton iteration
+ * (iter, solver iterations, solver code, |B|, |X|, |QFORCE|, |dunode|).  Returns 0 (converged),
+ * FX_ERROR_NOCONV_MAXIT (max_iter ran out; committed only if commit_unconverged) or an error. */
+int fx_newton_substep(fx_context *ctx, double factor0, double factor1, int32_t n_bc,
+                      const int32_t *bc_node, const int32_t *bc_dof, const double *bc_val,
+                      const double *cload, int32_t max_iter, double converg, int32_t *Iarray,
+                      double *Rarray, double *log, int32_t *n_iter, int commit_unconverged);
+
 /* ---- multi-GPU (one process per GPU, RCCL over xGMI) -------------------- */
 /* 128-byte ncclUniqueId made by rank 0 and broadcast by the host side
  * (torch.distributed / MPI); then every rank calls fx_comm_init. */

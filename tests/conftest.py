@@ -32,3 +32,9 @@ def oracle():
     from oracle import pyoracle
     pyoracle.build()
     return pyoracle
+
+
+@pytest.fixture(scope="session")
+def hip():
+    from frontistr_amd import hecmw
+    return hecmw

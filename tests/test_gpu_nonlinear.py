@@ -1,0 +1,169 @@
+"""GPU parity of the nonlinear C3D8 B-bar path through the C ABI: element tangent,
+stress update + return mapping + internal force, and whole load-step loops, against fixtures produced
+by the reference routines (tests/golden/nl_*.npz, see make_nl_golden.py) and against the oracle on
+other decks.  fp64; tolerances: element quantities 1e-11 relative to the largest entry (different
+summation order + FMA contraction), Newton histories 1e-6 relative (they pass through a Krylov solve
+to TOL 1e-10), converged fields 1e-8 / stresses 1e-7 relative to their maxima, plastic flags exact."""
+import os
+
+import numpy as np
+import pytest
+
+from frontistr_amd.mesh import CubeMesh
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _T():
+    import test_oracle_nl as T
+    return T
+
+
+def _fmat(mat):
+    from frontistr_amd import fstr
+    return fstr.tMaterial(mat.E, mat.nu, plastic=mat.plastic, harden=mat.harden, plconst=mat.plconst,
+                          table=mat.table if mat.table.size else None, nlgeom_flag=mat.nlgeom)
+
+
+def _solid(hip, mat, m):
+    from frontistr_amd import fstr
+    hm = hip.hecmwST_local_mesh(n_node=m.n_node)
+    hm.elem_node_item = m.conn.ravel()
+    hecMAT = hip.hecmw_mat_con(hm, hip.hecmwST_matrix())
+    ctx = hip.SolverContext()
+    ctx.upload(hecMAT, what=hip.FX_UP_PROFILE)
+    return ctx, hecMAT, fstr.fstr_solid(ctx, m.coord, m.conn, _fmat(mat))
+
+
+def _close(a, b, tol, tag):
+    scale = max(np.abs(b).max(), 1e-300)
+    err = np.abs(a - b).max() / scale
+    assert err < tol, "%s: %.3e" % (tag, err)
+
+
+NAMES = ["elastic_ul", "elastic_tl", "mises_multilinear_ul", "mises_bilinear_ul", "mises_swift_tl", "mises_ramberg_inf"]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_elements_vs_reference_golden(hip, name):
+    T = _T()
+    mat, m, unode, dunode, st = T.element_case(name)
+    g = np.load(os.path.join(GOLD, "nl_elements_%s.npz" % name))
+    ctx, hecMAT, solid = _solid(hip, mat, m)
+    solid.set_state(dict(st, unode=unode, dunode=dunode), latch=0)
+    _close(solid.element_tangents(), g["ke0"], 1e-11, "tangent before the first update")
+    qf = solid.element_update()
+    _close(qf, g["qf"], 1e-11, "internal force")
+    s = solid.get_state()
+    assert s["latch"] == (1 if mat.plastic else 0)
+    _close(s["stress"], g["stress"], 1e-11, "stress")
+    _close(s["strain"], g["strain"], 1e-11, "strain")
+    if mat.plastic:
+        _close(s["fstat"], g["fstat"], 1e-11, "fstatus(1)")
+        assert np.array_equal(s["istat"], g["istat"])
+    _close(solid.element_tangents(), g["ke1"], 1e-11, "tangent after the update (latched elastic matrix)")
+    ctx.close()
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_elements_vs_oracle_random(hip, oracle, seed):
+    """Another deck / history than the fixtures, all six material variants, against the oracle."""
+    T = _T()
+    for name in NAMES:
+        mat, m, unode, dunode, st = T.element_case(name, seed=seed)
+        ke0, qf, ke1, ost = oracle.nl_elements(mat, m.coord, m.conn, unode, dunode, st)
+        ctx, hecMAT, solid = _solid(hip, mat, m)
+        solid.set_state(dict(st, unode=unode, dunode=dunode), latch=0)
+        _close(solid.element_tangents(), ke0, 1e-11, name + " ke0")
+        _close(solid.element_update(), qf, 1e-11, name + " qf")
+        s = solid.get_state()
+        _close(s["stress"], ost["stress"], 1e-11, name + " stress")
+        assert np.array_equal(s["istat"], ost["istat"])
+        _close(solid.element_tangents(), ke1, 1e-11, name + " ke1")
+        ctx.close()
+
+
+def _check_steps(log, state, want, plastic):
+    wl = want["log"]
+    assert log.shape[0] == wl.shape[0], (log.shape, wl.shape)
+    assert np.array_equal(log[:, :2], wl[:, :2])                       # Newton iterations per substep
+    np.testing.assert_allclose(log[:, 4:], wl[:, 3:], rtol=1e-6, atol=1e-9)
+    _close(state["unode"], want["unode"], 1e-8, "unode")
+    _close(state["stress"], want["stress"], 1e-7, "stress")
+    if plastic:
+        assert np.abs(state["plstrain"] - want["plstrain"]).max() < 1e-9
+        assert np.array_equal(state["istat"], want["istat"])
+
+
+@pytest.mark.parametrize("name", ["mises_multilinear_ul", "mises_bilinear_ul", "elastic_tl"])
+def test_load_steps_vs_reference_golden(hip, name):
+    """fstr_solve_NLGEOM sub-step loop (3 substeps, CG + multicolour SSOR) against the reference's own run."""
+    from frontistr_amd import fstr
+    T = _T()
+    mat, m, bc, cload, I, R = T.step_case(name)
+    g = np.load(os.path.join(GOLD, "nl_steps_%s.npz" % name))
+    ctx, hecMAT, solid = _solid(hip, mat, m)
+    hecMAT.Iarray[:] = I
+    hecMAT.Rarray[:] = R
+    log = fstr.fstr_solve_NLGEOM(solid, hecMAT, bc, cload, 3, 12, T.STEP_CONVERG[name])
+    _check_steps(log, solid.get_state(), g, mat.plastic)
+    ctx.close()
+
+
+def test_load_steps_vs_oracle_bigger(hip, oracle):
+    """6^3 elements, 2 substeps, multilinear Mises + updated Lagrange, CG + block-Jacobi: against the oracle loop."""
+    from frontistr_amd import fstr
+    from oracle import refrun
+    T = _T()
+    mat = T.materials()["mises_multilinear_ul"]
+    m = CubeMesh(6, skew=0.08)
+    bn, bd, bv = m.dirichlet()
+    tn = np.repeat(m.top_nodes, 3).astype(np.int32)
+    td = np.tile(np.array([1, 2, 3], dtype=np.int32), m.top_nodes.size)
+    tv = np.tile(np.array([0.0, 0.05, 0.2]), m.top_nodes.size)
+    bc = (np.concatenate([bn, tn]), np.concatenate([bd, td]), np.concatenate([bv, tv]))
+    cload = np.zeros(m.ndof)
+    I, R = refrun.default_params(method=1, precond=3, tol=1e-10, iterlog=0, timelog=0)
+    model = oracle.NonlinearModel(mat, m.coord, m.conn)
+    olog = model.run_steps(*bc, cload, 2, 6, 1e-4, I, R, nthreads=2)
+    want = dict(log=olog, unode=model.unode, stress=model.state["stress"], plstrain=model.state["plstrain"],
+                istat=model.state["istat"])
+    ctx, hecMAT, solid = _solid(hip, mat, m)
+    hecMAT.Iarray[:] = I
+    hecMAT.Rarray[:] = R
+    log = fstr.fstr_solve_NLGEOM(solid, hecMAT, bc, cload, 2, 6, 1e-4)
+    _check_steps(log, solid.get_state(), want, True)
+    assert want["plstrain"].max() > 1e-3
+    ctx.close()
+
+
+def test_newton_pieces_match_substep(hip):
+    """The piecewise API (begin_substep / StiffMatrix / solve / UpdateNewton / UpdateState) reproduces fx_newton_substep."""
+    from frontistr_amd import fstr
+    from frontistr_amd.hecmw import lib, _chk, _ptr
+    T = _T()
+    mat, m, bc, cload, I, R = T.step_case("mises_bilinear_ul")
+    res = []
+    for piecewise in (False, True):
+        ctx, hecMAT, solid = _solid(hip, mat, m)
+        hecMAT.Iarray[:] = I
+        hecMAT.Rarray[:] = R
+        if not piecewise:
+            ok, log = fstr.fstr_Newton(solid, hecMAT, (0.0, 0.5), bc, cload, 4, 1e-12, commit_unconverged=True)
+            assert not ok and log.shape[0] == 4
+        else:
+            _chk(lib().fx_nl_begin_substep(ctx.h, _ptr(np.ascontiguousarray(cload * 0.5))))
+            for it in range(1, 5):
+                fstr.fstr_StiffMatrix(solid, (bc[0], bc[1], bc[2] * (0.5 if it == 1 else 0.0)))
+                hecMAT.Iarray[96] = 2 if it == 1 else 1
+                hecMAT.X[:] = 0.0
+                ctx.upload(hecMAT, what=hip.FX_UP_X)
+                ctx.solve_resident(hecMAT, want_history=False)
+                fstr.fstr_UpdateNewton(solid)
+            fstr.fstr_UpdateState(solid)
+        res.append(solid.get_state())
+        ctx.close()
+    _close(res[1]["unode"], res[0]["unode"], 1e-12, "unode")
+    _close(res[1]["stress_bak"], res[0]["stress_bak"], 1e-11, "stress_bak")
+    assert np.array_equal(res[1]["istat"], res[0]["istat"])
