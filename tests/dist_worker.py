@@ -8,6 +8,18 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 
+NL_MATERIAL = ((1.0e5, 0.3), dict(plastic=True, harden=0, plconst=(1000.0, 2000.0, 0.0), nlgeom_flag=2))
+
+
+def nl_bc(coord, clamp, ztop):
+    """bottom clamped (the deck's FIX group), top face pulled by 2 % in z with a 1 % x shear"""
+    top = (np.nonzero(coord[:, 2] == ztop)[0] + 1).astype(np.int32)
+    tn = np.repeat(top, 3).astype(np.int32)
+    td = np.tile(np.array([1, 2, 3], dtype=np.int32), top.size)
+    tv = np.tile(np.array([0.01 * ztop, 0.0, 0.02 * ztop]), top.size)
+    return (np.concatenate([clamp[0], tn]), np.concatenate([clamp[1], td]), np.concatenate([clamp[2], tv]))
+
+
 def main():
     mode, rank, world, port, m, meth, pc, out = sys.argv[1:9]
     rank, world, meth, pc = int(rank), int(world), int(meth), int(pc)
@@ -51,6 +63,23 @@ def main():
         I, R = default_params(method=meth, precond=pc)
         o = po.solve_iterative(A, I, R, nthreads=4, comm=comm)
         X, it, hist, code = o["X"], o["iter"], o["history"], o["code"]
+    elif mode == "hipnl":
+        # nonlinear static loop (elastoplastic, updated Lagrange) on the subdomain: 2 substeps x 4 Newton iterations
+        from frontistr_amd import fstr, hecmw as hip
+        from frontistr_amd.comm import attach_host_callbacks
+        hm = sub.hecmesh(hip)
+        hm.elem_node_item = sub.conn.ravel()
+        mat = hip.hecmw_mat_con(hm, hip.hecmwST_matrix())
+        ctx = hip.SolverContext(device=0)
+        attach_host_callbacks(ctx, hm, hip.lib())
+        ctx.upload(mat, hm, what=hip.FX_UP_PROFILE)
+        solid = fstr.fstr_solid(ctx, sub.coord, sub.conn, fstr.tMaterial(*NL_MATERIAL[0], **NL_MATERIAL[1]))
+        bc = nl_bc(sub.coord, sub.dirichlet(), dims[2] * int(m) - 1)
+        mat.Iarray[0] = 10000; mat.Iarray[1] = meth; mat.Iarray[2] = pc; mat.Rarray[0] = 1e-10
+        log = fstr.fstr_solve_NLGEOM(solid, mat, bc, None, 2, 4, 1e-12)
+        st = solid.get_state(("unode", "qforce"))
+        X, it, hist, code = st["unode"], log.shape[0], log[:, 4], 0
+        ctx.close()
     else:
         from frontistr_amd import hecmw as hip
         from frontistr_amd.comm import attach_host_callbacks

@@ -66,3 +66,33 @@ def test_hip_on_reference_partitioner_files(oracle, tmp_path):
     library; the field equals the serial solve of the undecomposed mesh."""
     res = run_world("hip", 4, "dist:" + dist_prefix(), 1, 3, tmp_path)
     check_against_serial(res, serial_cube4(oracle, 1, 3), 1)
+
+
+def test_hip_distributed_nonlinear_equals_serial_oracle(oracle, tmp_path):
+    """The nonlinear static loop (elastoplastic, updated Lagrange) on 2 subdomains: halo handling of
+    dunode / QFORCE / the residual and the nn_internal norms, against the serial oracle loop on the
+    undecomposed mesh (block-Jacobi CG, so the linear solves are decomposition independent)."""
+    from dist_worker import NL_MATERIAL, nl_bc
+    from oracle import refrun
+    m, dims = 5, (2, 1, 1)
+    res = run_world("hipnl", 2, m, 1, 3, tmp_path)
+    G = (dims[0] * m, dims[1] * m, dims[2] * m)
+    kk, jj, ii = np.meshgrid(np.arange(G[2]), np.arange(G[1]), np.arange(G[0]), indexing="ij")
+    coord = np.stack([ii.ravel(), jj.ravel(), kk.ravel()], axis=1).astype(float)
+    ek, ej, ei = np.meshgrid(np.arange(G[2] - 1), np.arange(G[1] - 1), np.arange(G[0] - 1), indexing="ij")
+    n0 = (1 + ei + G[0] * (ej + G[1] * ek)).ravel()
+    s1, s2 = G[0], G[0] * G[1]
+    conn = np.stack([n0, n0 + 1, n0 + 1 + s1, n0 + s1, n0 + s2, n0 + 1 + s2, n0 + 1 + s1 + s2, n0 + s1 + s2], axis=1).astype(np.int32)
+    bottom = (np.nonzero(coord[:, 2] == 0)[0] + 1).astype(np.int32)
+    clamp = (np.repeat(bottom, 3).astype(np.int32), np.tile(np.array([1, 2, 3], dtype=np.int32), bottom.size), np.zeros(3 * bottom.size))
+    bc = nl_bc(coord, clamp, G[2] - 1)
+    mat = refrun.Material(*NL_MATERIAL[0], plastic=True, harden=0, plconst=NL_MATERIAL[1]["plconst"], nlgeom=2)
+    I, R = refrun.default_params(method=1, precond=3, tol=1e-10, iterlog=0, timelog=0)
+    model = oracle.NonlinearModel(mat, coord, conn)
+    olog = model.run_steps(*bc, np.zeros(3 * coord.shape[0]), 2, 4, 1e-12, I, R, nthreads=2)
+    assert model.state["plstrain"].max() > 1e-3
+    us = model.unode.reshape(-1, 3)
+    for r in res:
+        assert int(r["it"]) == olog.shape[0] == 8
+        assert np.abs(r["X"].reshape(-1, 3) - us[r["gid"]]).max() < 1e-8 * np.abs(us).max()      # internal and halo nodes
+        np.testing.assert_allclose(r["hist"], olog[:, 3], rtol=1e-6)                               # |residual| per Newton iteration

@@ -89,3 +89,57 @@ def test_cg_reported_residual_is_true_residual(n, pc):
         Mr, Ms = ctx.precond_apply(r), ctx.precond_apply(s)
         assert abs(np.dot(s, Mr) - np.dot(r, Ms)) <= 1e-9 * (np.abs(s) @ np.abs(Mr))
     ctx.close()
+
+
+@pytest.mark.parametrize("n", [69, 149])
+def test_nonlinear_patch_test_fullsize(n):
+    """Nonlinear path at BASELINE sizes through the patch-test property: under a homogeneous displacement
+    increment every quadrature point of the (unskewed) mesh must return the same stress, plastic strain and
+    flag, the internal force must vanish at interior nodes, a second update with a zero increment must leave
+    the committed state alone (idempotence), and the updated-Lagrange tangent of that state must be
+    symmetric and annihilate translations."""
+    from frontistr_amd import fstr, hecmw as hip
+    from frontistr_amd.mesh import CubeMesh
+    mesh = CubeMesh(n)
+    hm = hip.hecmwST_local_mesh(n_node=mesh.n_node)
+    hm.elem_node_item = mesh.conn.ravel()
+    m = hip.hecmw_mat_con(hm, hip.hecmwST_matrix())
+    ctx = hip.SolverContext()
+    ctx.upload(m, what=hip.FX_UP_PROFILE | hip.FX_UP_X)                      # X = 0: no solver increment
+    table = [[450, 0], [608, 0.05], [679, 0.1], [732, 0.2], [752, 0.3], [766, 0.4], [780, 0.5]]
+    solid = fstr.fstr_solid(ctx, mesh.coord, mesh.conn,
+                            fstr.tMaterial(206900.0, 0.29, plastic=True, harden=fstr.MULTILINEAR, table=table))
+    H = np.array([[0.004, 0.002, 0.0], [0.0, -0.001, 0.001], [0.0005, 0.0, 0.012]])
+    du = (mesh.coord @ H.T).ravel()
+    solid.set_state(dict(dunode=du))
+    (res, xn, qn, dun), ms = fstr.fstr_UpdateNewton(solid)
+    assert xn == 0.0 and abs(dun - np.sqrt(np.dot(du, du))) < 1e-9 * dun
+    s = solid.get_state(("stress", "fstat", "istat", "qforce"))
+    sig = s["stress"].reshape(-1, 6)
+    assert np.abs(sig - sig[0]).max() < 1e-9 * np.abs(sig[0]).max()
+    assert s["istat"].min() == 1 and s["fstat"].min() > 1e-3
+    assert s["fstat"].max() - s["fstat"].min() < 1e-12
+    q = s["qforce"].reshape(-1, 3)
+    c = mesh.coord
+    interior = np.all((c > 0) & (c < n), axis=1)
+    assert np.abs(q[interior]).max() < 1e-9 * np.abs(q[~interior]).max()
+    del sig
+    # idempotence: commit, then a zero increment
+    fstr.fstr_UpdateState(solid)
+    solid.set_state(dict(dunode=np.zeros_like(du)))
+    fstr.fstr_UpdateNewton(solid)
+    s2 = solid.get_state(("stress", "istat", "fstat"))
+    assert np.abs(s2["stress"] - s["stress"]).max() < 1e-10 * np.abs(s["stress"]).max()
+    assert np.array_equal(s2["istat"], s["istat"]) and np.array_equal(s2["fstat"], s["fstat"])
+    del s, s2
+    # tangent of that state (no BC): symmetric, translations in the null space
+    fstr.fstr_StiffMatrix(solid)
+    m.D = np.zeros(1); m.AL = np.zeros(1); m.AU = np.zeros(1)
+    rng = np.random.default_rng(1)
+    w, v = rng.standard_normal(3 * m.NP), rng.standard_normal(3 * m.NP)
+    Aw, Av = spmv(hip, ctx, m, w), spmv(hip, ctx, m, v)
+    assert abs(np.dot(v, Aw) - np.dot(w, Av)) < 1e-10 * np.sqrt(np.dot(Aw, Aw) * np.dot(v, v))
+    for d in range(3):
+        t = np.zeros((m.NP, 3)); t[:, d] = 1.0
+        assert np.abs(spmv(hip, ctx, m, t.ravel())).max() < 1e-9 * np.abs(Aw).max()
+    ctx.close()
