@@ -717,6 +717,8 @@ int orc_solve_bicgstab(const orc_matrix *A, const orc_comm *c, orc_precond *P, i
   return error;
 }
 
+#include "hecmw_krylov2_oracle.c" /* GMRES, GPBiCG */
+
 /* hecmw_solve_iterative, hecmw_solver_Iterative.f90:13-210 (serial + comm hooks).
  * Error codes: hecmw_solve_error.f90:9-15. */
 int orc_solve_iterative(const orc_matrix *A, const orc_comm *c, const double *B, double *X,
@@ -767,6 +769,10 @@ int orc_solve_iterative(const orc_matrix *A, const orc_comm *c, const double *B,
       error = orc_solve_cg(A, c, P, iterPREmax, B, X, ITER, RESID, &iter_run, &resid_run, hist);
     else if (METHOD == 2)
       error = orc_solve_bicgstab(A, c, P, iterPREmax, B, X, ITER, RESID, &iter_run, &resid_run, hist);
+    else if (METHOD == 3)
+      error = orc_solve_gmres(A, c, P, iterPREmax, B, X, ITER, RESID, F1(Iarray, 6), &iter_run, &resid_run, hist, NULL);
+    else if (METHOD == 4)
+      error = orc_solve_gpbicg(A, c, P, iterPREmax, B, X, ITER, RESID, &iter_run, &resid_run, hist);
     else { orc_precond_free(P); return 1001; }
     orc_precond_free(P);
     if (error == ERR_DIVERGE_PC || error == ERR_DIVERGE_MAT) { /* :145-156 */

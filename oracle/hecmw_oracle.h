@@ -71,6 +71,13 @@ int orc_solve_cg(const orc_matrix *A, const orc_comm *c, orc_precond *P, int ite
 int orc_solve_bicgstab(const orc_matrix *A, const orc_comm *c, orc_precond *P, int iterPREmax,
                        const double *B, double *X, int maxit, double tol, int *iter_out,
                        double *resid_out, double *hist);
+/* hecmw_solver_GMRES.f90:17-458 (NREST = Iarray(6)); hist gets one RESID per inner iteration (nhist_out) */
+int orc_solve_gmres(const orc_matrix *A, const orc_comm *c, orc_precond *P, int iterPREmax, const double *B,
+                    double *X, int maxit, double tol, int nrest, int *iter_out, double *resid_out, double *hist,
+                    int *nhist_out);
+/* hecmw_solver_GPBiCG.f90:17-505 */
+int orc_solve_gpbicg(const orc_matrix *A, const orc_comm *c, orc_precond *P, int iterPREmax, const double *B,
+                     double *X, int maxit, double tol, int *iter_out, double *resid_out, double *hist);
 /* hecmw_solver_Iterative.f90:13-210: Iarray/Rarray protocol, zero-RHS / zero-diag checks,
  * final ||b-Ax||/||b|| -> Iarray(81).  nthreads selects the SSOR ordering path. */
 int orc_solve_iterative(const orc_matrix *A, const orc_comm *c, const double *B, double *X,

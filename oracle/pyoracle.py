@@ -139,7 +139,7 @@ def solve_iterative(m, I, R, nthreads=1, comm=None):
     R = np.ascontiguousarray(R, dtype=np.float64).copy()
     X = np.ascontiguousarray(m.X, dtype=np.float64).copy()
     B = np.ascontiguousarray(m.B, dtype=np.float64)
-    hist = np.zeros(max(int(I[0]), 1))
+    hist = np.zeros(max(int(I[0]), 1) + 2)      # GMRES may log MAXIT+1 lines
     it, rs = C.c_int(0), C.c_double(0.0)
     A = cmatrix(m)
     code = lib().orc_solve_iterative(C.byref(A), comm.ref() if comm else None, _dp(B), _dp(X), _ip(I),

@@ -93,6 +93,7 @@ def write_system(path, mode, m, I, R, nrepeat=1):
 
 
 HIST_RE = re.compile(r"^\s*(\d+)\s+([0-9.]+E[+-]\d+)\s*$")
+HIST3_RE = re.compile(r"^\s*(\d+)\s+(\d+)\s+([0-9.]+E[+-]\d+)\s*$")     # GMRES: iter, I+1, RESID (hecmw_solver_GMRES.f90:272)
 
 
 def parse_stdout(text):
@@ -101,6 +102,10 @@ def parse_stdout(text):
         m = HIST_RE.match(line)
         if m:
             hist.append((int(m.group(1)), float(m.group(2))))
+            continue
+        m = HIST3_RE.match(line)
+        if m:
+            hist.append((int(m.group(1)), float(m.group(3))))
             continue
         m = re.match(r"\s*(\d+) iterations\s+([0-9.E+-]+)", line)
         if m:

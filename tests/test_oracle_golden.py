@@ -43,6 +43,36 @@ def test_solver_matches_reference(oracle, deck, meth, pc, thr):
     assert o["Iarray"][80] == g[tag + "Iarray"][80] == 1
 
 
+# (deck, method, precond, reference threads, MAXIT, NREST): GMRES(m) and GPBiCG, incl. a restart length other
+# than the default and a run into MAXIT (GMRES runs MAXIT+1 iterations and updates X once more on failure)
+KRYLOV2_CASES = [(d, m, p, t, 10000, 10) for d in ("cube4", "cube3s") for m in (3, 4) for p, t in ((3, 1), (1, 4), (10, 1))] + [
+    ("exA_A361", 3, 10, 1, 10000, 10), ("exA_A361", 4, 3, 1, 10000, 10), ("exA_A361", 4, 1, 4, 10000, 10),
+    ("exA_A361", 4, 10, 1, 10000, 10), ("cube4", 3, 3, 1, 10000, 4), ("cube4", 3, 3, 1, 20, 10), ("cube4", 4, 3, 1, 8, 10)]
+
+
+def krylov2_tag(deck, meth, pc, thr, maxit, nrest):
+    return "%s_m%d_p%d_t%d_i%d_r%d_" % (deck, meth, pc, thr, maxit, nrest)
+
+
+@pytest.mark.parametrize("case", KRYLOV2_CASES, ids=lambda c: krylov2_tag(*c))
+def test_gmres_gpbicg_match_reference(oracle, case):
+    from oracle.refrun import default_params
+    deck, meth, pc, thr, maxit, nrest = case
+    g = load_golden("krylov2")
+    tag = krylov2_tag(*case)
+    A = golden_matrix(load_golden(deck))
+    I, R = default_params(method=meth, precond=pc, maxit=maxit)
+    I[5] = nrest
+    o = oracle.solve_iterative(A, I, R, nthreads=thr)
+    assert o["iter"] == int(g[tag + "iter"])
+    assert o["code"] == (3001 if o["iter"] > maxit else 0)      # both methods leave ITER = MAXIT+1 when they run out
+    h = g[tag + "hist"]
+    assert len(o["history"]) == len(h)
+    assert np.all(np.abs(o["history"] - h) <= 6e-7 * h)
+    assert np.array_equal(o["X"], g[tag + "X"])        # bit exact, also on the MAXIT path
+    assert o["Iarray"][80] == g[tag + "Iarray"][80]
+
+
 def test_exA_known_answer(oracle):
     """examples/static/exA/A361_correct.log extrema, the reference harness' own
     tolerance (|d| <= 1e-4, examples/test_FrontISTR.rb:10)."""
