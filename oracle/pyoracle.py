@@ -144,7 +144,7 @@ def solve_iterative(m, I, R, nthreads=1, comm=None):
     A = cmatrix(m)
     code = lib().orc_solve_iterative(C.byref(A), comm.ref() if comm else None, _dp(B), _dp(X), _ip(I),
                                      _dp(R), nthreads, C.byref(it), C.byref(rs), _dp(hist))
-    n = min(it.value, hist.size)
+    n = min(it.value, hist.size) if int(I[1]) == 3 else min(it.value, int(I[0]))   # a DO loop that runs out leaves ITER = MAXIT+1
     return dict(code=code, iter=it.value, resid=rs.value, history=hist[:n].copy(), X=X, Iarray=I)
 
 
