@@ -209,7 +209,7 @@ extern "C" void fx_destroy(fx_context *c) {
   free_matrix(c);
   dev_free(c->halo.export_item); dev_free(c->halo.import_item);
   dev_free(c->halo.sendbuf); dev_free(c->halo.recvbuf);
-  dev_free(c->st); dev_free(c->red_out); dev_free(c->hist);
+  dev_free(c->st); dev_free(c->red_out); dev_free(c->hist); dev_free(c->extra);
   if (c->st_host) (void)hipHostFree(c->st_host);
   if (c->h_send) (void)hipHostFree(c->h_send);
   if (c->h_recv) (void)hipHostFree(c->h_recv);
@@ -1205,6 +1205,8 @@ static int host_sum(fx_context *c, int nparts, int stride, double *v0, double *v
   return 0;
 }
 
+#include "fx_krylov2_host.h"
+
 extern "C" int fx_solve_resident(fx_context *c, int32_t *Iarray, double *Rarray, fx_solve_info *info, double *hist,
                                  int32_t hist_len) {
   HIP_TRY(hipSetDevice(c->device));
@@ -1272,7 +1274,19 @@ extern "C" int fx_solve_resident(fx_context *c, int32_t *Iarray, double *Rarray,
     Iarray[80] = 0; Iarray[81] = 0;
     int e;
     if (method == 1 || method == 2) e = run_krylov(c, method, maxit, tol, &s);
-    else { g_fx_error = "METHOD must be 1 (CG) or 2 (BiCGSTAB) on the GPU hot path"; return FX_ERROR_INCONS_PC; }
+    else if (method == 3 || method == 4) {
+      HostKrylov hk;
+      e = (method == 3) ? gmres_solve(c, maxit, tol, Iarray[5], &hk) : gpbicg_solve(c, maxit, tol, &hk);
+      if (e) return e;
+      memset(&s, 0, sizeof s);
+      s.iter = hk.iter; s.resid = hk.resid; s.status = hk.status; s.n_hist = (int32_t)hk.hist.size();
+      if (c->hist_cap < (int32_t)hk.hist.size()) {
+        dev_free(c->hist);
+        if (dev_alloc(&c->hist, hk.hist.size())) return FX_ERROR_RUNTIME;
+        c->hist_cap = (int32_t)hk.hist.size();
+      }
+      if (!hk.hist.empty()) HIP_TRY(hipMemcpy(c->hist, hk.hist.data(), hk.hist.size() * 8, hipMemcpyHostToDevice));
+    } else { g_fx_error = "METHOD must be 1 (CG), 2 (BiCGSTAB), 3 (GMRES) or 4 (GPBiCG)"; return FX_ERROR_INCONS_PC; }
     if (e) return e;
     if (s.status == FX_ERROR_DIVERGE_PC || s.status == FX_ERROR_DIVERGE_MAT) {  // :145-156
       Iarray[81] = 1;

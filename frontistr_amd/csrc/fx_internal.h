@@ -181,6 +181,9 @@ struct fx_context {
   double *W[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int iterpremax = 1;  // additive-Schwarz sweeps of hecmw_precond_33_apply
   int32_t wlen = 0;
+  double *extra = nullptr;  // further work vectors (GMRES basis, GPBiCG), extra_n x extra_len
+  int extra_n = 0;
+  int32_t extra_len = 0;
   // reductions
   double *partials = nullptr;  // 3 * max_partials
   int32_t max_partials = 0;

@@ -207,7 +207,7 @@ class SolverContext:
     def solve_resident(self, hecMAT, want_history=True):
         info = _SolveInfo()
         maxit = int(hecMAT.Iarray[0])
-        hist = np.zeros(max(maxit, 1)) if want_history else None
+        hist = np.zeros(max(maxit, 1) + 1) if want_history else None   # GMRES logs MAXIT+1 lines when it runs out
         code = lib().fx_solve_resident(self.h, _ptr(hecMAT.Iarray), _ptr(hecMAT.Rarray), C.byref(info),
                                        _ptr(hist), 0 if hist is None else hist.size)
         self._finish(code, info, hist)
@@ -350,7 +350,7 @@ def hecmw_solve(hecMESH, hecMAT, ctx=None, want_history=True):
     cv = hecMESH.comm_view() if hecMESH is not None else None
     info = _SolveInfo()
     maxit = int(hecMAT.Iarray[0])
-    hist = np.zeros(max(maxit, 1)) if want_history else None
+    hist = np.zeros(max(maxit, 1) + 1) if want_history else None   # GMRES logs MAXIT+1 lines when it runs out
     code = lib().fx_solve(ctx.h, C.byref(mv), C.byref(cv) if cv is not None else None, _ptr(hecMAT.Iarray),
                           _ptr(hecMAT.Rarray), C.byref(info), _ptr(hist), 0 if hist is None else hist.size)
     ctx._finish(code, info, hist)

@@ -107,7 +107,7 @@ contains
       cv%export_index = c_loc(hecMESH%export_index(0)); cv%export_item = c_loc(hecMESH%export_item(1))
     endif
 
-    nhist = max(hecmw_mat_get_iter(hecMAT), 1)
+    nhist = max(hecmw_mat_get_iter(hecMAT), 1) + 1   ! GMRES logs MAXIT+1 lines when it runs out
     allocate(hist(nhist))
     ierr = fx_solve(fx_ctx, mv, cv, hecMAT%Iarray, hecMAT%Rarray, info, hist, int(nhist, c_int32_t))
 
