@@ -167,3 +167,33 @@ def test_newton_pieces_match_substep(hip):
     _close(res[1]["unode"], res[0]["unode"], 1e-12, "unode")
     _close(res[1]["stress_bak"], res[0]["stress_bak"], 1e-11, "stress_bak")
     assert np.array_equal(res[1]["istat"], res[0]["istat"])
+
+
+def test_nonlinear_api_errors(hip):
+    """Protocol errors of the nonlinear entry points are reported, not crashed on."""
+    from frontistr_amd import fstr
+    from frontistr_amd.hecmw import HecmwSolverError, _chk, lib
+    T = _T()
+    mat, m, unode, dunode, st = T.element_case("elastic_ul")
+    ctx = hip.SolverContext()
+    with pytest.raises(HecmwSolverError):                       # no profile yet
+        fstr.fstr_solid(ctx, m.coord, m.conn, _fmat(mat))
+    with pytest.raises(HecmwSolverError):                       # fx_nl_init not called
+        _chk(lib().fx_nl_commit(ctx.h))
+    hm = hip.hecmwST_local_mesh(n_node=m.n_node)
+    hm.elem_node_item = m.conn.ravel()
+    hecMAT = hip.hecmw_mat_con(hm, hip.hecmwST_matrix())
+    ctx.upload(hecMAT, what=hip.FX_UP_PROFILE)
+    bad = _fmat(mat); bad.harden = 4                            # kinematic hardening: outside the hot path
+    with pytest.raises(HecmwSolverError) as e:
+        fstr.fstr_solid(ctx, m.coord, m.conn, bad)
+    assert e.value.code == -2
+    conn = m.conn.copy(); conn[0, 0] = m.n_node + 5
+    with pytest.raises(HecmwSolverError):                       # node id out of range
+        fstr.fstr_solid(ctx, m.coord, conn, _fmat(mat))
+    with pytest.raises(ValueError):                             # the reference's own check of the MULTILINEAR table
+        fstr.tMaterial(1e5, 0.3, plastic=True, harden=fstr.MULTILINEAR, table=[[100.0, 0.01], [200.0, 0.1]])
+    solid = fstr.fstr_solid(ctx, m.coord, m.conn, _fmat(mat))
+    with pytest.raises(HecmwSolverError):                       # BC node out of range
+        fstr.fstr_StiffMatrix(solid, (np.array([m.n_node + 1], dtype=np.int32), np.array([1], dtype=np.int32), np.zeros(1)))
+    ctx.close()
