@@ -123,6 +123,20 @@ static void dev_free(T *&p) {
   p = nullptr;
 }
 
+// Temporary device buffers of one entry point: released on every return path.
+struct DevScratch {
+  std::vector<void *> ptrs;
+  template <class T>
+  int alloc(T **p, size_t count) {
+    if (dev_alloc(p, count)) return FX_ERROR_RUNTIME;
+    ptrs.push_back((void *)*p);
+    return 0;
+  }
+  ~DevScratch() {
+    for (void *q : ptrs) (void)hipFree(q);
+  }
+};
+
 static inline int grid_for(int64_t n, int per_block = FX_BLOCK, int cap = 256 * 16) {
   int64_t g = (n + per_block - 1) / per_block;
   if (g < 1) g = 1;
@@ -134,6 +148,15 @@ static inline int grid_for(int64_t n, int per_block = FX_BLOCK, int cap = 256 * 
 // ---------------------------------------------------------------------------
 extern "C" const char *fx_last_error(void) { return g_fx_error.c_str(); }
 extern "C" const char *fx_version(void) { return "fistr_hip 0.1 (gfx950)"; }
+
+static int context_init(fx_context *c) {
+  HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreate(&c->ev0));
+  HIP_TRY(hipEventCreate(&c->ev1));
+  if (dev_alloc(&c->st, 1) || dev_alloc(&c->red_out, 16)) return FX_ERROR_RUNTIME;
+  HIP_TRY(hipHostMalloc((void **)&c->st_host, sizeof(KrylovState) * 4, hipHostMallocDefault));
+  return 0;
+}
 
 extern "C" int fx_create(int device, fx_context **out) {
   *out = nullptr;
@@ -150,18 +173,16 @@ extern "C" int fx_create(int device, fx_context **out) {
   HIP_TRY(hipSetDevice(device));
   fx_context *c = new fx_context();
   c->device = device;
-  HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  HIP_TRY(hipEventCreate(&c->ev0));
-  HIP_TRY(hipEventCreate(&c->ev1));
-  if (dev_alloc(&c->st, 1)) return FX_ERROR_RUNTIME;
-  HIP_TRY(hipHostMalloc((void **)&c->st_host, sizeof(KrylovState) * 4, hipHostMallocDefault));
+  if (context_init(c)) {  // release whatever was created before the failing call
+    fx_destroy(c);
+    return FX_ERROR_RUNTIME;
+  }
   if (const char *e = getenv("FX_PIPE_SPMV")) c->pipe_spmv = atoi(e) != 0;
   if (const char *e = getenv("FX_PIPE_SSOR")) c->pipe_ssor = atoi(e) != 0;
   if (const char *e = getenv("FX_SSOR_MODE")) c->ssor_mode = atoi(e);
   if (const char *e = getenv("FX_PIPE_MAX_SLICES")) c->pipe_max_slices = atoi(e);
   if (const char *e = getenv("FX_SSOR_BS")) c->ssor_bs = (atoi(e) == 64) ? 64 : 256;
   if (const char *e = getenv("FX_SPMV_BS")) c->spmv_bs = (atoi(e) == 64) ? 64 : 256;
-  if (dev_alloc(&c->red_out, 16)) return FX_ERROR_RUNTIME;
   *out = c;
   return 0;
 }
@@ -203,7 +224,7 @@ static void free_precond(fx_context *c) {
 extern "C" void fx_destroy(fx_context *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->stream);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
   nl_free(c);
   free_precond(c);
   free_matrix(c);

@@ -86,10 +86,11 @@ extern "C" int fx_assemble_c3d8(fx_context *c, const fx_mesh_view *mesh, double 
   if (mesh->n_node != c->A.NP) { g_fx_error = "fx_assemble_c3d8: mesh/profile size mismatch"; return FX_ERROR_RUNTIME; }
   if (elemopt < 1 || elemopt > 3) { g_fx_error = "fx_assemble_c3d8: elemopt must be 1 (IC), 2 (B-bar) or 3 (FI)"; return FX_ERROR_UNSUPPORTED; }
   DevCSR &A = c->A;
+  DevScratch tmp;
   double *d_coord = nullptr, *d_bcv = nullptr, *d_val = nullptr;
   int32_t *d_conn = nullptr, *d_err = nullptr, *d_node = nullptr, *d_dof = nullptr;
   uint8_t *d_flag = nullptr;
-  if (dev_alloc(&d_coord, (size_t)3 * mesh->n_node) || dev_alloc(&d_conn, (size_t)8 * mesh->n_elem) || dev_alloc(&d_err, 1))
+  if (tmp.alloc(&d_coord, (size_t)3 * mesh->n_node) || tmp.alloc(&d_conn, (size_t)8 * mesh->n_elem) || tmp.alloc(&d_err, 1))
     return FX_ERROR_RUNTIME;
   HIP_TRY(hipMemcpyAsync(d_coord, mesh->coord, (size_t)3 * mesh->n_node * 8, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(d_conn, mesh->conn, (size_t)8 * mesh->n_elem * 4, hipMemcpyHostToDevice, c->stream));
@@ -108,8 +109,8 @@ extern "C" int fx_assemble_c3d8(fx_context *c, const fx_mesh_view *mesh, double 
   if (load) HIP_TRY(hipMemcpyAsync(A.B, load, (size_t)3 * A.NP * 8, hipMemcpyHostToDevice, c->stream));
   else HIP_TRY(hipMemsetAsync(A.B, 0, (size_t)3 * A.NP * 8, c->stream));
   if (n_bc > 0) {
-    if (dev_alloc(&d_flag, (size_t)3 * A.NP) || dev_alloc(&d_bcv, (size_t)3 * A.NP) || dev_alloc(&d_node, (size_t)n_bc) ||
-        dev_alloc(&d_dof, (size_t)n_bc) || dev_alloc(&d_val, (size_t)n_bc))
+    if (tmp.alloc(&d_flag, (size_t)3 * A.NP) || tmp.alloc(&d_bcv, (size_t)3 * A.NP) || tmp.alloc(&d_node, (size_t)n_bc) ||
+        tmp.alloc(&d_dof, (size_t)n_bc) || tmp.alloc(&d_val, (size_t)n_bc))
       return FX_ERROR_RUNTIME;
     for (int32_t k = 0; k < n_bc; k++)
       if (bc_node[k] < 1 || bc_node[k] > A.NP) { g_fx_error = "fx_assemble_c3d8: BC node id out of range"; return FX_ERROR_RUNTIME; }
@@ -133,8 +134,6 @@ extern "C" int fx_assemble_c3d8(fx_context *c, const fx_mesh_view *mesh, double 
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
   if (ms_assemble) *ms_assemble = ms;
-  dev_free(d_coord); dev_free(d_conn); dev_free(d_err); dev_free(d_flag); dev_free(d_bcv);
-  dev_free(d_node); dev_free(d_dof); dev_free(d_val);
   if (herr == 1) { g_fx_error = "PIVOT ERROR in the incompatible-mode condensation (calInverse)"; return FX_ERROR_RUNTIME; }
   if (herr == 2) { g_fx_error = "###ERROR### : cannot find connectivity (element not covered by the profile)"; return FX_ERROR_RUNTIME; }
   c->have_values = true;
@@ -145,9 +144,10 @@ extern "C" int fx_assemble_c3d8(fx_context *c, const fx_mesh_view *mesh, double 
 
 extern "C" int fx_element_stiffness_c3d8(fx_context *c, int elemopt, const double *ecoord, double E, double nu, double *stiff) {
   HIP_TRY(hipSetDevice(c->device));
+  DevScratch tmp;
   double *d_coord = nullptr, *d_k = nullptr;
   int32_t *d_conn = nullptr, *d_err = nullptr;
-  if (dev_alloc(&d_coord, 24) || dev_alloc(&d_conn, 8) || dev_alloc(&d_k, 576) || dev_alloc(&d_err, 1)) return FX_ERROR_RUNTIME;
+  if (tmp.alloc(&d_coord, 24) || tmp.alloc(&d_conn, 8) || tmp.alloc(&d_k, 576) || tmp.alloc(&d_err, 1)) return FX_ERROR_RUNTIME;
   const int32_t conn[8] = {1, 2, 3, 4, 5, 6, 7, 8};
   HIP_TRY(hipMemcpy(d_coord, ecoord, 24 * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(d_conn, conn, 32, hipMemcpyHostToDevice));
@@ -167,6 +167,5 @@ extern "C" int fx_element_stiffness_c3d8(fx_context *c, int elemopt, const doubl
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(c->stream));
   HIP_TRY(hipMemcpy(stiff, d_k, 576 * 8, hipMemcpyDeviceToHost));
-  dev_free(d_coord); dev_free(d_conn); dev_free(d_k); dev_free(d_err);
   return 0;
 }

@@ -234,22 +234,23 @@ extern "C" int fx_nl_set_state(fx_context *c, const fx_nl_state_view *s) {
 extern "C" int fx_nl_element_tangents(fx_context *c, double *ke) {
   NL_READY("fx_nl_element_tangents");
   NlDev &n = c->nl;
+  DevScratch tmp;
   double *d = nullptr;
-  if (dev_alloc(&d, (size_t)576 * n.n_elem)) return FX_ERROR_RUNTIME;
+  if (tmp.alloc(&d, (size_t)576 * n.n_elem)) return FX_ERROR_RUNTIME;
   if (n.mat.nlgeom == 0) nl_launch_stiffness<0>(c, d);
   else if (n.mat.nlgeom == 1) nl_launch_stiffness<1>(c, d);
   else nl_launch_stiffness<2>(c, d);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(ke, d, (size_t)576 * n.n_elem * 8, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  dev_free(d);
   return 0;
 }
 extern "C" int fx_nl_element_update(fx_context *c, double *qf) {
   NL_READY("fx_nl_element_update");
   NlDev &n = c->nl;
+  DevScratch tmp;
   double *d = nullptr;
-  if (dev_alloc(&d, (size_t)24 * n.n_elem)) return FX_ERROR_RUNTIME;
+  if (tmp.alloc(&d, (size_t)24 * n.n_elem)) return FX_ERROR_RUNTIME;
   if (n.mat.nlgeom == 0) nl_launch_update<0>(c, d);
   else if (n.mat.nlgeom == 1) nl_launch_update<1>(c, d);
   else nl_launch_update<2>(c, d);
@@ -257,7 +258,6 @@ extern "C" int fx_nl_element_update(fx_context *c, double *qf) {
   if (n.mat.plastic) n.latch = 1;
   HIP_TRY(hipMemcpyAsync(qf, d, (size_t)24 * n.n_elem * 8, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  dev_free(d);
   return 0;
 }
 
