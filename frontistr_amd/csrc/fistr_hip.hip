@@ -183,6 +183,8 @@ extern "C" int fx_create(int device, fx_context **out) {
   if (const char *e = getenv("FX_PIPE_MAX_SLICES")) c->pipe_max_slices = atoi(e);
   if (const char *e = getenv("FX_SSOR_BS")) c->ssor_bs = (atoi(e) == 64) ? 64 : 256;
   if (const char *e = getenv("FX_SPMV_BS")) c->spmv_bs = (atoi(e) == 64) ? 64 : 256;
+  if (const char *e = getenv("FX_SPLIT_MAX_SLICES")) c->split_max_slices = atoi(e);
+  if (const char *e = getenv("FX_SPLIT_WPS")) c->split_wps = (atoi(e) == 2 || atoi(e) == 4 || atoi(e) == 8) ? atoi(e) : 0;
   *out = c;
   return 0;
 }
@@ -955,7 +957,10 @@ static int precond_apply_once(fx_context *c, const double *r, double *z, bool wa
     SsorDev &S = c->ssor;
     if (want_dot) {  // fused r.z partials need one slot per backward block; fall back to a separate dot otherwise
       int64_t tot = 0;
-      for (int col = 0; col < S.ncolor; col++) tot += (S.color_slice[col + 1] - S.color_slice[col]) / (c->ssor_bs / 64) + 1;
+      for (int col = 0; col < S.ncolor; col++) {
+        const int nsl = S.color_slice[col + 1] - S.color_slice[col];
+        tot += (nsl <= c->split_max_slices) ? nsl : nsl / (c->ssor_bs / 64) + 1;
+      }
       if (tot > c->max_partials) want_dot = false;
     }
     const bool full = (c->ord.kind == 1);  // Krylov vectors already colour-major: sweep in place on z
@@ -974,10 +979,24 @@ static int precond_apply_once(fx_context *c, const double *r, double *z, bool wa
       hipLaunchKernelGGL((k_ssor_color<FWD, false, B>), dim3(g), dim3(B), 0, c->stream, s0, s1, BL.pair_ptr, BL.val2, \
                          BL.col2, sn, S.alu, r, zsweep, znat, part, gate_status(c));                                  \
   } while (0)
+#define SPLIT_LAUNCH(FWD, s0, s1, part)                                                                                  \
+  do {                                                                                                                  \
+    const int wps = c->split_wps ? c->split_wps : (c->precond_kind == 10 ? 8 : 4);                                     \
+    if (wps == 2)                                                                                                       \
+      hipLaunchKernelGGL((k_ssor_color_split<FWD, 2>), dim3(s1 - s0), dim3(128), 0, c->stream, s0, s1, BL.pair_ptr, BL.val2, \
+                         BL.col2, sn, S.alu, r, zsweep, znat, part, gate_status(c));                                    \
+    else if (wps == 8)                                                                                                  \
+      hipLaunchKernelGGL((k_ssor_color_split<FWD, 8>), dim3(s1 - s0), dim3(512), 0, c->stream, s0, s1, BL.pair_ptr, BL.val2, \
+                         BL.col2, sn, S.alu, r, zsweep, znat, part, gate_status(c));                                    \
+    else                                                                                                                \
+      hipLaunchKernelGGL((k_ssor_color_split<FWD, 4>), dim3(s1 - s0), dim3(256), 0, c->stream, s0, s1, BL.pair_ptr, BL.val2, \
+                         BL.col2, sn, S.alu, r, zsweep, znat, part, gate_status(c));                                    \
+  } while (0)
     for (int col = 0; col < S.ncolor; col++) {
       const int s0 = S.color_slice[col], s1 = S.color_slice[col + 1];
       if (s1 <= s0) continue;
       const Bell &BL = S.L;
+      if (s1 - s0 <= c->split_max_slices) { SPLIT_LAUNCH(true, s0, s1, (double *)nullptr); continue; }
       const int g = (s1 - s0 + spb - 1) / spb;
       if (bs == 64) SSOR_LAUNCH(true, 64, g, s0, s1, (double *)nullptr);
       else SSOR_LAUNCH(true, 256, g, s0, s1, (double *)nullptr);
@@ -987,13 +1006,19 @@ static int precond_apply_once(fx_context *c, const double *r, double *z, bool wa
       const int s0 = S.color_slice[col], s1 = S.color_slice[col + 1];
       if (s1 <= s0) continue;
       const Bell &BL = S.U;
-      const int g = (s1 - s0 + spb - 1) / spb;
       double *part = want_dot ? c->partials + off : (double *)nullptr;
+      if (s1 - s0 <= c->split_max_slices) {
+        SPLIT_LAUNCH(false, s0, s1, part);
+        if (want_dot) off += s1 - s0;
+        continue;
+      }
+      const int g = (s1 - s0 + spb - 1) / spb;
       if (bs == 64) SSOR_LAUNCH(false, 64, g, s0, s1, part);
       else SSOR_LAUNCH(false, 256, g, s0, s1, part);
       if (want_dot) off += g;
     }
 #undef SSOR_LAUNCH
+#undef SPLIT_LAUNCH
     *nparts = off;
   } else {  // iterPREmax <= 0: Z = R (hecmw_precond.f90:89-94)
     hipLaunchKernelGGL(k_copy, dim3(grid_for(3 * (int64_t)N)), dim3(256), 0, c->stream, (int64_t)3 * N, r, z);

@@ -172,6 +172,13 @@ struct fx_context {
   int ssor_bs = 64;            // workgroup size of the colour sweeps: 64 (default) or 256. Measured 10M DOF: 1.78 -> 1.61 ms per apply
   int pipe_max_slices = 1 << 30;  // colours with more slices use the plain row loop (with 64-thread groups: pipelined everywhere wins, 1.61 vs 1.64/1.69 ms)
   int spmv_bs = 256;              // workgroup size of the SpMV (FX_SPMV_BS)
+  // Colours / ILU levels with at most this many slices run the wave-split sweep (k_ssor_color_split, split_wps waves
+  // per slice): latency-bound launches.  FX_SPLIT_MAX_SLICES (0 = off) / FX_SPLIT_WPS (2, 4, 8; 0 = auto) override.
+  // Measured at 10.1M DOF (same process): SSOR apply 1.46-1.49 -> 1.415 ms with 4 waves per slice on the 12 small
+  // colours (8 waves: 1.44; all colours split: 1.41); ILU(0) apply (1044 levels) 19.9 -> 13.9 ms with 4 and 11.9 ms
+  // with 8 waves per slice (BiCGSTAB + ILU(0) 24 -> 39 it/s).  Auto: 8 for ILU(0) levels, 4 for SSOR colours.
+  int split_max_slices = 2048;
+  int split_wps = 0;
   // software-pipelined row loop (2-deep: values + gathers of pair i+1 and ids of pair i+2 in flight while pair i
   // is multiplied; 116 VGPRs, 4 waves/SIMD).  Measured on MI355X at 10.1M DOF with the final layout (odd-tail BELL,
   // non-temporal stream loads): SpMV 1.14-1.17 -> 1.105-1.11 ms; colour sweeps 1.685 -> 1.61 ms per apply.

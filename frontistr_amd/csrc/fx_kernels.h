@@ -351,6 +351,101 @@ __global__ __launch_bounds__(BS) void k_ssor_color(int32_t slice0, int32_t slice
   if (!FWD && partials) block_sum_store<1, BS>(d, partials, 0, vb);
 }
 
+// Latency-bound colours and ILU(0) levels (a few dozen to a few thousand slices: less than two waves per SIMD, so a
+// wave's chain of dependent loads -- column ids -> gathered z -> next pair -- is the whole kernel time, 9.3 us per
+// level at 10M DOF).  WPS waves share one slice: wave w takes the block pairs w, w+WPS, ... (7 pairs for a hex-mesh
+// lower part => at most two per wave at WPS=4), issues every load of its pairs before the first use, and the partial
+// sums meet in LDS in a fixed order.  Same layout, same coalescing, 1/WPS of the dependent depth.
+__device__ __forceinline__ void bell_pair_fma(const double2 (&a)[9], const double (&xv)[6], double &s0, double &s1, double &s2) {
+  s0 += a[0].x * xv[0] + a[1].x * xv[1] + a[2].x * xv[2];
+  s1 += a[3].x * xv[0] + a[4].x * xv[1] + a[5].x * xv[2];
+  s2 += a[6].x * xv[0] + a[7].x * xv[1] + a[8].x * xv[2];
+  s0 += a[0].y * xv[3] + a[1].y * xv[4] + a[2].y * xv[5];
+  s1 += a[3].y * xv[3] + a[4].y * xv[4] + a[5].y * xv[5];
+  s2 += a[6].y * xv[3] + a[7].y * xv[4] + a[8].y * xv[5];
+}
+
+template <bool FWD, int WPS>
+__global__ __launch_bounds__(64 * WPS) void k_ssor_color_split(int32_t slice0, int32_t slice1,
+                                                               const int32_t *__restrict__ pair_ptr,
+                                                               const double *__restrict__ val2,
+                                                               const int *__restrict__ col2,
+                                                               const int32_t *__restrict__ slot_node,
+                                                               const double *__restrict__ alu,
+                                                               const double *__restrict__ r, double *__restrict__ zs,
+                                                               double *__restrict__ z, double *__restrict__ partials,
+                                                               const int32_t *__restrict__ gate) {
+  if (gate && *gate != 0) return;
+  __shared__ double part[WPS][3][64];
+  const int slice = slice0 + blockIdx.x;  // grid = slice1 - slice0
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int h0 = pair_ptr[slice], h1 = pair_ptr[slice + 1];
+  const int np = (h1 - h0) >> 1;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  const double2 *vbase = (const double2 *)(val2 + (size_t)h0 * 576) + lane;
+  const int2 *cbase = (const int2 *)(col2 + (size_t)h0 * 64) + lane;
+  int i = w;
+  for (; i + WPS < np; i += 2 * WPS) {  // two of this wave's pairs in flight together
+    const double2 *va = vbase + (size_t)i * 576, *vb = vbase + (size_t)(i + WPS) * 576;
+    const int2 ca = ld_stream(cbase + (size_t)i * 64), cb = ld_stream(cbase + (size_t)(i + WPS) * 64);
+    double2 a[9], b[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) a[e] = ld_stream(va + e * 64);
+#pragma unroll
+    for (int e = 0; e < 9; e++) b[e] = ld_stream(vb + e * 64);
+    const double *xa = zs + (size_t)3 * ca.x, *xb = zs + (size_t)3 * ca.y, *xc = zs + (size_t)3 * cb.x, *xd = zs + (size_t)3 * cb.y;
+    const double xva[6] = {xa[0], xa[1], xa[2], xb[0], xb[1], xb[2]};
+    const double xvb[6] = {xc[0], xc[1], xc[2], xd[0], xd[1], xd[2]};
+    bell_pair_fma(a, xva, s0, s1, s2);
+    bell_pair_fma(b, xvb, s0, s1, s2);
+  }
+  if (i < np) {
+    const double2 *va = vbase + (size_t)i * 576;
+    const int2 ca = ld_stream(cbase + (size_t)i * 64);
+    double2 a[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) a[e] = ld_stream(va + e * 64);
+    const double *xa = zs + (size_t)3 * ca.x, *xb = zs + (size_t)3 * ca.y;
+    const double xva[6] = {xa[0], xa[1], xa[2], xb[0], xb[1], xb[2]};
+    bell_pair_fma(a, xva, s0, s1, s2);
+  }
+  if (((h1 - h0) & 1) && w == (np % WPS))
+    bell_tail_block(val2 + (size_t)(h0 + 2 * np) * 576 + lane, col2 + (size_t)(h0 + 2 * np) * 64 + lane, zs, s0, s1, s2);
+  part[w][0][lane] = s0; part[w][1][lane] = s1; part[w][2][lane] = s2;
+  __syncthreads();
+  double d[1] = {0.0};
+  if (w == 0) {
+    s0 = part[0][0][lane]; s1 = part[0][1][lane]; s2 = part[0][2][lane];
+#pragma unroll
+    for (int k = 1; k < WPS; k++) { s0 += part[k][0][lane]; s1 += part[k][1][lane]; s2 += part[k][2][lane]; }
+    const int slot = slice * 64 + lane;
+    const int node = slot_node ? slot_node[slot] : slot;
+    if (node >= 0) {
+      double u[9];
+      const size_t base = (size_t)slice * 576 + lane;
+#pragma unroll
+      for (int e = 0; e < 9; e++) u[e] = alu[base + (size_t)e * 64];
+      double *zi = zs + (size_t)3 * slot;
+      const double *ri = r + (size_t)3 * node;
+      if (FWD) {
+        double x1 = ri[0] - s0, x2 = ri[1] - s1, x3 = ri[2] - s2;
+        lusolve33_dev(u, x1, x2, x3);
+        zi[0] = x1; zi[1] = x2; zi[2] = x3;
+      } else {
+        lusolve33_dev(u, s0, s1, s2);
+        const double x1 = zi[0] - s0, x2 = zi[1] - s1, x3 = zi[2] - s2;
+        zi[0] = x1; zi[1] = x2; zi[2] = x3;
+        if (z) {
+          double *zn = z + (size_t)3 * node;
+          zn[0] = x1; zn[1] = x2; zn[2] = x3;
+        }
+        if (partials) d[0] = ri[0] * x1 + ri[1] * x2 + ri[2] * x3;
+      }
+    }
+  }
+  if (!FWD && partials) block_sum_store<1, 64 * WPS>(d, partials, 0, blockIdx.x);
+}
+
 // ------------------------------------------------------------------------
 // K9: block ILU(0) (hecmw_precond_BILU_33.f90).  The reference factorises and substitutes
 // strictly sequentially (FORM_ILU0_33 :185-362, apply :90-157).  Here rows are grouped into
