@@ -837,6 +837,8 @@ static int ilu_setup_symbolic(fx_context *c) {
     if (slot_row[sl] >= 0) slot_of[slot_row[sl]] = sl;
   S.ncolor = nlev;
   S.color_slice.assign((size_t)nlev + 1, 0);
+  S.max_row_blocks = 0;
+  for (int32_t i = 0; i < N; i++) S.max_row_blocks = std::max(S.max_row_blocks, (iL[i + 1] - iL[i]) + (c->h_indexU[i + 1] - c->h_indexU[i]));
   S.slot_start.assign((size_t)nlev + 1, 0);
   for (int32_t l = 1; l <= nlev; l++) { S.color_slice[l] = start[l + 1] / 64; S.slot_start[l] = start[l + 1]; }
   S.nslots = nslots;
@@ -882,8 +884,12 @@ static int ilu_setup_numeric(fx_context *c, double sigma_diag) {
   for (int32_t l = 1; l <= S.ncolor; l++) {
     const int32_t s0 = S.slot_start[l - 1], s1 = S.slot_start[l];
     if (l == 1 || s1 <= s0) continue;  // level 1 rows have no lower blocks
-    hipLaunchKernelGGL(k_ilu0_factor_level, dim3((s1 - s0 + 127) / 128), dim3(128), 0, c->stream, s0, s1, S.slot_node, A.N,
-                       A.indexL, A.itemL, A.indexU, A.itemU, S.lu_D, S.lu_AL, S.lu_AU);
+    if (S.max_row_blocks <= 32)        // 32 lanes per row, one destination block each
+      hipLaunchKernelGGL(k_ilu0_factor_level32, dim3((s1 - s0 + 7) / 8), dim3(256), 0, c->stream, s0, s1, S.slot_node, A.N,
+                         A.indexL, A.itemL, A.indexU, A.itemU, S.lu_D, S.lu_AL, S.lu_AU);
+    else
+      hipLaunchKernelGGL(k_ilu0_factor_level, dim3((s1 - s0 + 127) / 128), dim3(128), 0, c->stream, s0, s1, S.slot_node, A.N,
+                         A.indexL, A.itemL, A.indexU, A.itemU, S.lu_D, S.lu_AL, S.lu_AU);
   }
   HIP_TRY(hipGetLastError());
   if (bell_fill_values(c, S.L, S.lu_D, S.lu_AL, S.lu_AU) || bell_fill_values(c, S.U, S.lu_D, S.lu_AL, S.lu_AU)) return FX_ERROR_RUNTIME;

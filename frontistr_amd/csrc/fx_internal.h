@@ -87,6 +87,7 @@ struct SsorDev {
   double *zs = nullptr;              // private sweep vector, 3*nslots, colour-major
   double *lu_D = nullptr, *lu_AL = nullptr, *lu_AU = nullptr;  // ILU(0): factor values in the reference CSR layout
   std::vector<int32_t> slot_start;   // ILU(0): first slot of each level (ncolor+1)
+  int32_t max_row_blocks = 0;        // ILU(0): largest number of off-diagonal blocks in a row (<= 32: lane-per-block factorisation)
   std::vector<int32_t> perm;         // new -> old (1-based), as the reference's perm(:)
   std::vector<int32_t> colorindex;   // COLORindex(0:ncolor)
 };
