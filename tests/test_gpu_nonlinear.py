@@ -197,3 +197,21 @@ def test_nonlinear_api_errors(hip):
     with pytest.raises(HecmwSolverError):                       # BC node out of range
         fstr.fstr_StiffMatrix(solid, (np.array([m.n_node + 1], dtype=np.int32), np.array([1], dtype=np.int32), np.zeros(1)))
     ctx.close()
+
+
+def test_plastic_cylinder_tutorial_vs_reference_golden(hip):
+    """configs[4]'s deck itself: tutorial/05_plastic_cylinder (necking.msh, multilinear Mises, updated Lagrange,
+    CG + SSOR 1e-8, CONVERG 1e-3), first 3 of its 40 substeps, against the run of the reference routines."""
+    from frontistr_amd import fstr
+    T = _T()
+    g, mat, bc, nsub, max_iter, converg, I, R = T.necking_case()
+
+    class M:
+        coord, conn, n_node = g["coord"], g["conn"], g["coord"].shape[0]
+    ctx, hecMAT, solid = _solid(hip, mat, M)
+    hecMAT.Iarray[:] = I
+    hecMAT.Rarray[:] = R
+    log = fstr.fstr_solve_NLGEOM(solid, hecMAT, bc, None, nsub, max_iter, converg)
+    _check_steps(log, solid.get_state(), g, True)
+    assert log.shape[0] == 46
+    ctx.close()

@@ -333,3 +333,33 @@ def test_gmres_gpbicg_larger_cube_vs_oracle(hip, oracle, meth, pc):
     assert abs(ctx.info.iterations - o["iter"]) <= max(2, (0.02 if meth == 3 else 0.15) * o["iter"])
     assert relerr(m.X, o["X"]) < 1e-7
     ctx.close()
+
+
+@pytest.mark.parametrize("meth,pc", [(1, 1), (1, 3), (2, 10), (3, 1), (4, 3)])
+def test_unstructured_hex_mesh_vs_oracle(hip, oracle, meth, pc):
+    """The mesher-made hex mesh of tutorial/05_plastic_cylinder (rows of 8..27 blocks, nothing cube-like) as a
+    linear-elastic deck: device assembly (IC element) + solve against the oracle."""
+    import os
+    from oracle.refrun import default_params
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "nl_necking.npz"))
+    coord, conn = g["coord"], g["conn"]
+    bc = (g["bc_node"], g["bc_dof"], g["bc_val"] * 0.01)
+    A = oracle.assemble(1, coord, conn, 206900.0, 0.29, bc=bc, load=np.zeros(3 * coord.shape[0]))
+    I, R = default_params(method=meth, precond=pc)
+    o = oracle.solve_iterative(A, I, R, nthreads=4)
+    hm = hip.hecmwST_local_mesh(n_node=coord.shape[0])
+    hm.elem_node_item = conn.ravel()
+    m = hip.hecmw_mat_con(hm, hip.hecmwST_matrix())
+    assert np.array_equal(m.indexL, A.indexL) and np.array_equal(m.itemU, A.itemU)
+    ctx = hip.SolverContext()
+    ctx.upload(m, what=hip.FX_UP_PROFILE)
+    ctx.assemble_c3d8(coord, conn, 206900.0, 0.29, elemopt=1, load=np.zeros(3 * coord.shape[0]), bc=bc)
+    m.Iarray[0] = 10000; m.Iarray[1] = meth; m.Iarray[2] = pc
+    assert ctx.solve_resident(m) == 0 and o["code"] == 0
+    ctx.download_x(m)
+    k = min(10, len(ctx.history), len(o["history"]))
+    assert np.all(np.abs(ctx.history[:k] - o["history"][:k]) <= 1e-9 * o["history"][:k])
+    tol_it = {1: 1, 2: 0.15 * o["iter"], 3: max(2, 0.02 * o["iter"]), 4: 0.15 * o["iter"]}[meth]
+    assert abs(ctx.info.iterations - o["iter"]) <= max(2, tol_it)
+    assert relerr(m.X, o["X"]) < 1e-7
+    ctx.close()

@@ -115,3 +115,21 @@ def test_load_steps_vs_golden(name):
     check_steps(model, log, g)
     if mat.plastic:
         assert g["plstrain"].max() > 1e-3
+
+
+def necking_case():
+    """The reference's own deck tutorial/05_plastic_cylinder (mesh + control data in the fixture)."""
+    g = np.load(os.path.join(GOLD, "nl_necking.npz"))
+    mat = refrun.Material(206900.0, 0.29, plastic=True, harden=1, table=g["table"], nlgeom=2)
+    nsub, frac = int(g["nsub"]), float(g["nsub"]) / float(g["nsub_total"])
+    bc = (g["bc_node"], g["bc_dof"], g["bc_val"] * frac)
+    I, R = refrun.default_params(method=1, precond=1, maxit=2000, tol=1e-8, iterlog=0, timelog=0)
+    return g, mat, bc, nsub, int(g["max_iter"]), float(g["converg"]), I, R
+
+
+def test_plastic_cylinder_tutorial_vs_golden():
+    g, mat, bc, nsub, max_iter, converg, I, R = necking_case()
+    model = pyoracle.NonlinearModel(mat, g["coord"], g["conn"])
+    log = model.run_steps(*bc, np.zeros(3 * g["coord"].shape[0]), nsub, max_iter, converg, I, R, nthreads=2)
+    check_steps(model, log, g)
+    assert log.shape[0] == 46 and int(g["istat"].sum()) == g["istat"].size      # 36 + 5 + 5 Newton iterations, fully plastic
