@@ -177,7 +177,7 @@ struct fx_context {
   // per slice): latency-bound launches.  FX_SPLIT_MAX_SLICES (0 = off) / FX_SPLIT_WPS (2, 4, 8; 0 = auto) override.
   // Measured at 10.1M DOF (same process): SSOR apply 1.46-1.49 -> 1.415 ms with 4 waves per slice on the 12 small
   // colours (8 waves: 1.44; all colours split: 1.41); ILU(0) apply (1044 levels) 19.9 -> 13.9 ms with 4 and 11.9 ms
-  // with 8 waves per slice (BiCGSTAB + ILU(0) 24 -> 39 it/s).  Auto: 8 for ILU(0) levels, 4 for SSOR colours.
+  // with 8 waves per slice, 10.7 ms with the diagonal factor prefetched (BiCGSTAB + ILU(0) 24 -> 43 it/s).  Auto: 8 for ILU(0) levels, 4 for SSOR colours.
   int split_max_slices = 2048;
   int split_wps = 0;
   // software-pipelined row loop (2-deep: values + gathers of pair i+1 and ids of pair i+2 in flight while pair i

@@ -381,6 +381,21 @@ __global__ __launch_bounds__(64 * WPS) void k_ssor_color_split(int32_t slice0, i
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int h0 = pair_ptr[slice], h1 = pair_ptr[slice + 1];
   const int np = (h1 - h0) >> 1;
+  // the finishing wave fetches its diagonal factor and right-hand side up front: they do not depend on the sweep,
+  // so their latency overlaps the block pairs instead of following the LDS exchange
+  const int slot = slice * 64 + lane;
+  int node = -1;
+  double u[9], ri0 = 0.0, ri1 = 0.0, ri2 = 0.0, zo0 = 0.0, zo1 = 0.0, zo2 = 0.0;
+  if (w == 0) {
+    node = slot_node ? slot_node[slot] : slot;
+    const size_t base = (size_t)slice * 576 + lane;
+#pragma unroll
+    for (int e = 0; e < 9; e++) u[e] = alu[base + (size_t)e * 64];
+    if (node >= 0) {
+      if (FWD || partials) { ri0 = r[(size_t)3 * node]; ri1 = r[(size_t)3 * node + 1]; ri2 = r[(size_t)3 * node + 2]; }
+      if (!FWD) { zo0 = zs[(size_t)3 * slot]; zo1 = zs[(size_t)3 * slot + 1]; zo2 = zs[(size_t)3 * slot + 2]; }
+    }
+  }
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
   const double2 *vbase = (const double2 *)(val2 + (size_t)h0 * 576) + lane;
   const int2 *cbase = (const int2 *)(col2 + (size_t)h0 * 64) + lane;
@@ -418,28 +433,21 @@ __global__ __launch_bounds__(64 * WPS) void k_ssor_color_split(int32_t slice0, i
     s0 = part[0][0][lane]; s1 = part[0][1][lane]; s2 = part[0][2][lane];
 #pragma unroll
     for (int k = 1; k < WPS; k++) { s0 += part[k][0][lane]; s1 += part[k][1][lane]; s2 += part[k][2][lane]; }
-    const int slot = slice * 64 + lane;
-    const int node = slot_node ? slot_node[slot] : slot;
     if (node >= 0) {
-      double u[9];
-      const size_t base = (size_t)slice * 576 + lane;
-#pragma unroll
-      for (int e = 0; e < 9; e++) u[e] = alu[base + (size_t)e * 64];
       double *zi = zs + (size_t)3 * slot;
-      const double *ri = r + (size_t)3 * node;
       if (FWD) {
-        double x1 = ri[0] - s0, x2 = ri[1] - s1, x3 = ri[2] - s2;
+        double x1 = ri0 - s0, x2 = ri1 - s1, x3 = ri2 - s2;
         lusolve33_dev(u, x1, x2, x3);
         zi[0] = x1; zi[1] = x2; zi[2] = x3;
       } else {
         lusolve33_dev(u, s0, s1, s2);
-        const double x1 = zi[0] - s0, x2 = zi[1] - s1, x3 = zi[2] - s2;
+        const double x1 = zo0 - s0, x2 = zo1 - s1, x3 = zo2 - s2;
         zi[0] = x1; zi[1] = x2; zi[2] = x3;
         if (z) {
           double *zn = z + (size_t)3 * node;
           zn[0] = x1; zn[1] = x2; zn[2] = x3;
         }
-        if (partials) d[0] = ri[0] * x1 + ri[1] * x2 + ri[2] * x3;
+        if (partials) d[0] = ri0 * x1 + ri1 * x2 + ri2 * x3;
       }
     }
   }
