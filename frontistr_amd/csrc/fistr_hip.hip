@@ -88,6 +88,22 @@ static int rccl_load() {
     }                                                                        \
   } while (0)
 
+struct PhaseTimer {  // FX_TIMING=1: wall time of the host-side set-up phases on stderr
+  double t0;
+  bool on;
+  const char *what;
+  explicit PhaseTimer(const char *w);
+  void lap(const char *phase);
+};
+static double now_s();
+PhaseTimer::PhaseTimer(const char *w) : t0(now_s()), on(getenv("FX_TIMING") && atoi(getenv("FX_TIMING")) != 0), what(w) {}
+void PhaseTimer::lap(const char *phase) {
+  if (!on) return;
+  const double t = now_s();
+  fprintf(stderr, "[fx timing] %s / %s: %.3f s\n", what, phase, t - t0);
+  t0 = t;
+}
+
 static double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -715,10 +731,14 @@ static int ssor_setup_symbolic(fx_context *c, int ncolor_in) {
   const int32_t N = c->A.N;
   SsorDev &S = c->ssor;
   const int32_t *iL = c->h_indexL.data(), *jL = c->h_itemL.data(), *iU = c->h_indexU.data(), *jU = c->h_itemU.data();
+  PhaseTimer pt("ssor symbolic");
   fxo::Graph g = fxo::build_graph(N, iL, jL, iU, jU);
+  pt.lap("graph");
   std::vector<int32_t> seq = fxo::rcm_sequence(g);
+  pt.lap("level ordering");
   std::vector<int32_t> perm0, cidx;
   fxo::multicolor(g, seq, ncolor_in, perm0, cidx);
+  pt.lap("multicolour");
   S.ncolor = (int32_t)cidx.size() - 1;
   S.colorindex = cidx;
   S.perm.resize(N);
@@ -748,6 +768,7 @@ static int ssor_setup_symbolic(fx_context *c, int ncolor_in) {
     S.color_slice.push_back((int32_t)(slot_row.size() / 64));
   }
   const int32_t nslots = (int32_t)slot_row.size();
+  pt.lap("slot order");
   // node -> slot of the sweep's private colour-major vector
   std::vector<int32_t> slot_of((size_t)N, 0);
   for (int32_t sl = 0; sl < nslots; sl++)
@@ -763,6 +784,7 @@ static int ssor_setup_symbolic(fx_context *c, int ncolor_in) {
   } else if (c->ord.kind != 0) {
     if (set_ordering(c, 0, nullptr)) return FX_ERROR_RUNTIME;
   }
+  pt.lap("solver ordering + full-matrix layout");
   // lower / upper parts per slot, entries ordered by the reference's new index (ascending for the
   // forward sweep, descending for the backward sweep, as SSOR_33.f90:312 / :369 walk them)
   auto collect = [&](int32_t slot, std::vector<BellEntry> &e, bool lower) {
@@ -792,7 +814,9 @@ static int ssor_setup_symbolic(fx_context *c, int ncolor_in) {
   auto fillL = [&](int32_t slot, std::vector<BellEntry> &e) { collect(slot, e, true); };
   auto fillU = [&](int32_t slot, std::vector<BellEntry> &e) { collect(slot, e, false); };
   if (bell_build2(c, S.L, nslots, &slot_row, countL, fillL)) return FX_ERROR_RUNTIME;
+  pt.lap("lower layout");
   if (bell_build2(c, S.U, nslots, &slot_row, countU, fillU)) return FX_ERROR_RUNTIME;
+  pt.lap("upper layout");
   dev_free(S.alu);
   if (dev_alloc(&S.alu, (size_t)(nslots / 64) * 576)) return FX_ERROR_RUNTIME;
   return 0;
@@ -816,6 +840,7 @@ static int ilu_setup_symbolic(fx_context *c) {
   const int32_t N = c->A.N;
   SsorDev &S = c->ssor;
   const int32_t *iL = c->h_indexL.data(), *jL = c->h_itemL.data(), *iU = c->h_indexU.data(), *jU = c->h_itemU.data();
+  PhaseTimer pt("ilu symbolic");
   std::vector<int32_t> level((size_t)N, 0);
   int32_t nlev = 0;
   for (int32_t i = 0; i < N; i++) {  // rows in natural order: every k in L(i) is < i
@@ -866,7 +891,9 @@ static int ilu_setup_symbolic(fx_context *c) {
       if (jU[j] <= N) e.push_back({3 * j + 2, so[jU[j] - 1]});
   };
   if (bell_build2(c, S.L, nslots, &slot_row, countL, fillL)) return FX_ERROR_RUNTIME;
+  pt.lap("lower layout");
   if (bell_build2(c, S.U, nslots, &slot_row, countU, fillU)) return FX_ERROR_RUNTIME;
+  pt.lap("upper layout");
   dev_free(S.alu);
   if (dev_alloc(&S.alu, (size_t)(nslots / 64) * 576)) return FX_ERROR_RUNTIME;
   return 0;
