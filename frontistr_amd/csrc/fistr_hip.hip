@@ -1348,6 +1348,8 @@ extern "C" int fx_solve_resident(fx_context *c, int32_t *Iarray, double *Rarray,
   const double t_setup = now_s() - t0;
   KrylovState s;
   memset(&s, 0, sizeof s);
+  const bool auto_sigma = Rarray[1] < 0.0;  // hecmw_solver_Iterative.f90:68-73
+  double sigma = auto_sigma ? 1.0 : Rarray[1];
   double t1 = now_s();
   for (;;) {
     Iarray[80] = 0; Iarray[81] = 0;
@@ -1369,7 +1371,26 @@ extern "C" int fx_solve_resident(fx_context *c, int32_t *Iarray, double *Rarray,
     if (e) return e;
     if (s.status == FX_ERROR_DIVERGE_PC || s.status == FX_ERROR_DIVERGE_MAT) {  // :145-156
       Iarray[81] = 1;
-      if (method == 1 && method2 > 1) { method = method2; continue; }
+      // a retry continues from the X the failed attempt left behind (hecMAT%X is not reset), halo included
+      if (halo_update(c, c->Xs) || from_slots(c, c->Xs, c->A.X)) return FX_ERROR_RUNTIME;
+      if (precond >= 10 && precond < 20 && auto_sigma && sigma < 2.0) {  // 'Increasing SIGMA_DIAG' retry of the ILU family
+        sigma += 0.1;
+        double R2[100];
+        memcpy(R2, Rarray, sizeof R2);
+        R2[1] = sigma;
+        if (int pe = fx_precond_setup(c, Iarray, R2)) return pe;
+        continue;
+      } else if (method == 1 && method2 > 1) {
+        if (auto_sigma && sigma != 1.0) {  // :152 SIGMA_DIAG back to 1 for the second method
+          sigma = 1.0;
+          double R2[100];
+          memcpy(R2, Rarray, sizeof R2);
+          R2[1] = sigma;
+          if (int pe = fx_precond_setup(c, Iarray, R2)) return pe;
+        }
+        method = method2;
+        continue;
+      }
     }
     break;
   }

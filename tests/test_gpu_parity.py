@@ -363,3 +363,27 @@ def test_unstructured_hex_mesh_vs_oracle(hip, oracle, meth, pc):
     assert abs(ctx.info.iterations - o["iter"]) <= max(2, tol_it)
     assert relerr(m.X, o["X"]) < 1e-7
     ctx.close()
+
+
+@pytest.mark.parametrize("sigma,method2", [(1.0, 0), (1.0, 2), (-1.0, 0), (-1.0, 2)])
+def test_divergence_retry_policy(hip, oracle, sigma, method2):
+    """hecmw_solver_Iterative.f90:145-156 on an indefinite matrix (one diagonal block negated): CG stops with
+    W-3002; SIGMA_DIAG < 0 ('auto') retries the ILU family with SIGMA_DIAG + 0.1 up to 2.0; METHOD2 then takes over
+    with SIGMA_DIAG back at 1.  Flags, codes and iteration counts as the oracle (bit-exact with the reference here)."""
+    from oracle.refrun import default_params
+    A = golden_matrix(load_golden("cube4"))
+    A.D = A.D.copy(); A.D[9 * 40:9 * 41] *= -1.0
+    I, R = default_params(method=1, precond=10, maxit=500)
+    R[1] = sigma; I[7] = method2
+    o = oracle.solve_iterative(A, I, R)
+    m = to_hecmat(hip, A)
+    m.Iarray[:] = I; m.Rarray[:] = R
+    ctx = hip.SolverContext()
+    code = hip.hecmw_solve(None, m, ctx=ctx)
+    assert code == o["code"]
+    # the CG break-off is deterministic (+-1); the BiCGSTAB take-over on this indefinite system is rounding sensitive
+    assert abs(ctx.info.iterations - o["iter"]) <= (1 if code else max(2, 0.3 * o["iter"]))
+    assert m.Iarray[80] == o["Iarray"][80] and m.Iarray[81] == o["Iarray"][81]
+    if code == 0:
+        assert relerr(m.X, o["X"]) < 1e-7
+    ctx.close()
