@@ -324,13 +324,14 @@ class NonlinearModel:
         cs = cstate(self.state)
         lib().orc_nl_commit(C.byref(self.cm), self.ne, C.byref(cs))
 
-    def run_steps(self, bc_node, bc_dof, bc_val, cload, nsub, max_iter, converg, I, R, nthreads=2):
-        """fstr_solve_NLGEOM.f90:100-121 + fstr_Newton (fstr_solve_NonLinear.f90:29-167)."""
+    def run_steps(self, bc_node, bc_dof, bc_val, cload, nsub, max_iter, converg, I, R, nthreads=2, factors=None):
+        """fstr_solve_NLGEOM.f90:100-121 + fstr_Newton (fstr_solve_NonLinear.f90:29-167).  factors: (FACTOR(1),
+        FACTOR(2)) of a single substep instead of the linear ramp over nsub substeps."""
         log = []
         I = np.ascontiguousarray(I, dtype=np.int32).copy()
         bc_idx = 3 * (np.asarray(bc_node, dtype=np.int64) - 1) + np.asarray(bc_dof, dtype=np.int64) - 1
         for sub in range(1, nsub + 1):
-            f1, f2 = (sub - 1) / nsub, sub / nsub
+            f1, f2 = ((sub - 1) / nsub, sub / nsub) if factors is None else factors
             self.dunode[:] = 0.0
             GL = cload * f2
             self.m.B[:] = GL - self.qforce

@@ -215,3 +215,26 @@ def test_plastic_cylinder_tutorial_vs_reference_golden(hip):
     _check_steps(log, solid.get_state(), g, True)
     assert log.shape[0] == 46
     ctx.close()
+
+
+def test_exI_known_answer_on_gpu(hip):
+    """examples/static/exI (NLGEOM, elastic, 10 substeps): the reference's A361_correct.log displacement extrema of
+    every step at the reference harness' 1e-4 tolerance, through the library."""
+    from frontistr_amd import fstr
+    T = _T()
+    d, e, mat, bc, I, R = T.exI_case()
+
+    class M:
+        coord, conn, n_node = d["coord"], d["conn"], d["coord"].shape[0]
+    ctx, hecMAT, solid = _solid(hip, mat, M)
+    hecMAT.Iarray[:] = I
+    hecMAT.Rarray[:] = R
+    nsub = int(e["substeps"])
+    unodes = []
+    for sub in range(1, nsub + 1):
+        ok, log = fstr.fstr_Newton(solid, hecMAT, ((sub - 1) / nsub, sub / nsub), bc, d["load"], int(e["max_iter"]),
+                                   float(e["converg"]))
+        assert ok
+        unodes.append(solid.get_state(("unode",))["unode"])
+    T.check_exI_extrema(unodes, e)
+    ctx.close()

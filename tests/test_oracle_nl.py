@@ -133,3 +133,35 @@ def test_plastic_cylinder_tutorial_vs_golden():
     log = model.run_steps(*bc, np.zeros(3 * g["coord"].shape[0]), nsub, max_iter, converg, I, R, nthreads=2)
     check_steps(model, log, g)
     assert log.shape[0] == 46 and int(g["istat"].sum()) == g["istat"].size      # 36 + 5 + 5 Newton iterations, fully plastic
+
+
+def exI_case():
+    """examples/static/exI: exA's A361 mesh under I300.cnt (NLGEOM, elastic, 10 substeps, CG + DIAG 1e-8)."""
+    from conftest import load_golden
+    d, e = load_golden("exA_A361"), np.load(os.path.join(GOLD, "exI_A361_expect.npz"))
+    mat = refrun.Material(float(e["E"]), float(e["nu"]), plastic=False, nlgeom=1)     # elastic under NLGEOM: TOTALLAG
+    bc = (d["bc_node"], d["bc_dof"], d["bc_val"])
+    I, R = refrun.default_params(method=1, precond=3, maxit=10000, tol=1e-8, iterlog=0, timelog=0)
+    return d, e, mat, bc, I, R
+
+
+def check_exI_extrema(unodes, e):
+    for s, u in enumerate(unodes):
+        U = u.reshape(-1, 3)
+        for c in range(3):
+            mx, mn = e["extrema"][s, c]
+            assert abs(U[:, c].max() - mx) <= 1e-4 and abs(U[:, c].min() - mn) <= 1e-4, (s + 1, c)   # test_FrontISTR.rb:10
+
+
+def test_exI_known_answer():
+    """The reference's own known answer for the geometrically nonlinear path: displacement extrema of all 10 steps of
+    exI/A361_correct.log at the reference harness' tolerance."""
+    d, e, mat, bc, I, R = exI_case()
+    model = pyoracle.NonlinearModel(mat, d["coord"], d["conn"])
+    nsub = int(e["substeps"])
+    unodes = []
+    for sub in range(1, nsub + 1):          # run_steps one substep at a time to look at every step
+        model.run_steps(bc[0], bc[1], bc[2], d["load"], 1, int(e["max_iter"]), float(e["converg"]), I, R, nthreads=1,
+                        factors=((sub - 1) / nsub, sub / nsub))
+        unodes.append(model.unode.copy())
+    check_exI_extrema(unodes, e)
