@@ -254,7 +254,7 @@ def build_partitioner(jobs):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--jobs", type=int, default=4)
-    ap.add_argument("--only", choices=["solve", "fem", "nl", "shim", "part"], default=None)
+    ap.add_argument("--only", choices=["solve", "fem", "nl", "load", "shim", "part"], default=None)
     a = ap.parse_args()
     if not os.path.isdir(REF):
         print(f"reference not present at {REF}; oracle/_ref left as is")
@@ -276,6 +276,10 @@ def main():
     nl = os.path.join(HERE, "ref_nl_driver.f90")
     if a.only in (None, "nl") and os.path.exists(nl):
         build_variant("omp", [nl], True, a.jobs, provides, uses, exe_name="ref_nl")
+    # Distributed-load vectors of the example decks exB..exE (fixture input, see ref_load_driver.f90)
+    ld = os.path.join(HERE, "ref_load_driver.f90")
+    if a.only in (None, "load") and os.path.exists(ld):
+        build_variant("fem", [ld], False, a.jobs, provides, uses, exe_name="ref_load")
     # The reference partitioner (hecmw1/tools/partitioner, plain C): fixture generator for the
     # HECMW-DIST reader and the multi-rank tests (METHOD=RCB; METIS is absent in this image).
     if a.only in (None, "part"):

@@ -387,3 +387,22 @@ def test_divergence_retry_policy(hip, oracle, sigma, method2):
     if code == 0:
         assert relerr(m.X, o["X"]) < 1e-7
     ctx.close()
+
+
+@pytest.mark.parametrize("deck", ["exB_361", "exC_361", "exD_361", "exE_361"])
+def test_example_decks_known_answers_on_gpu(hip, deck):
+    """The reference's examples exB..exE (known answers of X361_correct.log): device assembly + BC + CG/DIAG."""
+    from test_oracle_golden import check_extrema
+    g = load_golden(deck)
+    hm = hip.hecmwST_local_mesh(n_node=g["coord"].shape[0])
+    hm.elem_node_item = g["conn"].ravel()
+    m = hip.hecmw_mat_con(hm, hip.hecmwST_matrix())
+    ctx = hip.SolverContext()
+    ctx.upload(m, what=hip.FX_UP_PROFILE)
+    ctx.assemble_c3d8(g["coord"], g["conn"], float(g["E"]), float(g["nu"]), elemopt=1, load=g["load"],
+                      bc=(g["bc_node"], g["bc_dof"], g["bc_val"]))
+    m.Iarray[0] = 10000; m.Iarray[1] = 1; m.Iarray[2] = 3
+    assert ctx.solve_resident(m) == 0
+    ctx.download_x(m)
+    check_extrema(m.X, g["expect"])
+    ctx.close()

@@ -116,3 +116,31 @@ def test_multicolor_ordering_properties(oracle):
     for i in range(1, A.N + 1):                          # colours are independent sets
         nb = np.concatenate([A.itemL[A.indexL[i - 1]:A.indexL[i]], A.itemU[A.indexU[i - 1]:A.indexU[i]]])
         assert not np.any(color[nb] == color[i])
+
+
+EX_DECKS = ["exB_361", "exC_361", "exD_361", "exE_361"]
+
+
+def check_extrema(X, expect):
+    U = X.reshape(-1, 3)
+    for c in range(3):
+        mx, mn = expect[c]
+        assert abs(U[:, c].max() - mx) <= 1e-4 and abs(U[:, c].min() - mn) <= 1e-4, c      # examples/test_FrontISTR.rb:10
+        # ... and to the 5 digits the log prints (the harness' absolute 1e-4 says little about 1e-5-sized fields)
+        scale = max(abs(mx), abs(mn))
+        assert abs(U[:, c].max() - mx) <= 1e-4 * scale and abs(U[:, c].min() - mn) <= 1e-4 * scale, c
+
+
+@pytest.mark.parametrize("deck", EX_DECKS)
+def test_example_decks_known_answers(oracle, deck):
+    """examples/static/exB..exE (pressure, body force, gravity, centrifugal load on the TYPE=361 beam): assembly (IC
+    element) + Dirichlet BC + CG/DIAG of the restatement reproduce the displacement extrema of X361_correct.log.  The
+    load vector is fixture input computed by the reference's own DL_C3 (make_exBCDE_golden.py)."""
+    from oracle.refrun import default_params
+    g = load_golden(deck)
+    A = oracle.assemble(1, g["coord"], g["conn"], float(g["E"]), float(g["nu"]),
+                        bc=(g["bc_node"], g["bc_dof"], g["bc_val"]), load=g["load"])
+    I, R = default_params(method=1, precond=3)
+    o = oracle.solve_iterative(A, I, R)
+    assert o["code"] == 0
+    check_extrema(o["X"], g["expect"])
