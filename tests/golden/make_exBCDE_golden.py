@@ -22,6 +22,8 @@ DECKS = [
     ("exC_361", "exC/C361.msh", "exC/C361_correct.log", [("ALL", 3, [7.85e-6, 0, 0, 0, 0, 0, 0])]),                  # ALL, BZ, 7.85E-6
     ("exD_361", "exD/D361.msh", "exD/D361_correct.log", [("ALL", 4, [9800.0, 0.0, 0.0, -1.0, 0, 0, 0])]),            # ALL, GRAV, 9800, 0,0,-1
     ("exE_361", "exE/E361.msh", "exE/E361_correct.log", [("ALL", 5, [6283.1852, 0.0, 0.5, 0.5, 0.0, 0.5, 1.0])]),    # ALL, CENT, ...
+    # F300.cnt: !REFTEMP 20 ; !TEMPERATURE ALL, 120 ; expansion 1e-5 (ITEM=3 of the mesh material): thermal load of the IC element
+    ("exF_361", "exF/F361.msh", "exF/F361_correct.log", [("ALL", -1, [120.0, 20.0, None, None, None, 20.0, 0])]),
 ]
 
 
@@ -96,6 +98,9 @@ for name, msh, log, dloads in DECKS:
     fix = ngrp["FIX"]
     bc_node = np.repeat(fix, 3).astype(np.int32)
     bc_dof = np.tile(np.array([1, 2, 3], dtype=np.int32), fix.size)
+    alpha = mat[2][0] if len(mat) > 2 else 0.0
+    dloads = [(g_, lt, [alpha if k == 2 and v is None else E if k == 3 and v is None else nu if k == 4 and v is None else v
+                        for k, v in enumerate(p)]) for g_, lt, p in dloads]
     load = ref_load(coord, conn, [(lt, p, rho, egrp[g]) for g, lt, p in dloads])
     expect = parse_log(os.path.join(ROOT, log))
     np.savez_compressed(os.path.join(HERE, name + ".npz"), coord=coord, conn=conn, bc_node=bc_node, bc_dof=bc_dof,

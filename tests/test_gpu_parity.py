@@ -389,7 +389,7 @@ def test_divergence_retry_policy(hip, oracle, sigma, method2):
     ctx.close()
 
 
-@pytest.mark.parametrize("deck", ["exB_361", "exC_361", "exD_361", "exE_361"])
+@pytest.mark.parametrize("deck", ["exB_361", "exC_361", "exD_361", "exE_361", "exF_361"])
 def test_example_decks_known_answers_on_gpu(hip, deck):
     """The reference's examples exB..exE (known answers of X361_correct.log): device assembly + BC + CG/DIAG."""
     from test_oracle_golden import check_extrema

@@ -118,7 +118,7 @@ def test_multicolor_ordering_properties(oracle):
         assert not np.any(color[nb] == color[i])
 
 
-EX_DECKS = ["exB_361", "exC_361", "exD_361", "exE_361"]
+EX_DECKS = ["exB_361", "exC_361", "exD_361", "exE_361", "exF_361"]
 
 
 def check_extrema(X, expect):
@@ -133,7 +133,7 @@ def check_extrema(X, expect):
 
 @pytest.mark.parametrize("deck", EX_DECKS)
 def test_example_decks_known_answers(oracle, deck):
-    """examples/static/exB..exE (pressure, body force, gravity, centrifugal load on the TYPE=361 beam): assembly (IC
+    """examples/static/exB..exF (pressure, body force, gravity, centrifugal, thermal load on the TYPE=361 beam): assembly (IC
     element) + Dirichlet BC + CG/DIAG of the restatement reproduce the displacement extrema of X361_correct.log.  The
     load vector is fixture input computed by the reference's own DL_C3 (make_exBCDE_golden.py)."""
     from oracle.refrun import default_params
