@@ -406,3 +406,24 @@ def test_example_decks_known_answers_on_gpu(hip, deck):
     ctx.download_x(m)
     check_extrema(m.X, g["expect"])
     ctx.close()
+
+
+def test_one_context_many_configurations(hip):
+    """A single context (the reference's module-level solver state) driven through changing METHOD / PRECOND
+    between calls of hecmw_solve -- the numbering of the resident vectors switches between natural, colour-major
+    and level-major underneath -- must give the golden answer every time."""
+    g = load_golden("cube4")
+    A = golden_matrix(g)
+    ctx = hip.SolverContext()
+    for meth, pc, thr in [(1, 1, 4), (1, 3, 1), (2, 10, 1), (1, 1, 4), (2, 3, 1), (1, 10, 1), (2, 1, 4)]:
+        m = to_hecmat(hip, A)
+        m.Iarray[0] = 10000; m.Iarray[1] = meth; m.Iarray[2] = pc
+        assert hip.hecmw_solve(None, m, ctx=ctx) == 0
+        tag = "sol_m%d_p%d_t%d_" % (meth, pc, thr)
+        check_solve(ctx.info, ctx.history, m.X, int(g[tag + "iter"]), g[tag + "hist"], g[tag + "X"], meth, printed=True)
+    for meth, pc in [(3, 1), (4, 10), (3, 3)]:               # and the host-driven methods on the same state
+        m = to_hecmat(hip, A)
+        m.Iarray[0] = 10000; m.Iarray[1] = meth; m.Iarray[2] = pc
+        assert hip.hecmw_solve(None, m, ctx=ctx) == 0
+        assert relerr(m.X, g["sol_m1_p3_t1_X"]) < 1e-6
+    ctx.close()
