@@ -1555,7 +1555,7 @@ extern "C" int fx_stream_ceiling(fx_context *c, int nrepeat, double *gbs) {
   if (ensure_solver(c)) return FX_ERROR_RUNTIME;
   const int64_t n2 = (int64_t)c->M.npairs * 576 / 2;  // double2 words
   if (n2 <= 0) { g_fx_error = "fx_stream_ceiling: no matrix resident"; return FX_ERROR_RUNTIME; }
-  const int g = 256 * 8;  // 8 workgroups per CU, grid-stride
+  const int g = std::min(256 * 32, (int)c->max_partials);  // 32 contiguous chunks per CU, one partial each
   hipLaunchKernelGGL(k_stream_read, dim3(g), dim3(FX_BLOCK), 0, c->stream, n2, (const double2 *)c->M.val2, c->partials);
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
   for (int i = 0; i < nrepeat; i++)

@@ -685,22 +685,26 @@ __global__ __launch_bounds__(FX_BLOCK) void k_bi_update_xr(int64_t n, const Kryl
   if (UPDATE_R) block_sum_store<1>(d, partials, 0);
 }
 
-// On-box streaming ceiling (SURVEY 8d asks for a measured one beside the 8 TB/s vendor peak):
-// read-only sweep with 16-byte loads, one partial per block so nothing is optimised away.
+// On-box streaming ceiling (SURVEY 8d asks for a measured one beside the 8 TB/s vendor peak): read-only sweep with
+// non-temporal 16-byte loads, every workgroup walking its own contiguous chunk, 8 loads in flight per lane -- the
+// fastest of the patterns probed by scripts/stream_probe.hip on MI355X (7.0-7.1 TB/s; a grid-stride sweep with a
+// small grid, the first version of this kernel, stops at 6.2-6.4 TB/s, temporal loads at 6.2).
 __global__ __launch_bounds__(FX_BLOCK) void k_stream_read(int64_t n2, const double2 *__restrict__ a,
                                                           double *__restrict__ partials) {
   double d[1] = {0.0};
   double s0 = 0.0, s1 = 0.0;
-  const int64_t stride = (int64_t)gridDim.x * FX_BLOCK;
-  int64_t i = (int64_t)blockIdx.x * FX_BLOCK + threadIdx.x;
-  for (; i + 7 * stride < n2; i += 8 * stride) {  // 8 x 16 B in flight per lane
+  const int64_t per = (n2 + gridDim.x - 1) / gridDim.x;
+  int64_t i = (int64_t)blockIdx.x * per + threadIdx.x;
+  const int64_t end = (int64_t)(blockIdx.x + 1) * per < n2 ? (int64_t)(blockIdx.x + 1) * per : n2;
+  const int64_t stride = FX_BLOCK;
+  for (; i + 7 * stride < end; i += 8 * stride) {
     fx_d2 v[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) v[k] = __builtin_nontemporal_load((const fx_d2 *)(a + i + k * stride));
 #pragma unroll
     for (int k = 0; k < 8; k++) { s0 += v[k].x; s1 += v[k].y; }
   }
-  for (; i < n2; i += stride) {
+  for (; i < end; i += stride) {
     const fx_d2 v = __builtin_nontemporal_load((const fx_d2 *)(a + i));
     s0 += v.x; s1 += v.y;
   }
