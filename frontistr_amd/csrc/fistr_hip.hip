@@ -199,6 +199,7 @@ extern "C" int fx_create(int device, fx_context **out) {
   if (const char *e = getenv("FX_PIPE_MAX_SLICES")) c->pipe_max_slices = atoi(e);
   if (const char *e = getenv("FX_SSOR_BS")) c->ssor_bs = (atoi(e) == 64) ? 64 : 256;
   if (const char *e = getenv("FX_SPMV_BS")) c->spmv_bs = (atoi(e) == 64) ? 64 : 256;
+  if (const char *e = getenv("FX_SPMV_SPATIAL")) c->spmv_spatial = atoi(e) != 0;
   if (const char *e = getenv("FX_SPLIT_MAX_SLICES")) c->split_max_slices = atoi(e);
   if (const char *e = getenv("FX_SPLIT_WPS")) c->split_wps = (atoi(e) == 2 || atoi(e) == 4 || atoi(e) == 8) ? atoi(e) : 0;
   *out = c;
@@ -206,7 +207,7 @@ extern "C" int fx_create(int device, fx_context **out) {
 }
 
 static void bell_free(Bell &b) {
-  dev_free(b.pair_ptr); dev_free(b.val2_base); dev_free(b.col2); dev_free(b.slot_row); dev_free(b.src2);
+  dev_free(b.pair_ptr); dev_free(b.val2_base); dev_free(b.col2); dev_free(b.slot_row); dev_free(b.src2); dev_free(b.slice_order);
   b.val2 = nullptr;
   b = Bell();
 }
@@ -412,6 +413,20 @@ static int build_full_bell(fx_context *c) {
   }
   std::vector<int32_t> sr(o.slot_node.begin(), o.slot_node.begin() + o.nslots);
   if (bell_build2(c, c->M, o.nslots, &sr, count, fill)) return FX_ERROR_RUNTIME;
+  if (o.kind == 1 && c->spmv_spatial) {  // walk the slices by the mesh position of their rows, all colours of a region together
+    const int32_t nsl = c->M.nslices;
+    std::vector<int32_t> key((size_t)nsl, INT32_MAX), ordv((size_t)nsl);
+    for (int32_t sl = 0; sl < nsl; sl++) {
+      ordv[sl] = sl;
+      for (int l = 0; l < 64; l++) {
+        const int32_t r = sr[(size_t)sl * 64 + l];
+        if (r >= 0) { key[sl] = r; break; }  // rows of a slice are in natural order inside their colour: the first is the smallest
+      }
+    }
+    std::stable_sort(ordv.begin(), ordv.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
+    if (dev_alloc(&c->M.slice_order, (size_t)nsl)) return FX_ERROR_RUNTIME;
+    HIP_TRY(hipMemcpy(c->M.slice_order, ordv.data(), (size_t)nsl * 4, hipMemcpyHostToDevice));
+  }
   c->m_symbolic = true;
   c->bell_valid = false;
   return 0;
@@ -669,7 +684,7 @@ static int spmv(fx_context *c, int mode, int dot, double *x, const double *b, do
   double *part = c->partials;
 #define SPMV_LAUNCH3(MODE, DOT, PIPE, B)                                                                              \
   hipLaunchKernelGGL((k_spmv<MODE, DOT, PIPE, B>), g, blk, 0, c->stream, M.nslices, c->ord.nslots, M.pair_ptr, M.val2, \
-                     M.col2, x, b, y, part, gate, gate_val)
+                     M.col2, x, b, y, part, gate, gate_val, M.slice_order)
 #define SPMV_LAUNCH(MODE, DOT)                                     \
   do {                                                             \
     if (c->pipe_spmv) {                                            \

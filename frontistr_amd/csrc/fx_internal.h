@@ -54,6 +54,7 @@ struct Bell {
   int *col2 = nullptr;          // npairs*64
   int *src2 = nullptr;          // npairs*64: source block codes 3*idx+{0 D,1 AL,2 AU}, -1 padding (kept for numeric refresh)
   int32_t *slot_row = nullptr;  // nslots: 0-based node id of the slot, -1 = padding slot (may be null = identity)
+  int32_t *slice_order = nullptr;  // nslices: order in which the SpMV walks the slices (null = ascending)
   int64_t nblocks = 0;          // real (non padding) blocks
   size_t bytes() const { return (size_t)npairs * 64 * (9 * 8 + 4) + (size_t)(nslices + 1) * 4; }
 };
@@ -173,6 +174,10 @@ struct fx_context {
   int ssor_bs = 64;            // workgroup size of the colour sweeps: 64 (default) or 256. Measured 10M DOF: 1.78 -> 1.61 ms per apply
   int pipe_max_slices = 1 << 30;  // colours with more slices use the plain row loop (with 64-thread groups: pipelined everywhere wins, 1.61 vs 1.64/1.69 ms)
   int spmv_bs = 256;              // workgroup size of the SpMV (FX_SPMV_BS)
+  // Colour-/level-major vectors: the SpMV walks the slices in SPATIAL order (slices of all colours that cover the same
+  // part of the mesh next to each other), so the x entries a region gathers stay in L2 across its colours.  The data
+  // layout is untouched; only the block -> slice map changes.  FX_SPMV_SPATIAL=0: ascending slices.
+  bool spmv_spatial = true;
   // Colours / ILU levels with at most this many slices run the wave-split sweep (k_ssor_color_split, split_wps waves
   // per slice): latency-bound launches.  FX_SPLIT_MAX_SLICES (0 = off) / FX_SPLIT_WPS (2, 4, 8; 0 = auto) override.
   // Measured at 10.1M DOF (same process): SSOR apply 1.46-1.49 -> 1.415 ms with 4 waves per slice on the 12 small

@@ -206,10 +206,14 @@ __global__ __launch_bounds__(BS) void k_spmv(int32_t nslices, int32_t nrows,
                                                    const int *__restrict__ col2,
                                                    const double *__restrict__ x, const double *__restrict__ b,
                                                    double *__restrict__ y, double *__restrict__ partials,
-                                                   const int32_t *__restrict__ gate, int32_t gate_val) {
+                                                   const int32_t *__restrict__ gate, int32_t gate_val,
+                                                   const int32_t *__restrict__ slice_order) {
   if (gate && *gate != gate_val) return;
   const int vb = xcd_block(blockIdx.x, gridDim.x);
-  const int slice = vb * (BS / 64) + (threadIdx.x >> 6);
+  int slice = vb * (BS / 64) + (threadIdx.x >> 6);
+  const bool live = slice < nslices;
+  if (live && slice_order) slice = slice_order[slice];
+  if (!live) slice = nslices;
   const int lane = threadIdx.x & 63;
   double y0 = 0.0, y1 = 0.0, y2 = 0.0;
   const int row = slice * 64 + lane;
