@@ -206,6 +206,14 @@ struct fx_context {
   double *hist = nullptr;      // device residual history
   int32_t hist_cap = 0;
   int k_method = 1, k_maxit = 0, k_it = 1;  // host mirror of the running Krylov loop
+  // Launch-bound sizes (<= graph_max_rows block rows, single rank): one CG / BiCGSTAB iteration is captured once per
+  // solve into two hipGraphs (ordinary iteration; the one that recomputes r = b - A x) and replayed -- every kernel
+  // argument is constant over a solve, what changes lives in the device-resident KrylovState.
+  // FX_GRAPH=0 off, 1 auto (default: SSOR / ILU(0) only, where an iteration is 40+ launches), 2 always.
+  int graph_mode = 1;
+  int32_t graph_max_rows = 1 << 19;
+  bool k_graph = false;
+  hipGraphExec_t g_normal = nullptr, g_recompute = nullptr;
   // communication
   int rank = 0, nranks = 1;
   int32_t nn_internal = 0;

@@ -427,3 +427,36 @@ def test_one_context_many_configurations(hip):
         assert hip.hecmw_solve(None, m, ctx=ctx) == 0
         assert relerr(m.X, g["sol_m1_p3_t1_X"]) < 1e-6
     ctx.close()
+
+
+@pytest.mark.parametrize("meth,pc", [(1, 1), (2, 10), (1, 3)])
+def test_graph_replay_is_bit_identical(meth, pc, tmp_path):
+    """The hipGraph replay of the Krylov iteration (auto for small SSOR / ILU systems) enqueues the same kernels in the
+    same order as the plain launches: iteration count, history and solution must be bit-identical (FX_GRAPH=0 vs 2,
+    fresh processes because the switch is read when the context is created)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r"""
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))
+import numpy as np
+from conftest import golden_matrix, load_golden
+from frontistr_amd import hecmw as hip
+A = golden_matrix(load_golden('cube4'))
+m = hip.hecmwST_matrix.from_arrays(A.N, A.NP, A.indexL, A.itemL, A.indexU, A.itemU, A.D, A.AL, A.AU, A.B.copy())
+m.Iarray[0] = 10000; m.Iarray[1] = %d; m.Iarray[2] = %d
+ctx = hip.SolverContext()
+assert hip.hecmw_solve(None, m, ctx=ctx) == 0
+np.savez(sys.argv[1], X=m.X, hist=ctx.history, it=ctx.info.iterations)
+""" % (ROOT, ROOT, meth, pc)
+    outs = []
+    for g in ("0", "2"):
+        out = str(tmp_path / ("g%s.npz" % g))
+        p = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, FX_GRAPH=g), stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout[-2000:]
+        outs.append(np.load(out))
+    assert int(outs[0]["it"]) == int(outs[1]["it"])
+    assert np.array_equal(outs[0]["hist"], outs[1]["hist"]) and np.array_equal(outs[0]["X"], outs[1]["X"])
