@@ -777,10 +777,23 @@ static int ssor_setup_symbolic(fx_context *c, int ncolor_in) {
   std::vector<int32_t> slot_row;
   slot_row.reserve((size_t)N + 64 * S.ncolor);
   S.color_slice.assign(1, 0);
+  std::vector<std::vector<int32_t>> color_rows((size_t)S.ncolor);
+  {  // the colours are sorted independently: one host thread each
+    std::vector<std::thread> th;
+    const int nt = std::max(1, std::min(nthreads_host(), (int)S.ncolor));
+    for (int t = 0; t < nt; t++)
+      th.emplace_back([&, t] {
+        for (int32_t col = t; col < S.ncolor; col += nt) {
+          std::vector<int32_t> &rows = color_rows[col];
+          rows.assign(perm0.begin() + cidx[col], perm0.begin() + cidx[col + 1]);
+          std::sort(rows.begin(), rows.end());
+          std::stable_sort(rows.begin(), rows.end(), [&](int32_t a, int32_t b) { return nlow[a] < nlow[b]; });
+        }
+      });
+    for (auto &t : th) t.join();
+  }
   for (int32_t col = 0; col < S.ncolor; col++) {
-    std::vector<int32_t> rows(perm0.begin() + cidx[col], perm0.begin() + cidx[col + 1]);
-    std::sort(rows.begin(), rows.end());
-    std::stable_sort(rows.begin(), rows.end(), [&](int32_t a, int32_t b) { return nlow[a] < nlow[b]; });
+    const std::vector<int32_t> &rows = color_rows[col];
     slot_row.insert(slot_row.end(), rows.begin(), rows.end());
     while (slot_row.size() % 64) slot_row.push_back(-1);
     S.color_slice.push_back((int32_t)(slot_row.size() / 64));
@@ -808,8 +821,8 @@ static int ssor_setup_symbolic(fx_context *c, int ncolor_in) {
   auto collect = [&](int32_t slot, std::vector<BellEntry> &e, bool lower) {
     const int32_t r = slot_row[slot];
     const int32_t me = newpos[r];
-    const size_t first = e.size();
-    std::vector<std::pair<int32_t, BellEntry>> tmp;
+    thread_local std::vector<std::pair<int32_t, BellEntry>> tmp;  // one scratch per host thread, not one malloc per row
+    tmp.clear();
     for (int32_t j = iL[r]; j < iL[r + 1]; j++) {
       const int32_t co = jL[j] - 1;
       if ((newpos[co] < me) == lower) tmp.push_back({newpos[co], {3 * j + 1, so[co]}});
@@ -821,7 +834,6 @@ static int ssor_setup_symbolic(fx_context *c, int ncolor_in) {
     }
     if (lower) std::sort(tmp.begin(), tmp.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
     else std::sort(tmp.begin(), tmp.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
-    (void)first;
     for (auto &t : tmp) e.push_back(t.second);
   };
   auto countL = [&](int32_t slot) { const int32_t r = slot_row[slot]; return r < 0 ? 0 : nlow[r]; };

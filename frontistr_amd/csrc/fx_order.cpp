@@ -115,24 +115,32 @@ void multicolor(const Graph &g, const std::vector<int32_t> &seq, int ncolor_in, 
   const int32_t cap = n / ncolor_in;
   std::vector<int32_t> mark((size_t)n, 0);  // >0 coloured, -1 blocked this round
   std::vector<int32_t> blocked;
+  // the reference rescans the whole sequence for every colour (:29-60); visiting only the nodes still uncoloured,
+  // in the same order, picks the same nodes
+  std::vector<int32_t> rem(seq), next;
+  next.reserve(rem.size());
   perm.clear();
   perm.reserve(n);
   colorindex.assign(1, 0);
   for (int32_t color = 1; (int32_t)perm.size() < n; color++) {
     int32_t cnt = 0;
     blocked.clear();
-    for (int32_t q = 0; q < n; q++) {
-      const int32_t u = seq[q];
-      if (mark[u] != 0) continue;
+    next.clear();
+    size_t q = 0;
+    for (; q < rem.size(); q++) {
+      const int32_t u = rem[q];
+      if (mark[u] != 0) { next.push_back(u); continue; }  // blocked in this round: stays for the next one
       mark[u] = color;
       perm.push_back(u);
       cnt++;
-      if (cnt == cap || (int32_t)perm.size() == n) break;
+      if (cnt == cap || (int32_t)perm.size() == n) { q++; break; }
       for (int64_t e = g.ptr[u]; e < g.ptr[u + 1]; e++) {
         const int32_t v = g.adj[e];
         if (mark[v] == 0) { mark[v] = -1; blocked.push_back(v); }
       }
     }
+    next.insert(next.end(), rem.begin() + q, rem.end());  // not visited because the colour was full
+    rem.swap(next);
     colorindex.push_back((int32_t)perm.size());
     for (int32_t v : blocked)
       if (mark[v] == -1) mark[v] = 0;
