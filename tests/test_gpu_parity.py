@@ -460,3 +460,30 @@ np.savez(sys.argv[1], X=m.X, hist=ctx.history, it=ctx.info.iterations)
         outs.append(np.load(out))
     assert int(outs[0]["it"]) == int(outs[1]["it"])
     assert np.array_equal(outs[0]["hist"], outs[1]["hist"]) and np.array_equal(outs[0]["X"], outs[1]["X"])
+
+
+@pytest.mark.parametrize("n,skew", [(1, 0.0), (2, 0.2), (3, 0.0), (5, 0.25), (7, 0.1)])
+def test_small_and_odd_sizes_all_solvers(hip, oracle, n, skew):
+    """Edge sizes of the sliced layouts (8, 27, 64, 216, 512 nodes: fewer rows than a slice, exactly one slice, ragged
+    last slices, rows without lower or upper blocks) through every METHOD x PRECOND pair against the oracle."""
+    from frontistr_amd.mesh import CubeMesh
+    from oracle.refrun import default_params
+    mesh = CubeMesh(n, skew=skew)
+    A = oracle.assemble(1, mesh.coord, mesh.conn, 210000.0, 0.3, bc=mesh.dirichlet(), load=mesh.load())
+    hm = hip.hecmwST_local_mesh(n_node=mesh.n_node)
+    hm.elem_node_item = mesh.conn.ravel()
+    ctx = hip.SolverContext()
+    for meth in (1, 2, 3, 4):
+        for pc in (1, 3, 10):
+            I, R = default_params(method=meth, precond=pc)
+            o = oracle.solve_iterative(A, I, R, nthreads=4)
+            m = hip.hecmw_mat_con(hm, hip.hecmwST_matrix())
+            ctx.upload(m, what=hip.FX_UP_PROFILE)
+            ctx.assemble_c3d8(mesh.coord, mesh.conn, 210000.0, 0.3, elemopt=1, load=mesh.load(), bc=mesh.dirichlet())
+            m.Iarray[0] = 10000; m.Iarray[1] = meth; m.Iarray[2] = pc
+            code = ctx.solve_resident(m)
+            ctx.download_x(m)
+            assert code == o["code"] == 0, (meth, pc, code, o["code"])
+            assert relerr(m.X, o["X"]) < 1e-7, (meth, pc)
+            assert abs(ctx.info.iterations - o["iter"]) <= max(2, 0.2 * o["iter"]), (meth, pc, ctx.info.iterations, o["iter"])
+    ctx.close()
