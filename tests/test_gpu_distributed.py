@@ -11,7 +11,7 @@ from test_distributed import check_against_serial, dist_prefix, run_world, seria
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("world,m,meth,pc", [(2, 6, 1, 3), (4, 5, 1, 3), (2, 6, 2, 3)])
+@pytest.mark.parametrize("world,m,meth,pc", [(2, 6, 1, 3), (4, 5, 1, 3), (2, 6, 2, 3), (2, 6, 3, 3), (2, 6, 4, 3)])
 def test_hip_distributed_block_jacobi_equals_serial(oracle, tmp_path, world, m, meth, pc):
     dims = {2: (2, 1, 1), 4: (2, 2, 1)}[world]
     res = run_world("hip", world, m, meth, pc, tmp_path)
