@@ -238,3 +238,24 @@ def test_exI_known_answer_on_gpu(hip):
         unodes.append(solid.get_state(("unode",))["unode"])
     T.check_exI_extrema(unodes, e)
     ctx.close()
+
+
+@pytest.mark.parametrize("name", ["mises", "swift", "ramberg"])
+def test_one_element_plasticity_decks_on_gpu(hip, name):
+    """examples/static/1elem: perfectly plastic / Swift / Ramberg-Osgood hardening, 10 substeps of uniaxial stretch,
+    against the run of the reference routines, and sigma_xx on the hardening curve."""
+    from frontistr_amd import fstr
+    T = _T()
+    g, mat, bc, converg, I, R, want = T.one_elem_case(name)
+
+    class M:
+        coord, conn, n_node = g["coord"], g["conn"], 8
+    ctx, hecMAT, solid = _solid(hip, mat, M)
+    hecMAT.Iarray[:] = I
+    hecMAT.Rarray[:] = R
+    log = fstr.fstr_solve_NLGEOM(solid, hecMAT, bc, None, 10, 50, converg)
+    st = solid.get_state()
+    _check_steps(log, st, want, True)
+    sy = T.uniaxial_yield_stress(name, mat, st["plstrain"][0, 0])
+    assert np.abs(st["stress"][0, :, 0] - sy).max() < 2e-3 * sy
+    ctx.close()

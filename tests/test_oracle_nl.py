@@ -165,3 +165,38 @@ def test_exI_known_answer():
                         factors=((sub - 1) / nsub, sub / nsub))
         unodes.append(model.unode.copy())
     check_exI_extrema(unodes, e)
+
+
+ONE_ELEM = ["mises", "swift", "ramberg"]
+
+
+def one_elem_case(name):
+    """examples/static/1elem/{mises,swift,ramberg}: unit cube, uniaxial stretch in 10 substeps."""
+    g = np.load(os.path.join(GOLD, "nl_1elem.npz"))
+    mat = refrun.Material(float(g[name + "_E"]), float(g[name + "_nu"]), plastic=True, harden=int(g[name + "_harden"]),
+                          plconst=tuple(g[name + "_plconst"]), nlgeom=2)
+    bc = (g[name + "_bc_node"], g[name + "_bc_dof"], g[name + "_bc_val"])
+    I, R = refrun.default_params(method=1, precond=1, maxit=10000, tol=1e-12, iterlog=0, timelog=0)
+    want = {k: g[name + "_" + k] for k in ("log", "unode", "stress", "plstrain", "istat")}
+    return g, mat, bc, float(g[name + "_converg"]), I, R, want
+
+
+def uniaxial_yield_stress(name, mat, pl):
+    """The hardening law itself (calCurrYield, Elastoplastic.f90:254-292) at the final plastic strain: under the decks'
+    uniaxial stress state sigma_xx must sit on it -- a check that does not involve the reference's output."""
+    if name == "mises":
+        return mat.plconst[0] + mat.plconst[1] * pl
+    if name == "swift":
+        return mat.plconst[1] * (mat.plconst[0] + pl) ** mat.plconst[2]
+    return mat.plconst[1] * (pl / mat.plconst[0]) ** (1.0 / mat.plconst[2])
+
+
+@pytest.mark.parametrize("name", ONE_ELEM)
+def test_one_element_plasticity_decks(name):
+    g, mat, bc, converg, I, R, want = one_elem_case(name)
+    model = pyoracle.NonlinearModel(mat, g["coord"], g["conn"])
+    log = model.run_steps(*bc, np.zeros(24), 10, 50, converg, I, R, nthreads=2)
+    check_steps(model, log, want)
+    s, pl = model.state["stress"][0], model.state["plstrain"][0]
+    sy = uniaxial_yield_stress(name, mat, pl[0])
+    assert np.abs(s[:, 0] - sy).max() < 2e-3 * sy and np.abs(s[:, 1:]).max() < 2e-3 * sy      # BackwardEuler's tol = 1e-3 on f
