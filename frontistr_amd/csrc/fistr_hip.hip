@@ -226,7 +226,7 @@ static void free_matrix(fx_context *c) {
   c->m_symbolic = false;
   dev_free(c->Bs); dev_free(c->Xs);
   for (auto &w : c->W) dev_free(w);
-  dev_free(c->partials);
+  dev_free(c->partials); dev_free(c->scale_vec);
   c->wlen = 0;
   c->max_partials = 0;
   c->have_profile = c->have_values = c->bell_valid = false;
@@ -1353,6 +1353,34 @@ static int host_sum(fx_context *c, int nparts, int stride, double *v0, double *v
 
 #include "fx_krylov2_host.h"
 
+// SCALING=YES: the resident D/AL/AU/B are scaled in place before the preconditioner set-up and the Krylov loop and
+// divided back afterwards, as every solver of the reference does (hecmw_solver_CG.f90:104, :277).
+static int scaling_apply(fx_context *c, bool back) {
+  const DevCSR &A = c->A;
+  if (ensure_solver(c)) return FX_ERROR_RUNTIME;
+  if (!c->scale_vec && dev_alloc(&c->scale_vec, (size_t)3 * A.NP)) return FX_ERROR_RUNTIME;  // freed with the matrix
+  double *scale = c->scale_vec;
+  const int64_t n3 = (int64_t)3 * A.N;
+  if (!back) {
+    HIP_TRY(hipMemsetAsync(scale, 0, (size_t)3 * A.NP * 8, c->stream));
+    hipLaunchKernelGGL(k_scaling_vector, dim3((A.N + 255) / 256), dim3(256), 0, c->stream, A.N, A.D, scale);
+    if (multi_rank(c)) {  // hecmw_update_3_R(scale): natural numbering -> slots -> halo -> back
+      if (to_slots(c, scale, c->W[6]) || halo_update(c, c->W[6]) || from_slots(c, c->W[6], scale)) return FX_ERROR_RUNTIME;
+    }
+    hipLaunchKernelGGL((k_scaling_matrix<false>), dim3((A.NP + 255) / 256), dim3(256), 0, c->stream, A.NP, A.indexL, A.itemL,
+                       A.indexU, A.itemU, A.D, A.AL, A.AU, scale);
+    hipLaunchKernelGGL((k_scaling_rhs<false>), dim3(grid_for(n3)), dim3(256), 0, c->stream, n3, scale, A.B, A.X);
+  } else {
+    hipLaunchKernelGGL((k_scaling_rhs<true>), dim3(grid_for(n3)), dim3(256), 0, c->stream, n3, scale, A.B, A.X);
+    hipLaunchKernelGGL((k_scaling_matrix<true>), dim3((A.NP + 255) / 256), dim3(256), 0, c->stream, A.NP, A.indexL, A.itemL,
+                       A.indexU, A.itemU, A.D, A.AL, A.AU, scale);
+  }
+  HIP_TRY(hipGetLastError());
+  c->bell_valid = false;      // the streaming layouts are gathered again from the (un)scaled values
+  c->precond_valid = false;
+  return 0;
+}
+
 extern "C" int fx_solve_resident(fx_context *c, int32_t *Iarray, double *Rarray, fx_solve_info *info, double *hist,
                                  int32_t hist_len) {
   HIP_TRY(hipSetDevice(c->device));
@@ -1418,9 +1446,17 @@ extern "C" int fx_solve_resident(fx_context *c, int32_t *Iarray, double *Rarray,
   const bool auto_sigma = Rarray[1] < 0.0;  // hecmw_solver_Iterative.f90:68-73
   double sigma = auto_sigma ? 1.0 : Rarray[1];
   double t1 = now_s();
+  const bool scaling = Iarray[6] != 0;  // SCALING=YES (IDX_I_SCALING = 7)
   for (;;) {
     Iarray[80] = 0; Iarray[81] = 0;
     int e;
+    if (scaling) {  // scale, then build the preconditioner of the scaled matrix (CG.f90:104-112)
+      if (scaling_apply(c, false)) return FX_ERROR_RUNTIME;
+      double R2[100];
+      memcpy(R2, Rarray, sizeof R2);
+      R2[1] = sigma;
+      if (int pe = fx_precond_setup(c, Iarray, R2)) return pe;
+    }
     if (method == 1 || method == 2) e = run_krylov(c, method, maxit, tol, &s);
     else if (method == 3 || method == 4) {
       HostKrylov hk;
@@ -1436,6 +1472,10 @@ extern "C" int fx_solve_resident(fx_context *c, int32_t *Iarray, double *Rarray,
       if (!hk.hist.empty()) HIP_TRY(hipMemcpy(c->hist, hk.hist.data(), hk.hist.size() * 8, hipMemcpyHostToDevice));
     } else { g_fx_error = "METHOD must be 1 (CG), 2 (BiCGSTAB), 3 (GMRES) or 4 (GPBiCG)"; return FX_ERROR_INCONS_PC; }
     if (e) return e;
+    if (scaling) {  // x <- D^-1/2 x, b and the matrix divided back (CG.f90:277); then everything resident is refreshed
+      if (from_slots(c, c->Xs, c->A.X) || scaling_apply(c, true) || ensure_solver(c)) return FX_ERROR_RUNTIME;
+      if (to_slots(c, c->A.B, c->Bs) || to_slots(c, c->A.X, c->Xs)) return FX_ERROR_RUNTIME;
+    }
     if (s.status == FX_ERROR_DIVERGE_PC || s.status == FX_ERROR_DIVERGE_MAT) {  // :145-156
       Iarray[81] = 1;
       // a retry continues from the X the failed attempt left behind (hecMAT%X is not reset), halo included

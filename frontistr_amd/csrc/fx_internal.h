@@ -194,6 +194,7 @@ struct fx_context {
   double *W[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int iterpremax = 1;  // additive-Schwarz sweeps of hecmw_precond_33_apply
   int32_t wlen = 0;
+  double *scale_vec = nullptr;  // SCALING=YES: 1/sqrt|diag|, reference numbering, 3*NP (+ slack)
   double *extra = nullptr;  // further work vectors (GMRES basis, GPBiCG), extra_n x extra_len
   int extra_n = 0;
   int32_t extra_len = 0;

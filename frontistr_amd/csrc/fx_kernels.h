@@ -716,6 +716,41 @@ __global__ __launch_bounds__(FX_BLOCK) void k_stream_read(int64_t n2, const doub
   block_sum_store<1>(d, partials, 0);
 }
 
+// SCALING=YES (hecmw_solver_scaling_fw_33 / _bk_33, las/hecmw_solver_scaling_33.f90:20-117, :119-208):
+// scale(3i+k) = 1/sqrt|D_i(k,k)|, then A(ij) *= scale(i) scale(j), b *= scale  (back: /=, x *= scale).
+__global__ void k_scaling_vector(int32_t N, const double *__restrict__ D, double *__restrict__ scale) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+#pragma unroll
+  for (int k = 0; k < 3; k++) scale[(size_t)3 * i + k] = 1.0 / sqrt(fabs(D[(size_t)9 * i + 4 * k]));
+}
+template <bool BACK>
+__global__ void k_scaling_matrix(int32_t NP, const int32_t *__restrict__ indexL, const int32_t *__restrict__ itemL,
+                                 const int32_t *__restrict__ indexU, const int32_t *__restrict__ itemU,
+                                 double *__restrict__ D, double *__restrict__ AL, double *__restrict__ AU,
+                                 const double *__restrict__ scale) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NP) return;
+  const double si[3] = {scale[(size_t)3 * i], scale[(size_t)3 * i + 1], scale[(size_t)3 * i + 2]};
+  auto block = [&](double *v, int32_t j) {
+    const double sj[3] = {scale[(size_t)3 * j], scale[(size_t)3 * j + 1], scale[(size_t)3 * j + 2]};
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int q = 0; q < 3; q++) v[3 * r + q] = BACK ? v[3 * r + q] / (si[r] * sj[q]) : v[3 * r + q] * si[r] * sj[q];
+  };
+  block(D + (size_t)9 * i, i);
+  for (int32_t k = indexL[i]; k < indexL[i + 1]; k++) block(AL + (size_t)9 * k, itemL[k] - 1);
+  for (int32_t k = indexU[i]; k < indexU[i + 1]; k++) block(AU + (size_t)9 * k, itemU[k] - 1);
+}
+template <bool BACK>
+__global__ void k_scaling_rhs(int64_t n3, const double *__restrict__ scale, double *__restrict__ B, double *__restrict__ X) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n3; i += (int64_t)gridDim.x * blockDim.x) {
+    if (BACK) { X[i] = X[i] * scale[i]; B[i] = B[i] / scale[i]; }
+    else B[i] = B[i] * scale[i];
+  }
+}
+
 __global__ void k_copy(int64_t n, const double *__restrict__ a, double *__restrict__ b) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     b[i] = a[i];

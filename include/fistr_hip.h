@@ -92,7 +92,9 @@ int fx_device_synchronize(fx_context *ctx);
  * iteration = the ITERLOG channel (hecmw_solver_CG.f90:245), at most hist_len.
  * METHOD Iarray(2): 1 CG (hecmw_solver_CG.f90:19), 2 BiCGSTAB (hecmw_solver_BiCGSTAB.f90:16),
  * 3 GMRES(NREST=Iarray(6)) (hecmw_solver_GMRES.f90:17), 4 GPBiCG (hecmw_solver_GPBiCG.f90:17);
- * PRECOND Iarray(3): 1,2 SSOR, 3 DIAG (block Jacobi), 10 ILU(0); anything else E-1001. */
+ * PRECOND Iarray(3): 1,2 SSOR, 3 DIAG (block Jacobi), 10 ILU(0); anything else E-1001.
+ * SCALING Iarray(7) /= 0: symmetric diagonal scaling around every attempt (las/hecmw_solver_scaling_33.f90);
+ * SIGMA_DIAG Rarray(2) < 0: the reference's automatic retry for the ILU family; METHOD2 Iarray(8) take-over. */
 int fx_solve(fx_context *ctx, const fx_matrix_view *mat, const fx_comm_view *comm, int32_t *Iarray,
              double *Rarray, fx_solve_info *info, double *hist, int32_t hist_len);
 

@@ -73,6 +73,33 @@ def test_gmres_gpbicg_match_reference(oracle, case):
     assert o["Iarray"][80] == g[tag + "Iarray"][80]
 
 
+SCALING_CASES = [(d, m, p, t) for d in ("cube4", "cube3s", "exA_A361")
+                 for m, p, t in ((1, 3, 1), (1, 1, 4), (2, 10, 1), (3, 3, 1), (4, 1, 4)) if not (d == "exA_A361" and m == 3)]
+
+
+def scaling_tag(deck, meth, pc, thr):
+    return "%s_m%d_p%d_t%d_" % (deck, meth, pc, thr)
+
+
+@pytest.mark.parametrize("case", SCALING_CASES, ids=lambda c: scaling_tag(*c))
+def test_scaling_option_matches_reference(oracle, case):
+    """SCALING=YES (Iarray(7)): bit-exact X, iteration counts, histories and the converged flag -- including GMRES runs
+    whose final true-residual check against the un-scaled system fails (flag 0) although the scaled recurrence converged."""
+    from oracle.refrun import default_params
+    deck, meth, pc, thr = case
+    g = load_golden("scaling")
+    tag = scaling_tag(*case)
+    A = golden_matrix(load_golden(deck))
+    I, R = default_params(method=meth, precond=pc)
+    I[6] = 1
+    o = oracle.solve_iterative(A, I, R, nthreads=thr)
+    assert o["iter"] == int(g[tag + "iter"])
+    h = g[tag + "hist"]
+    assert len(o["history"]) == len(h) and np.all(np.abs(o["history"] - h) <= 6e-7 * h)
+    assert np.array_equal(o["X"], g[tag + "X"])
+    assert o["Iarray"][80] == g[tag + "Iarray"][80]
+
+
 def test_exA_known_answer(oracle):
     """examples/static/exA/A361_correct.log extrema, the reference harness' own
     tolerance (|d| <= 1e-4, examples/test_FrontISTR.rb:10)."""
