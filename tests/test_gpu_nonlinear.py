@@ -259,3 +259,32 @@ def test_one_element_plasticity_decks_on_gpu(hip, name):
     sy = T.uniaxial_yield_stress(name, mat, st["plstrain"][0, 0])
     assert np.abs(st["stress"][0, :, 0] - sy).max() < 2e-3 * sy
     ctx.close()
+
+
+def test_load_steps_with_bicgstab_ilu0(hip, oracle):
+    """configs[4]'s solver pairing inside the Newton loop: BiCGSTAB + ILU(0), multilinear Mises, updated Lagrange,
+    5^3 elements, 2 substeps, against the oracle loop (same Newton counts, fields 1e-7)."""
+    from frontistr_amd import fstr
+    from oracle import refrun
+    T = _T()
+    mat = T.materials()["mises_multilinear_ul"]
+    m = CubeMesh(5, skew=0.1)
+    bn, bd, bv = m.dirichlet()
+    tn = np.repeat(m.top_nodes, 3).astype(np.int32)
+    td = np.tile(np.array([1, 2, 3], dtype=np.int32), m.top_nodes.size)
+    tv = np.tile(np.array([0.03, 0.0, 0.15]), m.top_nodes.size)
+    bc = (np.concatenate([bn, tn]), np.concatenate([bd, td]), np.concatenate([bv, tv]))
+    I, R = refrun.default_params(method=2, precond=10, tol=1e-10, iterlog=0, timelog=0)
+    model = oracle.NonlinearModel(mat, m.coord, m.conn)
+    olog = model.run_steps(*bc, np.zeros(m.ndof), 2, 5, 1e-3, I, R, nthreads=1)
+    ctx, hecMAT, solid = _solid(hip, mat, m)
+    hecMAT.Iarray[:] = I
+    hecMAT.Rarray[:] = R
+    log = fstr.fstr_solve_NLGEOM(solid, hecMAT, bc, None, 2, 5, 1e-3)
+    st = solid.get_state()
+    assert log.shape[0] == olog.shape[0] and np.array_equal(log[:, :2], olog[:, :2])
+    np.testing.assert_allclose(log[:, 4:], olog[:, 3:], rtol=1e-5, atol=1e-9)
+    _close(st["unode"], model.unode, 1e-7, "unode")
+    _close(st["stress"], model.state["stress"], 1e-6, "stress")
+    assert np.array_equal(st["istat"], model.state["istat"]) and model.state["plstrain"].max() > 1e-3
+    ctx.close()
