@@ -70,14 +70,20 @@ contains
     type(fx_comm_view)   :: cv
     type(fx_solve_info)  :: info
     real(kind=kreal), allocatable, target :: hist(:)
-    integer(kind=kint) :: ierr, i, nhist
+    integer(kind=kint) :: ierr, i, nhist, precond
     character(len=8) :: env
     integer :: elen, estat
 
-    ! CPU escape hatch / anything that is not the iterative 3x3 path goes to the reference
+    ! Explicit opt-out (HECMW_GPU=0) and everything outside the GPU hot path -- other block sizes, direct solvers,
+    ! MPC / contact matrices, preconditioners other than SSOR / DIAG / ILU(0) -- stay with the reference's own CPU
+    ! code, and say so: the routing is never silent.
     call get_environment_variable('HECMW_GPU', env, elen, estat)
+    precond = hecMAT%Iarray(3)
     if ((estat == 0 .and. elen > 0 .and. env(1:1) == '0') .or. hecMAT%NDOF /= 3 .or. &
-        hecMAT%Iarray(99) /= 1 .or. hecMESH%mpc%n_mpc > 0 .or. hecMAT%cmat%n_val > 0) then
+        hecMAT%Iarray(99) /= 1 .or. hecMESH%mpc%n_mpc > 0 .or. hecMAT%cmat%n_val > 0 .or. &
+        .not. (precond == 1 .or. precond == 2 .or. precond == 3 .or. precond == 10)) then
+      if (hecMESH%my_rank == 0) write(*,'(a,i0,a,i0,a)') '### libfistr_hip: reference CPU solver used (NDOF=', &
+        hecMAT%NDOF, ', PRECOND=', precond, ', HECMW_GPU / MPC / contact / direct: see INTEGRATION.md)'
       call hecmw_solve_iterative(hecMESH, hecMAT)
       return
     endif

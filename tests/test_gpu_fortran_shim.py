@@ -23,6 +23,7 @@ def test_fistr_side_call_through_shim(deck, meth, pc, thr):
     I, R = refrun.default_params(method=meth, precond=pc)
     r = refrun.run_solve(A, I, R, exe_name="shim_solve")
     assert r["returncode"] == 0, r["stdout"][-2000:]
+    assert "(libfistr_hip) METHOD" in r["stdout"] and "reference CPU solver used" not in r["stdout"]   # the GPU path ran
     tag = "sol_m%d_p%d_t%d_" % (meth, pc, thr)
     x_ref, h_ref = g[tag + "X"], g[tag + "hist"]
     assert np.abs(r["X"] - x_ref).max() < 1e-8 * np.abs(x_ref).max()
@@ -43,4 +44,5 @@ def test_shim_cpu_escape_hatch():
     A = golden_matrix(g)
     I, R = refrun.default_params(method=1, precond=3)
     r = refrun.run_solve(A, I, R, exe_name="shim_solve", extra_env={"HECMW_GPU": "0"})
+    assert "reference CPU solver used" in r["stdout"]        # announced, never silent
     assert np.array_equal(r["X"], g["sol_m1_p3_t1_X"])      # bit-for-bit the reference
