@@ -1,5 +1,5 @@
 """Host-side neighbour exchange over torch.distributed (gloo on CPU, or any initialised
-backend): the transport behind fx_comm_set_host_callbacks and behind the oracle's comm hooks
+backend): the transport behind fx_comm_set_host_callbacks and behind the comm hooks of the CPU test harness
 in the multi-process tests.  Production multi-GPU runs use RCCL inside the library
 (fx_comm_init); this path exists so that the decomposition logic (pack order, import/export
 tables, reduction placement) is exercised on machines with a single GPU or none.
