@@ -82,6 +82,12 @@ def main():
     ap.add_argument("--cpu-sample-iters", type=int, default=40)
     a = ap.parse_args()
 
+    # Native libraries write to the process' stdout (RCCL prints a version banner when a communicator is created, the
+    # reference binaries of the cpu_baseline leg log their solver summary): keep fd 1 for the ONE JSON line only.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from frontistr_amd import hecmw as hip
@@ -115,6 +121,10 @@ def main():
         mesh = CubeMesh(a.n)
         hm = hip.hecmwST_local_mesh(n_node=mesh.n_node)
         coord, conn, load, bc = mesh.coord, mesh.conn, mesh.load(), mesh.dirichlet()
+        if os.environ.get("FX_FORCE_COMM", "0") not in ("", "0"):
+            # rehearsal of the in-stream RCCL reductions on one GPU: a 1-rank communicator, every scalar stage goes
+            # reduce -> ncclAllReduce -> logic exactly as in a multi-GPU run (no halo: there are no neighbours)
+            ctx.comm_init(hip.comm_unique_id(), 0, 1)
     else:
         from frontistr_amd.partition import cube_subdomain
         sub = cube_subdomain(a.n + 1, decomposition(world), rank)
@@ -236,7 +246,10 @@ def main():
                 "sample_matvec_s": cb.get("matvec"), "sample_precond_s": cb.get("precond"),
             }
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(json_fd, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)                      # whatever teardown prints goes to stderr again
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
