@@ -191,7 +191,7 @@ def main():
         # weak scaling: every rank advances its own 10.125M-DOF subdomain by K iterations, so the job
         # processed world*K subdomain-iterations (N=1: plain CG iterations/s on the 10M-DOF mesh)
         "value": world * a.steps / dt,
-        "unit": "CG iterations/s" if world == 1 else "CG iterations/s x subdomains (10.125M-DOF subdomain-iterations/s, summed over GPUs)",
+        "unit": "CG iterations/s" if world == 1 else "CG iterations/s x subdomains (%.3fM-DOF subdomain-iterations/s, summed over GPUs)" % (3 * N / 1e6),
         "global_iterations_per_s": a.steps / dt,
         "n_gpus": world,
         "steps": a.steps,
