@@ -23,6 +23,7 @@ extern "C" int fx_nl_init(fx_context *c, const fx_mesh_view *mesh, const fx_mate
     return FX_ERROR_UNSUPPORTED;
   }
   if (mat->plastic && mat->harden == 1 && (mat->ntab < 1 || !mat->tab)) { g_fx_error = "fx_nl_init: MULTILINEAR hardening needs a table"; return FX_ERROR_RUNTIME; }
+  if (mesh->n_elem < 1 || mesh->n_node < 1) { g_fx_error = "fx_nl_init: empty mesh"; return FX_ERROR_RUNTIME; }
   for (int64_t k = 0; k < (int64_t)8 * mesh->n_elem; k++)
     if (mesh->conn[k] < 1 || mesh->conn[k] > mesh->n_node) { g_fx_error = "fx_nl_init: node id out of range"; return FX_ERROR_RUNTIME; }
   nl_free(c);
@@ -271,6 +272,7 @@ extern "C" int fx_newton_substep(fx_context *c, double factor0, double factor1, 
                                  const int32_t *bc_dof, const double *bc_val, const double *cload, int32_t max_iter, double converg,
                                  int32_t *Iarray, double *Rarray, double *log, int32_t *n_iter, int commit_unconverged) {
   NL_READY("fx_newton_substep");
+  if (max_iter < 1) { g_fx_error = "fx_newton_substep: max_iter must be >= 1"; return FX_ERROR_RUNTIME; }
   const size_t np3 = (size_t)3 * c->A.NP;
   std::vector<double> gl, inc((size_t)std::max(n_bc, 1)), zero((size_t)std::max(n_bc, 1), 0.0);
   if (cload) {
