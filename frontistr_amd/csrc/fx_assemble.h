@@ -100,7 +100,9 @@ __global__ __launch_bounds__(FXA_BLOCK) void k_assemble_c3d8(int32_t n_elem, con
                                                              const int32_t *__restrict__ indexU,
                                                              const int32_t *__restrict__ itemU, double *__restrict__ D,
                                                              double *__restrict__ AL, double *__restrict__ AU,
-                                                             double *__restrict__ Kout, int32_t *__restrict__ err) {
+                                                             double *__restrict__ Kout, int32_t *__restrict__ err,
+                                                             const int32_t *__restrict__ elem_mat,
+                                                             const double *__restrict__ mat_tab) {
   constexpr int NJ = (ELEMOPT == 1) ? 11 : 8;
   __shared__ double Ksh[(ELEMOPT == 1) ? FXA_EPB : 1][9][34];
   __shared__ double Xinv[(ELEMOPT == 1) ? FXA_EPB : 1][9][10];
@@ -113,6 +115,10 @@ __global__ __launch_bounds__(FXA_BLOCK) void k_assemble_c3d8(int32_t n_elem, con
 #pragma unroll
     for (int e = 0; e < 9; e++) K[b][e] = 0.0;
   int32_t nod[8];
+  if (active && elem_mat) {  // several sections: (D11, D12, D44) of this element's material (hecMESH%section_ID)
+    const int32_t mid = elem_mat[elem] - 1;
+    D11 = mat_tab[3 * mid]; D12 = mat_tab[3 * mid + 1]; D44 = mat_tab[3 * mid + 2];
+  }
   if (active) {
     double ec[8][3];
 #pragma unroll

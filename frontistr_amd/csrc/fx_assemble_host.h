@@ -72,15 +72,17 @@ static void elastic_constants(double E, double nu, double &D11, double &D12, dou
 
 template <int EO>
 static void launch_assemble(fx_context *c, int32_t n_elem, const double *coord, const int32_t *conn, double D11, double D12,
-                            double D44, double *Kout, int32_t *err) {
+                            double D44, double *Kout, int32_t *err, const int32_t *elem_mat = nullptr,
+                            const double *mat_tab = nullptr) {
   const DevCSR &A = c->A;
   hipLaunchKernelGGL((k_assemble_c3d8<EO>), dim3((n_elem + FXA_EPB - 1) / FXA_EPB), dim3(FXA_BLOCK), 0, c->stream, n_elem,
-                     coord, conn, D11, D12, D44, A.indexL, A.itemL, A.indexU, A.itemU, A.D, A.AL, A.AU, Kout, err);
+                     coord, conn, D11, D12, D44, A.indexL, A.itemL, A.indexU, A.itemU, A.D, A.AL, A.AU, Kout, err, elem_mat,
+                     mat_tab);
 }
 
-extern "C" int fx_assemble_c3d8(fx_context *c, const fx_mesh_view *mesh, double E, double nu, int elemopt, const double *load,
-                                int32_t n_bc, const int32_t *bc_node, const int32_t *bc_dof, const double *bc_val,
-                                float *ms_assemble) {
+static int assemble_c3d8_common(fx_context *c, const fx_mesh_view *mesh, double E, double nu, int32_t n_mat, const double *Es,
+                                const double *nus, const int32_t *elem_mat, int elemopt, const double *load, int32_t n_bc,
+                                const int32_t *bc_node, const int32_t *bc_dof, const double *bc_val, float *ms_assemble) {
   HIP_TRY(hipSetDevice(c->device));
   if (!c->have_profile) { g_fx_error = "fx_assemble_c3d8: upload the profile first (fx_upload FX_UP_PROFILE)"; return FX_ERROR_RUNTIME; }
   if (mesh->n_node != c->A.NP) { g_fx_error = "fx_assemble_c3d8: mesh/profile size mismatch"; return FX_ERROR_RUNTIME; }
@@ -95,16 +97,29 @@ extern "C" int fx_assemble_c3d8(fx_context *c, const fx_mesh_view *mesh, double 
   HIP_TRY(hipMemcpyAsync(d_coord, mesh->coord, (size_t)3 * mesh->n_node * 8, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(d_conn, mesh->conn, (size_t)8 * mesh->n_elem * 4, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemsetAsync(d_err, 0, 4, c->stream));
-  double D11, D12, D44;
-  elastic_constants(E, nu, D11, D12, D44);
+  double D11 = 0.0, D12 = 0.0, D44 = 0.0;
+  int32_t *d_emat = nullptr;
+  double *d_mtab = nullptr;
+  if (n_mat > 0) {  // several sections: per-element material id + a (D11, D12, D44) table
+    std::vector<double> tab((size_t)3 * n_mat);
+    for (int32_t k = 0; k < n_mat; k++) elastic_constants(Es[k], nus[k], tab[3 * k], tab[3 * k + 1], tab[3 * k + 2]);
+    for (int32_t e = 0; e < mesh->n_elem; e++)
+      if (elem_mat[e] < 1 || elem_mat[e] > n_mat) { g_fx_error = "fx_assemble_c3d8_sections: material id out of range"; return FX_ERROR_RUNTIME; }
+    if (tmp.alloc(&d_emat, (size_t)mesh->n_elem) || tmp.alloc(&d_mtab, tab.size())) return FX_ERROR_RUNTIME;
+    HIP_TRY(hipMemcpyAsync(d_emat, elem_mat, (size_t)mesh->n_elem * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_mtab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // tab is a host temporary
+  } else {
+    elastic_constants(E, nu, D11, D12, D44);
+  }
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
   // hecmw_mat_clear (fstr_StiffMatrix.f90:40)
   HIP_TRY(hipMemsetAsync(A.D, 0, (size_t)9 * A.NP * 8, c->stream));
   HIP_TRY(hipMemsetAsync(A.AL, 0, (size_t)9 * A.NPL * 8, c->stream));
   HIP_TRY(hipMemsetAsync(A.AU, 0, (size_t)9 * A.NPU * 8, c->stream));
-  if (elemopt == 1) launch_assemble<1>(c, mesh->n_elem, d_coord, d_conn, D11, D12, D44, nullptr, d_err);
-  else if (elemopt == 2) launch_assemble<2>(c, mesh->n_elem, d_coord, d_conn, D11, D12, D44, nullptr, d_err);
-  else launch_assemble<3>(c, mesh->n_elem, d_coord, d_conn, D11, D12, D44, nullptr, d_err);
+  if (elemopt == 1) launch_assemble<1>(c, mesh->n_elem, d_coord, d_conn, D11, D12, D44, nullptr, d_err, d_emat, d_mtab);
+  else if (elemopt == 2) launch_assemble<2>(c, mesh->n_elem, d_coord, d_conn, D11, D12, D44, nullptr, d_err, d_emat, d_mtab);
+  else launch_assemble<3>(c, mesh->n_elem, d_coord, d_conn, D11, D12, D44, nullptr, d_err, d_emat, d_mtab);
   HIP_TRY(hipGetLastError());
   if (load) HIP_TRY(hipMemcpyAsync(A.B, load, (size_t)3 * A.NP * 8, hipMemcpyHostToDevice, c->stream));
   else HIP_TRY(hipMemsetAsync(A.B, 0, (size_t)3 * A.NP * 8, c->stream));
@@ -142,6 +157,22 @@ extern "C" int fx_assemble_c3d8(fx_context *c, const fx_mesh_view *mesh, double 
   return 0;
 }
 
+extern "C" int fx_assemble_c3d8(fx_context *c, const fx_mesh_view *mesh, double E, double nu, int elemopt, const double *load,
+                                int32_t n_bc, const int32_t *bc_node, const int32_t *bc_dof, const double *bc_val,
+                                float *ms_assemble) {
+  return assemble_c3d8_common(c, mesh, E, nu, 0, nullptr, nullptr, nullptr, elemopt, load, n_bc, bc_node, bc_dof, bc_val,
+                              ms_assemble);
+}
+
+extern "C" int fx_assemble_c3d8_sections(fx_context *c, const fx_mesh_view *mesh, int32_t n_mat, const double *E, const double *nu,
+                                         const int32_t *elem_mat, int elemopt, const double *load, int32_t n_bc,
+                                         const int32_t *bc_node, const int32_t *bc_dof, const double *bc_val,
+                                         float *ms_assemble) {
+  if (n_mat < 1 || !E || !nu || !elem_mat) { g_fx_error = "fx_assemble_c3d8_sections: materials missing"; return FX_ERROR_RUNTIME; }
+  return assemble_c3d8_common(c, mesh, 0.0, 0.0, n_mat, E, nu, elem_mat, elemopt, load, n_bc, bc_node, bc_dof, bc_val,
+                              ms_assemble);
+}
+
 extern "C" int fx_element_stiffness_c3d8(fx_context *c, int elemopt, const double *ecoord, double E, double nu, double *stiff) {
   HIP_TRY(hipSetDevice(c->device));
   DevScratch tmp;
@@ -158,7 +189,7 @@ extern "C" int fx_element_stiffness_c3d8(fx_context *c, int elemopt, const doubl
   double *nud = nullptr;
 #define ONE(EO)                                                                                                         \
   hipLaunchKernelGGL((k_assemble_c3d8<EO>), dim3(1), dim3(FXA_BLOCK), 0, c->stream, 1, d_coord, d_conn, D11, D12, D44, nul, \
-                     nul, nul, nul, nud, nud, nud, d_k, d_err)
+                     nul, nul, nul, nud, nud, nud, d_k, d_err, nul, (const double *)nullptr)
   if (elemopt == 1) ONE(1);
   else if (elemopt == 2) ONE(2);
   else if (elemopt == 3) ONE(3);

@@ -266,7 +266,8 @@ class SolverContext:
         _chk(lib().fx_dot_host(self.h, _ptr(x), _ptr(y), C.byref(out)))
         return out.value
 
-    def assemble_c3d8(self, coord, conn, E, nu, elemopt=1, load=None, bc=None):
+    def assemble_c3d8(self, coord, conn, E, nu, elemopt=1, load=None, bc=None, sections=None):
+        """fstr_StiffMatrix + fstr_AddBC on the device.  sections = (E[], nu[], elem_mat[] 1-based): several materials."""
         coord = np.ascontiguousarray(coord, dtype=np.float64)
         conn = np.ascontiguousarray(conn, dtype=np.int32)
         mv = _MeshView(coord.shape[0], conn.shape[0], _ptr(coord), _ptr(conn))
@@ -278,6 +279,13 @@ class SolverContext:
             bv = np.ascontiguousarray(bc[2], dtype=np.float64)
         load = None if load is None else np.ascontiguousarray(load, dtype=np.float64)
         ms = C.c_float(0)
+        if sections is not None:
+            Es = np.ascontiguousarray(sections[0], dtype=np.float64)
+            nus = np.ascontiguousarray(sections[1], dtype=np.float64)
+            em = np.ascontiguousarray(sections[2], dtype=np.int32)
+            _chk(lib().fx_assemble_c3d8_sections(self.h, C.byref(mv), int(Es.size), _ptr(Es), _ptr(nus), _ptr(em), int(elemopt),
+                                                 _ptr(load), int(bn.size), _ptr(bn), _ptr(bd), _ptr(bv), C.byref(ms)))
+            return ms.value
         _chk(lib().fx_assemble_c3d8(self.h, C.byref(mv), C.c_double(E), C.c_double(nu), int(elemopt), _ptr(load),
                                     int(bn.size), _ptr(bn), _ptr(bd), _ptr(bv), C.byref(ms)))
         return ms.value

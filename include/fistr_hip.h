@@ -158,6 +158,12 @@ typedef struct fx_mesh_view {
 int fx_assemble_c3d8(fx_context *ctx, const fx_mesh_view *mesh, double E, double nu, int elemopt,
                      const double *load, int32_t n_bc, const int32_t *bc_node,
                      const int32_t *bc_dof, const double *bc_val, float *ms_assemble);
+/* The same for a group whose elements belong to several sections / materials (hecMESH%section_ID ->
+ * fstrSOLID%materials, fstr_setup.f90:325-400): elem_mat[e] in 1..n_mat selects (E[m-1], nu[m-1]). */
+int fx_assemble_c3d8_sections(fx_context *ctx, const fx_mesh_view *mesh, int32_t n_mat, const double *E,
+                              const double *nu, const int32_t *elem_mat, int elemopt, const double *load,
+                              int32_t n_bc, const int32_t *bc_node, const int32_t *bc_dof,
+                              const double *bc_val, float *ms_assemble);
 /* One element stiffness through the device kernel (tests): ecoord 8x3, stiff 24x24 row-major. */
 int fx_element_stiffness_c3d8(fx_context *ctx, int elemopt, const double *ecoord, double E, double nu,
                               double *stiff);

@@ -1214,6 +1214,25 @@ void orc_mat_ass_bc(int32_t NP, const int32_t *indexL, const int32_t *itemL, con
 }
 
 /* fstr_StiffMatrix element loop, fstr_StiffMatrix.f90:40 (clear) + :58-207 */
+/* the same loop with several sections: material of element e = (E[elem_mat[e]-1], nu[...]) as
+ * fstrSOLID%elements(icel)%gausses(:)%pMaterial => fstrSOLID%materials(section material) (fstr_setup.f90:325-400) */
+void orc_assemble_c3d8_sections(int elemopt, int32_t NP, int32_t n_elem, const double *coord, const int32_t *conn,
+                                const double *E, const double *nu, const int32_t *elem_mat, const int32_t *indexL,
+                                const int32_t *itemL, const int32_t *indexU, const int32_t *itemU, double *D,
+                                double *AL, double *AU) {
+  memset(D, 0, (size_t)9 * NP * sizeof(double));
+  memset(AL, 0, (size_t)9 * indexL[NP] * sizeof(double));
+  memset(AU, 0, (size_t)9 * indexU[NP] * sizeof(double));
+  for (int32_t e = 0; e < n_elem; e++) {
+    double ec[24], stiff[576];
+    const int32_t *nod = &conn[(size_t)8 * e];
+    for (int j = 0; j < 8; j++)
+      for (int d = 0; d < 3; d++) ec[3 * j + d] = coord[3 * (size_t)(nod[j] - 1) + d];
+    orc_stf_c3d8(elemopt, ec, E[elem_mat[e] - 1], nu[elem_mat[e] - 1], stiff);
+    orc_mat_ass_elem(NP, indexL, itemL, indexU, itemU, D, AL, AU, 8, nod, stiff);
+  }
+}
+
 void orc_assemble_c3d8(int elemopt, int32_t NP, int32_t n_elem, const double *coord,
                        const int32_t *conn, double E, double nu, const int32_t *indexL,
                        const int32_t *itemL, const int32_t *indexU, const int32_t *itemU, double *D,

@@ -109,6 +109,11 @@ void orc_assemble_c3d8(int elemopt, int32_t NP, int32_t n_elem, const double *co
                        const int32_t *itemL, const int32_t *indexU, const int32_t *itemU, double *D,
                        double *AL, double *AU);
 
+void orc_assemble_c3d8_sections(int elemopt, int32_t NP, int32_t n_elem, const double *coord, const int32_t *conn,
+                                const double *E, const double *nu, const int32_t *elem_mat, const int32_t *indexL,
+                                const int32_t *itemL, const int32_t *indexU, const int32_t *itemU, double *D,
+                                double *AL, double *AU);
+
 /* ---- Nonlinear (elastoplastic) C3D8 B-bar path: restated in fstr_nl_oracle.c ---- */
 typedef struct {
   double E, nu;

@@ -167,8 +167,9 @@ def stf_c3d8(elemopt, ecoord, E, nu):
     return k
 
 
-def assemble(elemopt, coord, conn, E, nu, bc=None, load=None):
-    """Profile + element loop + Dirichlet BC, returning a refrun.BSR-like object."""
+def assemble(elemopt, coord, conn, E, nu, bc=None, load=None, sections=None):
+    """Profile + element loop + Dirichlet BC, returning a refrun.BSR-like object.  sections = (E[], nu[], elem_mat[]
+    1-based) assembles several materials (E, nu ignored)."""
     from .refrun import BSR
     coord = np.ascontiguousarray(coord, dtype=np.float64)
     conn = np.ascontiguousarray(conn, dtype=np.int32)
@@ -177,9 +178,16 @@ def assemble(elemopt, coord, conn, E, nu, bc=None, load=None):
     D = np.zeros(9 * NP)
     AL = np.zeros(9 * max(itemL.size, 1))
     AU = np.zeros(9 * max(itemU.size, 1))
-    lib().orc_assemble_c3d8(elemopt, NP, conn.shape[0], _dp(coord), _ip(conn), C.c_double(E),
-                            C.c_double(nu), _ip(indexL), _ip(itemL), _ip(indexU), _ip(itemU),
-                            _dp(D), _dp(AL), _dp(AU))
+    if sections is None:
+        lib().orc_assemble_c3d8(elemopt, NP, conn.shape[0], _dp(coord), _ip(conn), C.c_double(E),
+                                C.c_double(nu), _ip(indexL), _ip(itemL), _ip(indexU), _ip(itemU),
+                                _dp(D), _dp(AL), _dp(AU))
+    else:
+        Es = np.ascontiguousarray(sections[0], dtype=np.float64)
+        nus = np.ascontiguousarray(sections[1], dtype=np.float64)
+        em = np.ascontiguousarray(sections[2], dtype=np.int32)
+        lib().orc_assemble_c3d8_sections(elemopt, NP, conn.shape[0], _dp(coord), _ip(conn), _dp(Es), _dp(nus), _ip(em),
+                                         _ip(indexL), _ip(itemL), _ip(indexU), _ip(itemU), _dp(D), _dp(AL), _dp(AU))
     B = np.zeros(3 * NP) if load is None else np.ascontiguousarray(load, dtype=np.float64).copy()
     if bc is not None:
         node, dof, val = bc

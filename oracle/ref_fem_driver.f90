@@ -12,6 +12,8 @@
 !>          real64 coord(3*n_node); int32 conn(8*n_elem) (1-based)
 !>          int32 bc_node(n_bc) bc_dof(n_bc); real64 bc_val(n_bc)
 !>          real64 B0(3*n_node)
+!>          elemopt > 10 (= 10 + formulation): several sections follow -- int32 n_mat ; real64 E(n_mat) nu(n_mat) ;
+!>          int32 elem_mat(n_elem) (1-based material of each element, as hecMESH%section_ID -> fstrSOLID%materials)
 !> out.bin: int32 N NP NPL NPU; int32 indexL(0:NP) indexU(0:NP) itemL itemU
 !>          real64 D AL AU B ; real64 stiff_first_element(24,24) (column major)
 !>          real64 t_assemble
@@ -29,6 +31,10 @@ program ref_fem
   type(hecmwST_local_mesh) :: hecMESH
   type(hecmwST_matrix)     :: hecMAT
   type(tMaterial), target  :: matl
+  type(tMaterial), allocatable, target :: mats(:)
+  integer(kind=4), allocatable :: elem_mat(:)
+  real(kind=8), allocatable :: Es(:), nus(:)
+  integer(kind=4) :: n_mat
   type(tGaussStatus)       :: gausses(8)
   character(len=1024) :: fin, fout
   integer(kind=4) :: magic, elemopt, n_node, n_elem, n_bc, u, icel, j, i, k
@@ -51,6 +57,22 @@ program ref_fem
   read(u) bc_dof
   read(u) bc_val
   read(u) B0
+  n_mat = 0
+  if (elemopt > 10) then
+    elemopt = elemopt - 10
+    read(u) n_mat
+    allocate(Es(n_mat), nus(n_mat), elem_mat(n_elem), mats(n_mat))
+    read(u) Es
+    read(u) nus
+    read(u) elem_mat
+    do i = 1, n_mat
+      call initMaterial(mats(i))
+      mats(i)%mtype = ELASTIC
+      mats(i)%nlgeom_flag = INFINITE
+      mats(i)%variables(M_YOUNGS) = Es(i)
+      mats(i)%variables(M_POISSON) = nus(i)
+    enddo
+  endif
   close(u)
 
   call hecmw_nullify_mesh(hecMESH)
@@ -96,6 +118,11 @@ program ref_fem
         ecoord(i,j) = coord(3*nodLOCAL(j)+i-3)
       enddo
     enddo
+    if (n_mat > 0) then
+      do i = 1, 8
+        gausses(i)%pMaterial => mats(elem_mat(icel))
+      enddo
+    endif
     select case (elemopt)
     case (1)
       call STF_C3D8IC(361, 8, ecoord, gausses, stiff, 0, coords, 0.d0, 0.d0)

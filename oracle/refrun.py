@@ -156,8 +156,9 @@ def run_solve(m, I, R, mode=1, threads=1, nrepeat=1, workdir=None, timeout=None,
     return info
 
 
-def run_fem(coord, conn, E, nu, bc_node, bc_dof, bc_val, B0, elemopt=1, workdir=None):
-    """Reference profile + element stiffness + assembly + Dirichlet BC."""
+def run_fem(coord, conn, E, nu, bc_node, bc_dof, bc_val, B0, elemopt=1, workdir=None, sections=None):
+    """Reference profile + element stiffness + assembly + Dirichlet BC.  sections = (E[], nu[], elem_mat[] 1-based):
+    several materials, E / nu arguments ignored."""
     exe = os.path.join(REFDIR, "ref_fem")
     if not os.path.exists(exe):
         raise FileNotFoundError(exe)
@@ -165,7 +166,7 @@ def run_fem(coord, conn, E, nu, bc_node, bc_dof, bc_val, B0, elemopt=1, workdir=
     with tempfile.TemporaryDirectory(dir=workdir) as td:
         fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
         with open(fin, "wb") as f:
-            np.array([MAGIC_FEM, elemopt, n_node, n_elem, len(bc_node)], dtype=np.int32).tofile(f)
+            np.array([MAGIC_FEM, elemopt + (10 if sections is not None else 0), n_node, n_elem, len(bc_node)], dtype=np.int32).tofile(f)
             np.array([E, nu], dtype=np.float64).tofile(f)
             np.ascontiguousarray(coord, dtype=np.float64).tofile(f)
             np.ascontiguousarray(conn, dtype=np.int32).tofile(f)
@@ -173,6 +174,12 @@ def run_fem(coord, conn, E, nu, bc_node, bc_dof, bc_val, B0, elemopt=1, workdir=
             np.ascontiguousarray(bc_dof, dtype=np.int32).tofile(f)
             np.ascontiguousarray(bc_val, dtype=np.float64).tofile(f)
             np.ascontiguousarray(B0, dtype=np.float64).tofile(f)
+            if sections is not None:
+                Es, nus, em = sections
+                np.array([len(Es)], dtype=np.int32).tofile(f)
+                np.ascontiguousarray(Es, dtype=np.float64).tofile(f)
+                np.ascontiguousarray(nus, dtype=np.float64).tofile(f)
+                np.ascontiguousarray(em, dtype=np.int32).tofile(f)
         p = subprocess.run([exe, fin, fout], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if p.returncode != 0 or not os.path.exists(fout):
             raise RuntimeError("ref_fem failed: " + p.stdout)

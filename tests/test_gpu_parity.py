@@ -237,6 +237,35 @@ def test_assembly_vs_reference_golden(hip, deck, eo, tag):
     ctx.close()
 
 
+@pytest.mark.parametrize("eo,tag", [(1, "ic_"), (2, "bbar_"), (3, "fi_")])
+def test_assembly_several_sections(hip, eo, tag):
+    """Three sections / materials: fx_assemble_c3d8_sections against the reference's assembly and its CG + SSOR answer."""
+    g, s = load_golden("cube3s"), load_golden("sections_cube3s")
+    ctx = hip.SolverContext()
+    mesh = hip.hecmwST_local_mesh(n_node=g["coord"].shape[0])
+    mesh.elem_node_item = g["conn"].ravel()
+    m = hip.hecmw_mat_con(mesh, hip.hecmwST_matrix())
+    ctx.upload(m, what=hip.FX_UP_PROFILE)
+    ctx.assemble_c3d8(g["coord"], g["conn"], 0.0, 0.0, elemopt=eo, load=g["load"], bc=(g["bc_node"], g["bc_dof"], g["bc_val"]),
+                      sections=(s["E"], s["nu"], s["elem_mat"]))
+    ctx.download_matrix(m)
+    scale = np.abs(s[tag + "D"]).max()
+    for k in ("D", "AL", "AU"):
+        assert np.abs(getattr(m, k) - s[tag + k]).max() < 1e-12 * scale, k
+    assert np.abs(m.B - s[tag + "B"]).max() < 1e-12 * max(np.abs(s[tag + "B"]).max(), 1.0)
+    if eo == 1:
+        m.Iarray[0], m.Iarray[1], m.Iarray[2] = 1000, 1, 1
+        assert ctx.solve_resident(m) == 0
+        ctx.download_x(m)
+        assert abs(ctx.info.iterations - int(s["ic_iter"])) <= 1
+        assert relerr(m.X, s["ic_X"]) < 1e-6
+    with pytest.raises(Exception):    # a material id outside 1..n_mat is refused on the host, nothing is launched
+        bad = s["elem_mat"].copy()
+        bad[3] = 4
+        ctx.assemble_c3d8(g["coord"], g["conn"], 0.0, 0.0, elemopt=eo, sections=(s["E"], s["nu"], bad))
+    ctx.close()
+
+
 def test_assembly_nonzero_dirichlet(hip, oracle):
     """Prescribed non-zero displacement: the RHS fix-up of hecmw_mat_ass_bc (:307-319, :356-372)."""
     from frontistr_amd.mesh import CubeMesh

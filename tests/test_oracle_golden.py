@@ -24,6 +24,21 @@ def test_assembly_bit_exact(oracle, deck, eo, tag):
         assert np.array_equal(getattr(A, k), g[tag + k]), k
 
 
+@pytest.mark.parametrize("eo,tag", [(1, "ic_"), (2, "bbar_"), (3, "fi_")])
+def test_assembly_several_sections_bit_exact(oracle, eo, tag):
+    """Three sections / materials in one element group (tests/golden/make_sections_golden.py)."""
+    g, s = load_golden("cube3s"), load_golden("sections_cube3s")
+    A = oracle.assemble(eo, g["coord"], g["conn"], 0.0, 0.0, bc=(g["bc_node"], g["bc_dof"], g["bc_val"]), load=g["load"],
+                        sections=(s["E"], s["nu"], s["elem_mat"]))
+    for k in ("D", "AL", "AU", "B"):
+        assert np.array_equal(getattr(A, k), s[tag + k]), k
+    # one section through the sections entry == the uniform entry
+    one = oracle.assemble(eo, g["coord"], g["conn"], 0.0, 0.0, sections=([float(g["E"])], [float(g["nu"])],
+                                                                          np.ones(g["conn"].shape[0], dtype=np.int32)))
+    uni = oracle.assemble(eo, g["coord"], g["conn"], float(g["E"]), float(g["nu"]))
+    assert np.array_equal(one.D, uni.D) and np.array_equal(one.AL, uni.AL) and np.array_equal(one.AU, uni.AU)
+
+
 @pytest.mark.parametrize("deck", DECKS)
 @pytest.mark.parametrize("meth,pc,thr", CONFIGS)
 def test_solver_matches_reference(oracle, deck, meth, pc, thr):
