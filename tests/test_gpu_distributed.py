@@ -1,8 +1,9 @@
 """N > 1 path of the HIP library on ONE GPU: 2 (and 4) ranks share cuda:0 and exchange halos /
 reduce scalars through the host-callback transport (gloo), so the library's pack/unpack,
 import/export handling, nn_internal dot products and reduction placement are checked against
-the serial oracle.  (RCCL itself refuses two ranks on one device; its calls are the only part of
-the multi-GPU path this test cannot reach.)"""
+the serial oracle.  RCCL itself refuses two ranks on one device, so its calls are driven with a 1-rank
+communicator: the in-stream ncclAllReduce (FX_FORCE_COMM) and the grouped ncclSend / ncclRecv halo update
+against the rank itself (test_rccl_self_neighbour_halo_exchange)."""
 import numpy as np
 import pytest
 
@@ -59,6 +60,88 @@ print('rccl ok', ctx.info.iterations)
     p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        text=True, timeout=600)
     assert p.returncode == 0 and "rccl ok" in p.stdout, p.stdout[-3000:]
+
+
+def test_rccl_self_neighbour_halo_exchange(tmp_path):
+    """The grouped ncclSend / ncclRecv halo update (halo_update: pack -> send/recv -> unpack, all in-stream) driven on ONE GPU:
+    a 1-rank communicator whose only neighbour is the rank itself (periodic tables: halo node k receives internal node
+    export_item[k]).  hecmw_matvec and a 30-iteration BiCGSTAB through RCCL are compared with numpy and with the
+    host-callback transport on the same tables; the tables are also split into two messages to check the offsets."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r"""
+import ctypes as C, os, sys
+sys.path.insert(0, %r)
+import numpy as np
+from frontistr_amd import hecmw as hip
+from frontistr_amd.partition import cube_subdomain
+sub = cube_subdomain(7, (2, 1, 1), 0)
+hm = sub.hecmesh(hip)
+hm.elem_node_item = sub.conn.ravel()
+m = hip.hecmw_mat_con(hm, hip.hecmwST_matrix())
+N, NP = m.N, m.NP
+rng = np.random.default_rng(5)
+m.D = rng.standard_normal(9 * NP); m.AL = 0.1 * rng.standard_normal(9 * m.NPL); m.AU = 0.1 * rng.standard_normal(9 * m.NPU)
+m.D.reshape(NP, 3, 3)[:] += 6.0 * np.eye(3)
+m.B = rng.standard_normal(3 * NP); m.X = np.zeros(3 * NP)
+n_imp = NP - N
+assert n_imp > 0 and np.array_equal(np.sort(hm.import_item), np.arange(N + 1, NP + 1))
+exp_item = (1 + rng.permutation(N)[:n_imp]).astype(np.int32)
+
+def tables(nmsg):
+    cut = np.linspace(0, n_imp, nmsg + 1).astype(np.int32)
+    hm.my_rank, hm.PETOT, hm.n_neighbor_pe = 0, 1, nmsg
+    hm.neighbor_pe = np.zeros(nmsg, dtype=np.int32)
+    hm.import_index = cut.copy(); hm.export_index = cut.copy()
+    hm.export_item = exp_item
+
+def dense_apply(x):
+    xf = x.copy().reshape(NP, 3)
+    xf[hm.import_item - 1] = xf[exp_item - 1]
+    y = np.einsum('nij,nj->ni', m.D.reshape(NP, 3, 3)[:N], xf[:N])
+    for i in range(N):
+        for j in range(m.indexL[i], m.indexL[i + 1]):
+            y[i] += m.AL[9 * j:9 * j + 9].reshape(3, 3) @ xf[m.itemL[j] - 1]
+        for j in range(m.indexU[i], m.indexU[i + 1]):
+            y[i] += m.AU[9 * j:9 * j + 9].reshape(3, 3) @ xf[m.itemU[j] - 1]
+    return y.ravel()
+
+HALO = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
+ARED = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int, C.c_void_p)
+def _halo(send, recv, _u):
+    C.memmove(recv, send, 8 * 3 * n_imp)
+cbs = (HALO(_halo), ARED(lambda v, n, u: None))
+
+X = rng.standard_normal(3 * NP)
+ref = dense_apply(X)
+res = {}
+for nmsg in (1, 2):
+    tables(nmsg)
+    for transport in ('rccl', 'host'):
+        ctx = hip.SolverContext()
+        if transport == 'rccl':
+            ctx.comm_init(hip.comm_unique_id(), 0, 1)
+        else:
+            assert hip.lib().fx_comm_set_host_callbacks(ctx.h, 0, 1, cbs[0], cbs[1], None) == 0
+        Y = np.zeros(3 * NP)
+        hip.hecmw_matvec(hm, m, X.copy(), Y, ctx=ctx)
+        assert np.abs(Y[:3 * N] - ref).max() < 1e-12 * np.abs(ref).max(), (nmsg, transport)
+        m.Iarray[0], m.Iarray[1], m.Iarray[2] = 30, 2, 3
+        m.Rarray[0] = 1e-30
+        m.X[:] = 0.0
+        hip.hecmw_solve(hm, m, ctx=ctx)
+        res[(nmsg, transport)] = (ctx.history.copy(), m.X.copy())
+        ctx.close()
+    h1, x1 = res[(nmsg, 'rccl')]; h2, x2 = res[(nmsg, 'host')]
+    assert len(h1) == len(h2) >= 30 and np.allclose(h1, h2, rtol=1e-9), (h1[:5], h2[:5])
+    assert np.abs(x1 - x2).max() <= 1e-9 * np.abs(x2).max()
+assert np.allclose(res[(1, 'rccl')][0], res[(2, 'rccl')][0], rtol=1e-9)
+print('self halo ok', len(res[(1, 'rccl')][0]), res[(1, 'rccl')][0][-1])
+""" % (ROOT,)
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0 and "self halo ok" in p.stdout, p.stdout[-3000:]
 
 
 def test_hip_on_reference_partitioner_files(oracle, tmp_path):
