@@ -9,7 +9,8 @@
 !> forwards them over the C ABI of include/fistr_hip.h; messages and abort policy follow
 !> hecmw_solve_error (hecmw1/src/solver/init/hecmw_solve_error.f90:19-83).
 !>
-!> HECMW_GPU=0 in the environment keeps the original CPU path (hecmw_solve_iterative).
+!> HECMW_GPU=0 in the environment keeps the original CPU path (hecmw_solve_iterative); configurations outside the
+!> GPU path abort unless HECMW_GPU_UNSUPPORTED=reference asks for the reference's CPU solver for them.
 module hecmw_solver
   use iso_c_binding
   implicit none
@@ -72,20 +73,34 @@ contains
     real(kind=kreal), allocatable, target :: hist(:)
     integer(kind=kint) :: ierr, i, nhist, precond
     character(len=8) :: env
+    character(len=16) :: envu
     integer :: elen, estat
 
-    ! Explicit opt-out (HECMW_GPU=0) and everything outside the GPU hot path -- other block sizes, direct solvers,
-    ! MPC / contact matrices, preconditioners other than SSOR / DIAG / ILU(0) -- stay with the reference's own CPU
-    ! code, and say so: the routing is never silent.
+    ! Explicit opt-out: HECMW_GPU=0 keeps the reference's own CPU solver for every call, and says so.
+    ! Configurations outside the GPU hot path -- other block sizes, direct solvers, MPC / contact matrices,
+    ! preconditioners other than SSOR / DIAG / ILU(0) -- are REFUSED (E-message + abort), unless the user has asked for
+    ! the reference's CPU code for exactly those with HECMW_GPU_UNSUPPORTED=reference.  Nothing is routed silently and
+    ! nothing is routed by default.
     call get_environment_variable('HECMW_GPU', env, elen, estat)
     precond = hecMAT%Iarray(3)
-    if ((estat == 0 .and. elen > 0 .and. env(1:1) == '0') .or. hecMAT%NDOF /= 3 .or. &
-        hecMAT%Iarray(99) /= 1 .or. hecMESH%mpc%n_mpc > 0 .or. hecMAT%cmat%n_val > 0 .or. &
-        .not. (precond == 1 .or. precond == 2 .or. precond == 3 .or. precond == 10)) then
-      if (hecMESH%my_rank == 0) write(*,'(a,i0,a,i0,a)') '### libfistr_hip: reference CPU solver used (NDOF=', &
-        hecMAT%NDOF, ', PRECOND=', precond, ', HECMW_GPU / MPC / contact / direct: see INTEGRATION.md)'
+    if (estat == 0 .and. elen > 0 .and. env(1:1) == '0') then
+      if (hecMESH%my_rank == 0) write(*,'(a)') '### libfistr_hip: reference CPU solver used (HECMW_GPU=0)'
       call hecmw_solve_iterative(hecMESH, hecMAT)
       return
+    endif
+    if (hecMAT%NDOF /= 3 .or. hecMAT%Iarray(99) /= 1 .or. hecMESH%mpc%n_mpc > 0 .or. hecMAT%cmat%n_val > 0 .or. &
+        .not. (precond == 1 .or. precond == 2 .or. precond == 3 .or. precond == 10)) then
+      call get_environment_variable('HECMW_GPU_UNSUPPORTED', envu, elen, estat)
+      if (estat == 0 .and. elen >= 9 .and. envu(1:9) == 'reference') then
+        if (hecMESH%my_rank == 0) write(*,'(a,i0,a,i0,a)') '### libfistr_hip: reference CPU solver used (NDOF=', &
+          hecMAT%NDOF, ', PRECOND=', precond, ', MPC / contact / direct: HECMW_GPU_UNSUPPORTED=reference)'
+        call hecmw_solve_iterative(hecMESH, hecMAT)
+        return
+      endif
+      if (hecMESH%my_rank == 0) write(*,'(a,i0,a,i0,a,i0,a)') '#### libfistr_hip-E: not on the GPU path (NDOF=', hecMAT%NDOF, &
+        ', PRECOND=', precond, ', solver type=', hecMAT%Iarray(99), &
+        ', MPC / contact); set HECMW_GPU_UNSUPPORTED=reference to run these on the reference CPU solver'
+      call hecmw_abort(hecmw_comm_get_comm())
     endif
 
     if (.not. c_associated(fx_ctx)) then

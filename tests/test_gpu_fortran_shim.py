@@ -46,3 +46,17 @@ def test_shim_cpu_escape_hatch():
     r = refrun.run_solve(A, I, R, exe_name="shim_solve", extra_env={"HECMW_GPU": "0"})
     assert "reference CPU solver used" in r["stdout"]        # announced, never silent
     assert np.array_equal(r["X"], g["sol_m1_p3_t1_X"])      # bit-for-bit the reference
+
+
+def test_shim_refuses_what_is_not_on_the_gpu_path():
+    """A preconditioner outside SSOR / DIAG / ILU(0) is refused (abort) -- no default CPU routing -- and runs on the reference's
+    CPU solver only when HECMW_GPU_UNSUPPORTED=reference asks for that."""
+    from oracle import refrun
+    if not refrun.have_ref("shim_solve"):
+        pytest.skip("oracle/_ref/shim_solve not built")
+    A = golden_matrix(load_golden("cube4"))
+    I, R = refrun.default_params(method=1, precond=11)      # block ILU(1)
+    r = refrun.run_solve(A, I, R, exe_name="shim_solve")
+    assert "libfistr_hip-E: not on the GPU path" in r["stdout"] and "X" not in r     # hecmw_abort: no solution is written
+    r = refrun.run_solve(A, I, R, exe_name="shim_solve", extra_env={"HECMW_GPU_UNSUPPORTED": "reference"})
+    assert r["returncode"] == 0 and "reference CPU solver used" in r["stdout"] and r["Iarray"][80] == 1
