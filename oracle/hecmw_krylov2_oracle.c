@@ -28,9 +28,9 @@ static void gmres_update_x(const orc_matrix *A, const orc_comm *c, orc_precond *
 int orc_solve_gmres(const orc_matrix *A, const orc_comm *c, orc_precond *P, int iterPREmax, const double *B,
                     double *X, int MAXIT, double TOL, int NREST, int *iter_out, double *resid_out, double *hist,
                     int *nhist_out) {
-  int32_t N = A->N, NP = A->NP, NNDOF = 3 * N;
-  size_t len = (size_t)3 * NP;
-  if (NREST >= 3 * NP - 1) NREST = 3 * NP - 2;                              /* :88 */
+  int32_t N = A->N, NP = A->NP, NNDOF = ORC_ND(A) * N;
+  size_t len = (size_t)ORC_ND(A) * NP;
+  if (NREST >= ORC_ND(A) * NP - 1) NREST = ORC_ND(A) * NP - 2;                              /* :88 */
   const int NRK = NREST + 7;
   double *H = (double *)calloc((size_t)NRK * NRK, sizeof(double));
   double *S = (double *)calloc((size_t)NRK + 2, sizeof(double));            /* the leading entries of WW(:,S) */
@@ -43,11 +43,11 @@ int orc_solve_gmres(const orc_matrix *A, const orc_comm *c, orc_precond *P, int 
   int error = 0, ITER = 0, I = 0, nh = 0;
   double RESID = 0.0;
   orc_matresid_33(A, c, X, B, R);                                           /* :127 */
-  double BNRM2 = orc_inner_product(N, B, B, c);
+  double BNRM2 = dotn(NNDOF, B, B, c);
   if (BNRM2 == 0.0) { MAXIT = 0; RESID = 0.0; for (size_t i = 0; i < len; i++) X[i] = 0.0; }
   for (;;) { /* OUTER :158 */
     I = 0;
-    double DNRM2 = orc_inner_product(N, R, R, c);                           /* :167 */
+    double DNRM2 = dotn(NNDOF, R, R, c);                           /* :167 */
     if (DNRM2 == 0.0) break;
     double RNORM = sqrt(DNRM2), coef = 1.0 / RNORM;
     for (int32_t ik = 0; ik < NNDOF; ik++) V[1][ik] = R[ik] * coef;
@@ -59,11 +59,11 @@ int orc_solve_gmres(const orc_matrix *A, const orc_comm *c, orc_precond *P, int 
       orc_precond_apply(A, c, P, iterPREmax, V[I], ZQ, ZP);                 /* :195 */
       orc_matvec_33(A, c, ZQ, W);
       for (int K = 1; K <= I; K++) {                                        /* :207-214 modified Gram-Schmidt */
-        double val = orc_inner_product(N, W, V[K], c);
+        double val = dotn(NNDOF, W, V[K], c);
         for (int32_t ik = 0; ik < NNDOF; ik++) W[ik] = W[ik] - val * V[K][ik];
         HH(K, I) = val;
       }
-      double val = orc_inner_product(N, W, W, c);
+      double val = dotn(NNDOF, W, W, c);
       if (val == 0.0) break;                                                /* :217 */
       HH(I + 1, I) = sqrt(val);
       coef = 1.0 / HH(I + 1, I);
@@ -106,7 +106,7 @@ int orc_solve_gmres(const orc_matrix *A, const orc_comm *c, orc_precond *P, int 
     /* restart :311-351 (after an early `exit` of the inner loop the reference lands here as well) */
     gmres_update_x(A, c, P, iterPREmax, NNDOF, NREST, NRK, H, S, V, AV, ZQ, ZP, X);
     orc_matresid_33(A, c, X, B, R);
-    DNRM2 = orc_inner_product(N, R, R, c);
+    DNRM2 = dotn(NNDOF, R, R, c);
     if (I + 1 <= NRK) S[I + 1] = sqrt(DNRM2 / BNRM2);
     RESID = sqrt(DNRM2 / BNRM2);
     if (RESID <= TOL) break;
@@ -125,8 +125,8 @@ int orc_solve_gmres(const orc_matrix *A, const orc_comm *c, orc_precond *P, int 
 int orc_solve_gpbicg(const orc_matrix *A, const orc_comm *c, orc_precond *P, int iterPREmax, const double *B,
                      double *X, int MAXIT, double TOL, int *iter_out, double *resid_out, double *hist) {
   const int N_ITER_RECOMPUTE_R = 20;
-  int32_t N = A->N, NP = A->NP, NNDOF = 3 * N;
-  size_t len = (size_t)3 * NP;
+  int32_t N = A->N, NP = A->NP, NNDOF = ORC_ND(A) * N;
+  size_t len = (size_t)ORC_ND(A) * NP;
   double *WW = (double *)calloc(14 * len, sizeof(double));
   /* R=1 RT=2 T=3 TT=4 T0=5 P=6 PT=7 U=8 W1=9 Y=10 Z=11 WK=12 W2=13 ZQ=14 (:56-69) */
   double *R = WW, *RT = WW + len, *T = WW + 2 * len, *TT = WW + 3 * len, *T0 = WW + 4 * len, *Pv = WW + 5 * len,
@@ -136,16 +136,16 @@ int orc_solve_gpbicg(const orc_matrix *A, const orc_comm *c, orc_precond *P, int
   double RESID = 0.0, BETA = 0.0, ALPHA, QSI, ETA, RHO, RHO1, DNRM2, COEF1;
   orc_matresid_33(A, c, X, B, R);                                           /* :113 */
   for (int32_t i = 0; i < NNDOF; i++) RT[i] = R[i];
-  double BNRM2 = orc_inner_product(N, B, B, c);
+  double BNRM2 = dotn(NNDOF, B, B, c);
   if (BNRM2 == 0.0) { iter = 0; MAXIT = 0; RESID = 0.0; for (size_t i = 0; i < len; i++) X[i] = 0.0; }
-  RHO = orc_inner_product(N, RT, R, c);                                     /* :127 */
+  RHO = dotn(NNDOF, RT, R, c);                                     /* :127 */
   for (iter = 1; iter <= MAXIT; iter++) {
     for (int32_t j = 0; j < NNDOF; j++) WK[j] = R[j];                       /* :155-159 */
     orc_precond_apply(A, c, P, iterPREmax, WK, R, ZQ);
     if (iter > 1) for (int32_t j = 0; j < NNDOF; j++) Pv[j] = R[j] + BETA * (Pv[j] - U[j]); /* :166-174 */
     else for (int32_t j = 0; j < NNDOF; j++) Pv[j] = R[j];
     orc_matvec_33(A, c, Pv, PT);                                            /* :184 */
-    RHO1 = orc_inner_product(N, RT, PT, c);
+    RHO1 = dotn(NNDOF, RT, PT, c);
     ALPHA = RHO / RHO1;
     for (int32_t j = 0; j < NNDOF; j++) {                                   /* :197-200 */
       Y[j] = T[j] - WK[j] + ALPHA * (-W1[j] + PT[j]);
@@ -209,7 +209,7 @@ int orc_solve_gpbicg(const orc_matrix *A, const orc_comm *c, orc_precond *P, int
     if (RESID <= TOL) {                                                     /* :300-307 */
       if (iter % N_ITER_RECOMPUTE_R == 0) break;
       orc_matresid_33(A, c, X, B, R);
-      DNRM2 = orc_inner_product(N, R, R, c);
+      DNRM2 = dotn(NNDOF, R, R, c);
       RESID = sqrt(DNRM2 / BNRM2);
       if (RESID <= TOL) break;
     }

@@ -13,6 +13,8 @@
 
 /* 1-based views, Fortran style */
 #define F1(a, i) ((a)[(i)-1])
+#define ORC_ND(A) ((A)->ndof > 0 ? (A)->ndof : 3) /* hecMAT%NDOF; 0 = the 3x3 default of the older callers */
+void orc_matvec_nn(const orc_matrix *A, const orc_comm *c, double *X, double *Y);
 
 /* ------------------------------------------------------------------ */
 /* las                                                                  */
@@ -20,6 +22,7 @@
 
 /* hecmw_matvec_33_inner, hecmw_solver_las_33.f90:245 (halo) + :263-300 (loop) */
 void orc_matvec_33(const orc_matrix *A, const orc_comm *c, double *X, double *Y) {
+  if (ORC_ND(A) != 3) { orc_matvec_nn(A, c, X, Y); return; } /* hecmw_matvec: select case(NDOF), hecmw_solver_las.f90:57-77 */
   const int32_t N = A->N;
   const int32_t *indexL = A->indexL, *indexU = A->indexU, *itemL = A->itemL, *itemU = A->itemU;
   const double *D = A->D, *AL = A->AL, *AU = A->AU;
@@ -50,15 +53,18 @@ void orc_matvec_33(const orc_matrix *A, const orc_comm *c, double *X, double *Y)
 /* hecmw_matresid_33, hecmw_solver_las_33.f90:358-380 */
 void orc_matresid_33(const orc_matrix *A, const orc_comm *c, double *X, const double *B, double *R) {
   orc_matvec_33(A, c, X, R);
-  for (int32_t i = 0; i < 3 * A->N; i++) R[i] = B[i] - R[i];
+  for (int32_t i = 0; i < ORC_ND(A) * A->N; i++) R[i] = B[i] - R[i];
 }
 
-/* hecmw_InnerProduct_R, hecmw_solver_misc.f90:46-70: sequential sum + allreduce */
-double orc_inner_product(int32_t nn_internal, const double *X, const double *Y, const orc_comm *c) {
+/* hecmw_InnerProduct_R, hecmw_solver_misc.f90:46-70: sequential sum over NDOF*nn_internal entries + allreduce */
+static double dotn(int32_t n, const double *X, const double *Y, const orc_comm *c) {
   double sum = 0.0;
-  for (int32_t i = 0; i < 3 * nn_internal; i++) sum = sum + X[i] * Y[i];
+  for (int32_t i = 0; i < n; i++) sum = sum + X[i] * Y[i];
   if (c && c->allreduce) c->allreduce(&sum, 1, c->ctx);
   return sum;
+}
+double orc_inner_product(int32_t nn_internal, const double *X, const double *Y, const orc_comm *c) {
+  return dotn(3 * nn_internal, X, Y, c);
 }
 
 /* ------------------------------------------------------------------ */
@@ -265,6 +271,7 @@ static int32_t bsearch_1(const int32_t *array, int32_t istart, int32_t iend, int
 
 struct orc_precond {
   int kind; /* 1 SSOR, 3 DIAG, 10 ILU0 */
+  int ndof; /* 3: the _33 routines; anything else: the _nn restatement (hecmw_nn_oracle.c) */
   int32_t N, NP;
   /* DIAG / SSOR */
   double *ALU;
@@ -537,10 +544,19 @@ static void ilu_apply(const orc_precond *P, double *WW) {
 }
 
 /* hecmw_precond_33_setup dispatch, 33/hecmw_precond_33.f90:27-50 */
+#include "hecmw_nn_oracle.c" /* NDOF != 3: matvec, DIAG, SSOR */
+
 orc_precond *orc_precond_setup(const orc_matrix *A, int precond, double sigma_diag, int ncolor_in,
                                int nthreads) {
   orc_precond *P = (orc_precond *)calloc(1, sizeof(orc_precond));
-  P->N = A->N; P->NP = A->NP;
+  P->N = A->N; P->NP = A->NP; P->ndof = ORC_ND(A);
+  if (P->ndof != 3) { /* hecmw_precond_setup: select case(NDOF), hecmw_precond.f90:28-50 */
+    switch (precond) {
+      case 1: case 2: P->kind = 1; ssor_nn_setup(P, A, sigma_diag, ncolor_in, nthreads); return P;
+      case 3: P->kind = 3; diag_nn_setup(P, A, sigma_diag); return P;
+      default: free(P); return NULL; /* block ILU of the other sizes is not restated */
+    }
+  }
   switch (precond) {
     case 1: case 2: P->kind = 1; ssor_setup(P, A, sigma_diag, ncolor_in, nthreads); break;
     case 3: P->kind = 3; diag_setup(P, A, sigma_diag); break;
@@ -566,7 +582,7 @@ const int32_t *orc_precond_colorindex(const orc_precond *P) { return P->COLORind
 /* hecmw_precond_apply hecmw_precond.f90:75-123 + hecmw_precond_33_apply 33/..._33.f90:74-115 */
 void orc_precond_apply(const orc_matrix *A, const orc_comm *c, orc_precond *P, int iterPREmax,
                        double *R, double *Z, double *ZP) {
-  int32_t NNDOF = 3 * A->N, NPNDOF = 3 * A->NP;
+  int32_t NNDOF = ORC_ND(A) * A->N, NPNDOF = ORC_ND(A) * A->NP;
   if (iterPREmax <= 0) {
     for (int32_t i = 0; i < NNDOF; i++) Z[i] = R[i];
     return;
@@ -576,8 +592,8 @@ void orc_precond_apply(const orc_matrix *A, const orc_comm *c, orc_precond *P, i
   for (int32_t i = 0; i < NPNDOF; i++) Z[i] = 0.0;
   for (int iterPRE = 1; iterPRE <= iterPREmax; iterPRE++) {
     switch (P->kind) {
-      case 1: ssor_apply(P, ZP); break;
-      case 3: diag_apply(P, ZP); break;
+      case 1: if (P->ndof != 3) ssor_nn_apply(P, ZP); else ssor_apply(P, ZP); break;
+      case 3: if (P->ndof != 3) diag_nn_apply(P, ZP); else diag_apply(P, ZP); break;
       case 10: ilu_apply(P, ZP); break;
     }
     for (int32_t i = 0; i < NNDOF; i++) Z[i] = Z[i] + ZP[i]; /* additive Schwarz */
@@ -596,22 +612,22 @@ int orc_solve_cg(const orc_matrix *A, const orc_comm *c, orc_precond *P, int ite
                  const double *B, double *X, int MAXIT, double TOL, int *iter_out, double *resid_out,
                  double *hist) {
   const int N_ITER_RECOMPUTE_R = 50;
-  int32_t N = A->N, NP = A->NP, NNDOF = 3 * N;
-  size_t len = (size_t)3 * NP;
+  int32_t N = A->N, NP = A->NP, NNDOF = ORC_ND(A) * N;
+  size_t len = (size_t)ORC_ND(A) * NP;
   double *WW = (double *)calloc(4 * len, sizeof(double));
   double *R = WW, *Z = WW + len, *Q = WW + len, *Pv = WW + 2 * len, *WK = WW + 3 * len;
   int error = 0, n_indef_precond = 0, iter = 0;
   double RHO = 0, RHO1 = 0, BETA = 0, C1, ALPHA, DNRM2, RESID = 0;
 
   orc_matresid_33(A, c, X, B, R);                     /* :120 */
-  double BNRM2 = orc_inner_product(N, B, B, c);       /* :123 */
+  double BNRM2 = dotn(NNDOF, B, B, c);       /* :123 */
   if (BNRM2 == 0.0) {                                 /* :124-129 */
     iter = 0; MAXIT = 0; RESID = 0.0;
     for (size_t i = 0; i < len; i++) X[i] = 0.0;
   }
   for (iter = 1; iter <= MAXIT; iter++) {             /* :153 */
     orc_precond_apply(A, c, P, iterPREmax, R, Z, WK); /* :160 */
-    RHO = orc_inner_product(N, R, Z, c);              /* :168 */
+    RHO = dotn(NNDOF, R, Z, c);              /* :168 */
     if (RHO == 0.0) break;                            /* :170-172 */
     else if (iter > 1 && RHO * RHO1 <= 0) {           /* :173-180 */
       n_indef_precond++;
@@ -624,19 +640,19 @@ int orc_solve_cg(const orc_matrix *A, const orc_comm *c, orc_precond *P, int ite
       for (int32_t i = 0; i < NNDOF; i++) Pv[i] = Z[i] + BETA * Pv[i];
     }
     orc_matvec_33(A, c, Pv, Q);                       /* :204 */
-    C1 = orc_inner_product(N, Pv, Q, c);              /* :211 */
+    C1 = dotn(NNDOF, Pv, Q, c);              /* :211 */
     if (C1 <= 0) { error = ERR_DIVERGE_MAT; break; }  /* :213-217 */
     ALPHA = RHO / C1;
     for (int32_t i = 0; i < NNDOF; i++) X[i] = X[i] + ALPHA * Pv[i]; /* :227-230 */
     if (iter % N_ITER_RECOMPUTE_R == 0) orc_matresid_33(A, c, X, B, R); /* :232-233 */
     else for (int32_t i = 0; i < NNDOF; i++) R[i] = R[i] - ALPHA * Q[i];
-    DNRM2 = orc_inner_product(N, R, R, c);            /* :240 */
+    DNRM2 = dotn(NNDOF, R, R, c);            /* :240 */
     RESID = sqrt(DNRM2 / BNRM2);
     if (hist) hist[iter - 1] = RESID;                 /* :245 ITERLOG line */
     if (RESID <= TOL) {                               /* :259-266 */
       if (iter % N_ITER_RECOMPUTE_R == 0) break;
       orc_matresid_33(A, c, X, B, R);
-      DNRM2 = orc_inner_product(N, R, R, c);
+      DNRM2 = dotn(NNDOF, R, R, c);
       RESID = sqrt(DNRM2 / BNRM2);
       if (RESID <= TOL) break;
     }
@@ -655,8 +671,8 @@ int orc_solve_bicgstab(const orc_matrix *A, const orc_comm *c, orc_precond *P, i
                        const double *B, double *X, int MAXIT, double TOL, int *iter_out,
                        double *resid_out, double *hist) {
   const int N_ITER_RECOMPUTE_R = 100;
-  int32_t N = A->N, NP = A->NP, NNDOF = 3 * N;
-  size_t len = (size_t)3 * NP;
+  int32_t N = A->N, NP = A->NP, NNDOF = ORC_ND(A) * N;
+  size_t len = (size_t)ORC_ND(A) * NP;
   double *WW = (double *)calloc(8 * len, sizeof(double));
   /* R=1 RT=2 P=3 PT=4 S=5 ST=1 T=6 V=7 WK=8 (hecmw_solver_BiCGSTAB.f90:45-53) */
   double *R = WW, *RT = WW + len, *Pv = WW + 2 * len, *PT = WW + 3 * len, *S = WW + 4 * len;
@@ -666,13 +682,13 @@ int orc_solve_bicgstab(const orc_matrix *A, const orc_comm *c, orc_precond *P, i
 
   orc_matresid_33(A, c, X, B, R);
   for (int32_t i = 0; i < NNDOF; i++) RT[i] = R[i];
-  double BNRM2 = orc_inner_product(N, B, B, c);
+  double BNRM2 = dotn(NNDOF, B, B, c);
   if (BNRM2 == 0.0) {
     iter = 0; MAXIT = 0; RESID = 0.0;
     for (size_t i = 0; i < len; i++) X[i] = 0.0;
   }
   for (iter = 1; iter <= MAXIT; iter++) {
-    RHO = orc_inner_product(N, R, RT, c);                       /* :152 */
+    RHO = dotn(NNDOF, R, RT, c);                       /* :152 */
     if (iter > 1) {                                             /* :160-170 */
       BETA = (RHO / RHO1) * (ALPHA / OMEGA);
       for (int32_t i = 0; i < NNDOF; i++) Pv[i] = R[i] + BETA * (Pv[i] - OMEGA * V[i]);
@@ -681,7 +697,7 @@ int orc_solve_bicgstab(const orc_matrix *A, const orc_comm *c, orc_precond *P, i
     }
     orc_precond_apply(A, c, P, iterPREmax, Pv, PT, WK);         /* :177 */
     orc_matvec_33(A, c, PT, V);                                 /* :184 */
-    C2 = orc_inner_product(N, RT, V, c);                        /* :188 */
+    C2 = dotn(NNDOF, RT, V, c);                        /* :188 */
     ALPHA = RHO / C2;
     for (int32_t i = 0; i < NNDOF; i++) S[i] = R[i] - ALPHA * V[i]; /* :194-196 */
     /* ST aliases R (index 1): hecmw_solver_BiCGSTAB.f90:50 `ST= 1` */
@@ -698,13 +714,13 @@ int orc_solve_bicgstab(const orc_matrix *A, const orc_comm *c, orc_precond *P, i
     for (int32_t i = 0; i < NNDOF; i++) X[i] = X[i] + ALPHA * PT[i] + OMEGA * ST[i]; /* :231-233 */
     if (iter % N_ITER_RECOMPUTE_R == 0) orc_matresid_33(A, c, X, B, R);
     else for (int32_t i = 0; i < NNDOF; i++) R[i] = S[i] - OMEGA * T[i];
-    DNRM2 = orc_inner_product(N, R, R, c);
+    DNRM2 = dotn(NNDOF, R, R, c);
     RESID = sqrt(DNRM2 / BNRM2);
     if (hist) hist[iter - 1] = RESID;
     if (RESID <= TOL) {
       if (iter % N_ITER_RECOMPUTE_R == 0) break;
       orc_matresid_33(A, c, X, B, R);
-      DNRM2 = orc_inner_product(N, R, R, c);
+      DNRM2 = dotn(NNDOF, R, R, c);
       RESID = sqrt(DNRM2 / BNRM2);
       if (RESID <= TOL) break;
     }
@@ -762,19 +778,20 @@ int orc_solve_iterative(const orc_matrix *A, const orc_comm *c, const double *B,
   int auto_sigma_diag = 0, error = 0, ret = 0;
   if (SIGMA_DIAG < 0.0) { auto_sigma_diag = 1; SIGMA_DIAG = 1.0; }
   int32_t N = A->N, NP = A->NP;
+  const int nd = ORC_ND(A), NNDOF = nd * N;
   /* hecmw_solve_check_zerorhs :242-278 */
   {
     double rhs = 0.0;
-    for (int32_t i = 0; i < 3 * N; i++) rhs = rhs + B[i] * B[i];
+    for (int32_t i = 0; i < nd * N; i++) rhs = rhs + B[i] * B[i];
     if (c && c->allreduce) c->allreduce(&rhs, 1, c->ctx);
-    if (rhs == 0.0) { ret = 2002; for (int32_t i = 0; i < 3 * NP; i++) X[i] = 0.0; }
+    if (rhs == 0.0) { ret = 2002; for (int32_t i = 0; i < nd * NP; i++) X[i] = 0.0; }
   }
   /* hecmw_solve_check_zerodiag :212-240 */
   {
     double err = 0.0;
     for (int32_t i = 0; i < N; i++)
-      for (int j = 0; j < 3; j++)
-        if (fabs(A->D[9 * i + 4 * j]) == 0.0) err = 2001;
+      for (int j = 0; j < nd; j++)
+        if (fabs(A->D[(size_t)nd * nd * i + (nd + 1) * j]) == 0.0) err = 2001;
     if (c && c->allreduce) { /* MAX in the reference; flags are 0/2001 so SUM>0 is equivalent */
       c->allreduce(&err, 1, c->ctx);
     }
@@ -792,6 +809,7 @@ int orc_solve_iterative(const orc_matrix *A, const orc_comm *c, const double *B,
   /* SCALING=YES (Iarray(7)): every method scales first thing and un-scales last thing (CG.f90:104/:277 and the same
    * lines of the other three); the caller's arrays are left alone here, the solve runs on scaled copies */
   const int scaling = F1(Iarray, 7) != 0;
+  if (scaling && nd != 3) return 1001; /* hecmw_solver_scaling_nn is not restated */
   orc_matrix As = *A;
   double *sD = NULL, *sAL = NULL, *sAU = NULL, *sB = NULL, *scale = NULL;
   const orc_matrix *Aorig = A;
@@ -842,11 +860,11 @@ int orc_solve_iterative(const orc_matrix *A, const orc_comm *c, const double *B,
   if (error != 0) ret = error;
   /* hecmw_rel_resid_L2, hecmw_solver_las.f90:129-158 */
   {
-    double *r = (double *)calloc((size_t)3 * NP, sizeof(double));
-    double b2 = orc_inner_product(N, B, B, c);
+    double *r = (double *)calloc((size_t)nd * NP, sizeof(double));
+    double b2 = dotn(NNDOF, B, B, c);
     if (b2 == 0.0) b2 = 1.0;
     orc_matresid_33(A, c, X, B, r);
-    double r2 = orc_inner_product(N, r, r, c);
+    double r2 = dotn(NNDOF, r, r, c);
     double resid2 = sqrt(r2 / b2);
     if (resid2 < F1(Rarray, 1)) F1(Iarray, 81) = 1;
     free(r);

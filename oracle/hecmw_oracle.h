@@ -23,6 +23,7 @@ typedef struct {
   int32_t N, NP;
   const int32_t *indexL, *itemL, *indexU, *itemU; /* index: NP+1 entries; item: 1-based */
   const double *D, *AL, *AU;
+  int32_t ndof; /* hecMAT%NDOF; 0 = 3 */
 } orc_matrix;
 
 /* Optional communication hooks (multi-subdomain runs driven from Python over

@@ -19,7 +19,7 @@ class _Matrix(C.Structure):
     _fields_ = [("N", C.c_int32), ("NP", C.c_int32),
                 ("indexL", C.c_void_p), ("itemL", C.c_void_p),
                 ("indexU", C.c_void_p), ("itemU", C.c_void_p),
-                ("D", C.c_void_p), ("AL", C.c_void_p), ("AU", C.c_void_p)]
+                ("D", C.c_void_p), ("AL", C.c_void_p), ("AU", C.c_void_p), ("ndof", C.c_int32)]
 
 
 class _Comm(C.Structure):
@@ -61,7 +61,7 @@ def _ip(a):
 def cmatrix(m):
     """m: any object with N, NP, indexL, itemL, indexU, itemU, D, AL, AU (refrun.BSR)."""
     s = _Matrix(m.N, m.NP, _p(m.indexL), _p(m.itemL), _p(m.indexU), _p(m.itemU),
-                _p(m.D), _p(m.AL), _p(m.AU))
+                _p(m.D), _p(m.AL), _p(m.AU), int(getattr(m, "NDOF", 3)))
     s._keep = m
     return s
 
@@ -89,7 +89,7 @@ class Comm:
 
 def matvec(m, x, comm=None):
     x = np.ascontiguousarray(x, dtype=np.float64).copy()
-    y = np.zeros(3 * m.NP)
+    y = np.zeros(int(getattr(m, "NDOF", 3)) * m.NP)
     A = cmatrix(m)
     lib().orc_matvec_33(C.byref(A), comm.ref() if comm else None, _dp(x), _dp(y))
     return y
@@ -106,8 +106,8 @@ class Precond:
 
     def apply(self, r, iterpremax=1, comm=None):
         r = np.ascontiguousarray(r, dtype=np.float64).copy()
-        z = np.zeros(3 * self.m.NP)
-        zp = np.zeros(3 * self.m.NP)
+        z = np.zeros(int(getattr(self.m, "NDOF", 3)) * self.m.NP)
+        zp = np.zeros(z.size)
         lib().orc_precond_apply(C.byref(self.A), comm.ref() if comm else None, self.h, iterpremax,
                                 _dp(r), _dp(z), _dp(zp))
         return z

@@ -29,7 +29,7 @@ program ref_solve
   type(hecmwST_local_mesh) :: hecMESH
   type(hecmwST_matrix)     :: hecMAT
   character(len=1024) :: fin, fout
-  integer(kind=4) :: magic, mode, N, NP, NPL, NPU, nrepeat, u, irep
+  integer(kind=4) :: magic, mode, N, NP, NPL, NPU, nrepeat, u, irep, nd
   integer(kind=4) :: Iarr(100)
   real(kind=8)    :: Rarr(100), t0, t1, tcomm
   real(kind=8), allocatable :: Y(:), WK(:), X0(:)
@@ -39,6 +39,11 @@ program ref_solve
   open(newunit=u, file=trim(fin), access='stream', form='unformatted', status='old')
   read(u) magic, mode, N, NP, NPL, NPU, nrepeat
   if (magic /= 1179210580) stop 'bad magic'
+  nd = 3                          ! mode = 100*NDOF + mode selects another block size (hecMAT%NDOF)
+  if (mode >= 100) then
+    nd = mode / 100
+    mode = mod(mode, 100)
+  endif
   read(u) Iarr
   read(u) Rarr
 
@@ -46,10 +51,10 @@ program ref_solve
   call hecmw_mat_init(hecMAT)
   hecMAT%Iarray = Iarr
   hecMAT%Rarray = Rarr
-  hecMAT%N = N; hecMAT%NP = NP; hecMAT%NPL = NPL; hecMAT%NPU = NPU; hecMAT%NDOF = 3
+  hecMAT%N = N; hecMAT%NP = NP; hecMAT%NPL = NPL; hecMAT%NPU = NPU; hecMAT%NDOF = nd
   hecMAT%NPCL = 0; hecMAT%NPCU = 0
   allocate(hecMAT%indexL(0:NP), hecMAT%indexU(0:NP), hecMAT%itemL(NPL), hecMAT%itemU(NPU))
-  allocate(hecMAT%D(9*NP), hecMAT%AL(9*NPL), hecMAT%AU(9*NPU), hecMAT%B(3*NP), hecMAT%X(3*NP))
+  allocate(hecMAT%D(nd*nd*NP), hecMAT%AL(nd*nd*NPL), hecMAT%AU(nd*nd*NPU), hecMAT%B(nd*NP), hecMAT%X(nd*NP))
   read(u) hecMAT%indexL
   read(u) hecMAT%indexU
   read(u) hecMAT%itemL
@@ -63,14 +68,14 @@ program ref_solve
 
   hecMESH%zero = 0; hecMESH%MPI_COMM = 0; hecMESH%PETOT = 1; hecMESH%PEsmpTOT = 1
   hecMESH%my_rank = 0; hecMESH%n_subdomain = 1; hecMESH%n_neighbor_pe = 0
-  hecMESH%n_node = NP; hecMESH%nn_internal = N; hecMESH%n_dof = 3
+  hecMESH%n_node = NP; hecMESH%nn_internal = N; hecMESH%n_dof = nd
   hecMESH%nn_middle = NP
   hecMESH%mpc%n_mpc = 0
   allocate(hecMESH%neighbor_pe(0), hecMESH%import_index(0:0), hecMESH%export_index(0:0))
   allocate(hecMESH%import_item(0), hecMESH%export_item(0))
   hecMESH%import_index(0) = 0; hecMESH%export_index(0) = 0
 
-  allocate(Y(3*NP), WK(3*NP), X0(3*NP))
+  allocate(Y(nd*NP), WK(nd*NP), X0(nd*NP))
   X0 = hecMAT%X
   t0 = hecmw_Wtime()
   select case (mode)
@@ -92,7 +97,7 @@ program ref_solve
     do irep = 1, max(nrepeat, 1)
       call hecmw_matvec(hecMESH, hecMAT, hecMAT%X, Y, tcomm)
     enddo
-    Y(3*N+1:) = 0.d0
+    Y(nd*N+1:) = 0.d0
   case (3)
     tcomm = 0.d0
     call hecmw_precond_setup(hecMAT, hecMESH, 1)

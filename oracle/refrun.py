@@ -24,8 +24,8 @@ def have_ref(name="ref_solve"):
 class BSR:
     """Plain container mirroring hecmwST_matrix's members (1-based items)."""
 
-    def __init__(self, N, NP, indexL, itemL, indexU, itemU, D, AL, AU, B=None, X=None):
-        self.N, self.NP = int(N), int(NP)
+    def __init__(self, N, NP, indexL, itemL, indexU, itemU, D, AL, AU, B=None, X=None, NDOF=3):
+        self.N, self.NP, self.NDOF = int(N), int(NP), int(NDOF)
         self.indexL = np.ascontiguousarray(indexL, dtype=np.int32)
         self.indexU = np.ascontiguousarray(indexU, dtype=np.int32)
         self.itemL = np.ascontiguousarray(itemL, dtype=np.int32)
@@ -33,8 +33,8 @@ class BSR:
         self.D = np.ascontiguousarray(D, dtype=np.float64)
         self.AL = np.ascontiguousarray(AL, dtype=np.float64)
         self.AU = np.ascontiguousarray(AU, dtype=np.float64)
-        self.B = np.zeros(3 * self.NP) if B is None else np.ascontiguousarray(B, dtype=np.float64)
-        self.X = np.zeros(3 * self.NP) if X is None else np.ascontiguousarray(X, dtype=np.float64)
+        self.B = np.zeros(self.NDOF * self.NP) if B is None else np.ascontiguousarray(B, dtype=np.float64)
+        self.X = np.zeros(self.NDOF * self.NP) if X is None else np.ascontiguousarray(X, dtype=np.float64)
 
     @property
     def NPL(self):
@@ -83,7 +83,8 @@ def default_params(method=1, precond=3, maxit=10000, tol=1e-8, iterlog=1, timelo
 
 def write_system(path, mode, m, I, R, nrepeat=1):
     with open(path, "wb") as f:
-        np.array([MAGIC_SOLVE, mode, m.N, m.NP, m.NPL, m.NPU, nrepeat], dtype=np.int32).tofile(f)
+        ndof = int(getattr(m, "NDOF", 3))
+        np.array([MAGIC_SOLVE, mode + (100 * ndof if ndof != 3 else 0), m.N, m.NP, m.NPL, m.NPU, nrepeat], dtype=np.int32).tofile(f)
         I.astype(np.int32).tofile(f)
         R.astype(np.float64).tofile(f)
         for a in (m.indexL, m.indexU, m.itemL, m.itemU):
@@ -151,7 +152,7 @@ def run_solve(m, I, R, mode=1, threads=1, nrepeat=1, workdir=None, timeout=None,
             with open(fout, "rb") as f:
                 info["Iarray"] = np.fromfile(f, dtype=np.int32, count=100)
                 info["Rarray"] = np.fromfile(f, dtype=np.float64, count=100)
-                info["X"] = np.fromfile(f, dtype=np.float64, count=3 * m.NP)
+                info["X"] = np.fromfile(f, dtype=np.float64, count=int(getattr(m, "NDOF", 3)) * m.NP)
                 info["t_total"] = float(np.fromfile(f, dtype=np.float64, count=1)[0])
     return info
 
