@@ -214,6 +214,7 @@ static void bell_free(Bell &b) {
 }
 
 static void nl_free(fx_context *c);  // fx_nonlinear_host.h
+static void nn_free(fx_context *c);  // fx_nn_host.h
 static void graphs_destroy(fx_context *c);
 static void free_matrix(fx_context *c) {
   DevCSR &A = c->A;
@@ -248,6 +249,7 @@ extern "C" void fx_destroy(fx_context *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   graphs_destroy(c);
   nl_free(c);
+  nn_free(c);
   free_precond(c);
   free_matrix(c);
   dev_free(c->halo.export_item); dev_free(c->halo.import_item);
@@ -1534,10 +1536,13 @@ extern "C" int fx_solve_resident(fx_context *c, int32_t *Iarray, double *Rarray,
   return ret;
 }
 
+#include "fx_nn_host.h"
+
 // hecmw_solve (hecmw_solver.f90:9): host arrays in, host X out.
 extern "C" int fx_solve(fx_context *c, const fx_matrix_view *m, const fx_comm_view *cm, int32_t *Iarray, double *Rarray,
                         fx_solve_info *info, double *hist, int32_t hist_len) {
   if (Iarray[98] != 1) { g_fx_error = "Iarray(99) selects a direct solver: outside the GPU hot path"; return FX_ERROR_UNSUPPORTED; }
+  if (m->NDOF != 3) return nn_solve(c, m, cm, Iarray, Rarray, info, hist, hist_len);  // select case(NDOF): the nn path
   int what = FX_UP_RHS | FX_UP_X;
   if (Iarray[97] >= 1 || !c->have_profile) what |= FX_UP_PROFILE;  // symbolic: profile changed
   if (Iarray[96] >= 1 || !c->have_values) what |= FX_UP_VALUES;    // numeric: values changed
@@ -1551,6 +1556,7 @@ extern "C" int fx_solve(fx_context *c, const fx_matrix_view *m, const fx_comm_vi
 
 extern "C" int fx_matvec(fx_context *c, const fx_matrix_view *m, const fx_comm_view *cm, double *x, double *y,
                          double *commtime) {
+  if (m->NDOF != 3) return nn_matvec(c, m, cm, x, y, commtime);
   int what = 0;
   if (!c->have_profile) what |= FX_UP_PROFILE;
   if (!c->have_values) what |= FX_UP_VALUES;
@@ -1574,6 +1580,14 @@ extern "C" int fx_matvec(fx_context *c, const fx_matrix_view *m, const fx_comm_v
   if (from_slots(c, c->W[6], c->W[4])) return FX_ERROR_RUNTIME;
   HIP_TRY(hipMemcpyAsync(x, c->W[4], len, hipMemcpyDeviceToHost, c->stream));  // halo part of X is updated
   HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int fx_nn_matvec_resident(fx_context *c, int nrepeat, float *ms_per_call, int64_t stats[4]) {
+  HIP_TRY(hipSetDevice(c->device));
+  if (int e = nn_matvec_resident(c, nrepeat, ms_per_call)) return e;
+  NnDev *n = nn_of(c);
+  if (stats) { stats[0] = n->ndof; stats[1] = n->N; stats[2] = n->M.nblocks_padded * 64; stats[3] = (int64_t)n->N + n->NPL + n->NPU; }
   return 0;
 }
 

@@ -226,6 +226,7 @@ struct fx_context {
   double *h_send = nullptr, *h_recv = nullptr;  // pinned staging
   HaloDev halo;
   NlDev nl;
+  void *nn = nullptr;  // NnDev (fx_nn_host.h): systems with NDOF != 3
   // timing
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };

@@ -103,9 +103,9 @@ class hecmwST_matrix:
         hecmw_mat_init(self)
 
     @classmethod
-    def from_arrays(cls, N, NP, indexL, itemL, indexU, itemU, D, AL, AU, B=None, X=None):
+    def from_arrays(cls, N, NP, indexL, itemL, indexU, itemU, D, AL, AU, B=None, X=None, NDOF=3):
         m = cls()
-        m.N, m.NP = int(N), int(NP)
+        m.N, m.NP, m.NDOF = int(N), int(NP), int(NDOF)
         m.indexL = np.ascontiguousarray(indexL, dtype=np.int32)
         m.itemL = np.ascontiguousarray(itemL, dtype=np.int32)
         m.indexU = np.ascontiguousarray(indexU, dtype=np.int32)
@@ -114,8 +114,8 @@ class hecmwST_matrix:
         m.D = None if D is None else np.ascontiguousarray(D, dtype=np.float64)
         m.AL = None if AL is None else np.ascontiguousarray(AL, dtype=np.float64)
         m.AU = None if AU is None else np.ascontiguousarray(AU, dtype=np.float64)
-        m.B = np.zeros(3 * m.NP) if B is None else np.ascontiguousarray(B, dtype=np.float64)
-        m.X = np.zeros(3 * m.NP) if X is None else np.ascontiguousarray(X, dtype=np.float64)
+        m.B = np.zeros(m.NDOF * m.NP) if B is None else np.ascontiguousarray(B, dtype=np.float64)
+        m.X = np.zeros(m.NDOF * m.NP) if X is None else np.ascontiguousarray(X, dtype=np.float64)
         return m
 
     def view(self):

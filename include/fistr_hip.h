@@ -33,7 +33,7 @@ enum fx_status {
   FX_ERROR_DIVERGE_MAT = 3002,  /* W: diverged due to indefinite/neg-def matrix */
   FX_ERROR_DIVERGE_PC = 3003,   /* W: diverged due to indefinite preconditioner */
   FX_ERROR_RUNTIME = -1,        /* HIP / RCCL failure, see fx_last_error()      */
-  FX_ERROR_UNSUPPORTED = -2     /* NDOF != 3, or an option outside the hot path */
+  FX_ERROR_UNSUPPORTED = -2     /* NDOF outside 1..6, or an option outside the hot path */
 };
 
 /* Borrowed view of hecmwST_matrix (hecmw_util_f.F90:433-468).  The caller owns
@@ -44,9 +44,9 @@ typedef struct fx_matrix_view {
   int32_t N, NP, NPL, NPU, NDOF;
   const int32_t *indexL, *itemL; /* (0:NP), (NPL) */
   const int32_t *indexU, *itemU; /* (0:NP), (NPU) */
-  const double *D, *AL, *AU;     /* 9*NP, 9*NPL, 9*NPU */
-  const double *B;               /* 3*NP */
-  double *X;                     /* 3*NP, in: initial guess, out: solution */
+  const double *D, *AL, *AU;     /* NDOF^2 * NP, NPL, NPU (row-major NDOF x NDOF blocks) */
+  const double *B;               /* NDOF*NP */
+  double *X;                     /* NDOF*NP, in: initial guess, out: solution */
 } fx_matrix_view;
 
 /* Borrowed view of the communication part of hecmwST_local_mesh
@@ -94,7 +94,9 @@ int fx_device_synchronize(fx_context *ctx);
  * 3 GMRES(NREST=Iarray(6)) (hecmw_solver_GMRES.f90:17), 4 GPBiCG (hecmw_solver_GPBiCG.f90:17);
  * PRECOND Iarray(3): 1,2 SSOR, 3 DIAG (block Jacobi), 10 ILU(0); anything else E-1001.
  * SCALING Iarray(7) /= 0: symmetric diagonal scaling around every attempt (las/hecmw_solver_scaling_33.f90);
- * SIGMA_DIAG Rarray(2) < 0: the reference's automatic retry for the ILU family; METHOD2 Iarray(8) take-over. */
+ * SIGMA_DIAG Rarray(2) < 0: the reference's automatic retry for the ILU family; METHOD2 Iarray(8) take-over.
+ * NDOF = 3 is the tuned path.  NDOF = 1, 2, 4, 5, 6 (hecmw_matvec_nn las_nn.f90:135, precond/nn + 11/22/44/66) take the
+ * generic-block path: METHOD 1, 2; PRECOND 1, 2, 3; no SCALING; anything else E-1001 / FX_ERROR_UNSUPPORTED. */
 int fx_solve(fx_context *ctx, const fx_matrix_view *mat, const fx_comm_view *comm, int32_t *Iarray,
              double *Rarray, fx_solve_info *info, double *hist, int32_t hist_len);
 
@@ -125,6 +127,9 @@ int fx_download_x(fx_context *ctx, double *X, int32_t n);          /* 3*NP doubl
 int fx_download_matrix(fx_context *ctx, double *D, double *AL, double *AU, double *B);
 /* Resident single operations (tests, roofline timing). */
 int fx_matvec_resident(fx_context *ctx, int nrepeat, float *ms_per_call); /* y = A x on work vectors */
+/* The same for the resident NDOF != 3 system of the last fx_solve / fx_matvec (hecmw_matvec_nn, las_nn.f90:135-310).
+ * stats: NDOF, N, padded blocks of the layout, blocks of the matrix (N + NPL + NPU). */
+int fx_nn_matvec_resident(fx_context *ctx, int nrepeat, float *ms_per_call, int64_t stats[4]);
 int fx_precond_apply_resident(fx_context *ctx, int nrepeat, float *ms_per_call); /* z = M^-1 b, timed */
 int fx_precond_apply_host(fx_context *ctx, const double *r, double *z);   /* z = M^-1 r, 3*NP doubles */
 /* out[0..12]: N NP NPL NPU | M pairs, blocks, slices | ncolor | L pairs, blocks | U pairs, blocks | slices */

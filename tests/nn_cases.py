@@ -3,6 +3,14 @@ profile of a skewed cube of hex8 elements: every element contributes a random SP
 NDOF rows per node, so the global matrix is SPD with the reference's D / AL / AU layout (row-major NDOF x NDOF blocks)."""
 import numpy as np
 
+NN_NDOF = [1, 2, 4, 5, 6]
+# (METHOD, PRECOND): CG / BiCGSTAB x SSOR (RCM + multicolour, the reference's OpenMP path) / DIAG
+NN_CASES = [(1, 1), (1, 3), (2, 1), (2, 3)]
+
+
+def nn_tag(nd, meth, pc):
+    return "n%d_m%d_p%d_" % (nd, meth, pc)
+
 
 def nn_system(ndof, m=4, seed=0, halo=0):
     from frontistr_amd.mesh import CubeMesh
@@ -21,7 +29,7 @@ def nn_system(ndof, m=4, seed=0, halo=0):
     for e in range(mesh.conn.shape[0]):
         nod = mesh.conn[e] - 1
         G = rng.standard_normal((8 * ndof, 8 * ndof))
-        L = G @ G.T / (8 * ndof) + 0.25 * np.eye(8 * ndof)
+        L = G @ G.T / (8 * ndof) + 0.02 * np.eye(8 * ndof)
         for a in range(8):
             for b in range(8):
                 blk = L[a * ndof:(a + 1) * ndof, b * ndof:(b + 1) * ndof]
