@@ -74,6 +74,7 @@ contains
     integer(kind=kint) :: ierr, i, nhist, precond
     character(len=8) :: env
     character(len=16) :: envu
+    logical :: on_gpu
     integer :: elen, estat
 
     ! Explicit opt-out: HECMW_GPU=0 keeps the reference's own CPU solver for every call, and says so.
@@ -88,8 +89,14 @@ contains
       call hecmw_solve_iterative(hecMESH, hecMAT)
       return
     endif
-    if (hecMAT%NDOF /= 3 .or. hecMAT%Iarray(99) /= 1 .or. hecMESH%mpc%n_mpc > 0 .or. hecMAT%cmat%n_val > 0 .or. &
-        .not. (precond == 1 .or. precond == 2 .or. precond == 3 .or. precond == 10)) then
+    on_gpu = hecMAT%Iarray(99) == 1 .and. hecMESH%mpc%n_mpc == 0 .and. hecMAT%cmat%n_val == 0
+    if (hecMAT%NDOF == 3) then
+      on_gpu = on_gpu .and. (precond == 1 .or. precond == 2 .or. precond == 3 .or. precond == 10)
+    else   ! generic block sizes: CG / BiCGSTAB with SSOR / DIAG, no SCALING (include/fistr_hip.h)
+      on_gpu = on_gpu .and. hecMAT%NDOF >= 1 .and. hecMAT%NDOF <= 6 .and. (precond >= 1 .and. precond <= 3) .and. &
+               (hecMAT%Iarray(2) == 1 .or. hecMAT%Iarray(2) == 2) .and. hecMAT%Iarray(7) == 0
+    endif
+    if (.not. on_gpu) then
       call get_environment_variable('HECMW_GPU_UNSUPPORTED', envu, elen, estat)
       if (estat == 0 .and. elen >= 9 .and. envu(1:9) == 'reference') then
         if (hecMESH%my_rank == 0) write(*,'(a,i0,a,i0,a)') '### libfistr_hip: reference CPU solver used (NDOF=', &
@@ -134,8 +141,8 @@ contains
 
     ! the reference's stdout channel (hecmw_solver_Iterative.f90:418-419, hecmw_solver_CG.f90:245, :168)
     if (hecMESH%my_rank == 0 .and. (hecMAT%Iarray(21) == 1 .or. hecMAT%Iarray(22) >= 1)) then
-      write(*,'(a,i0,a,i0,a,i0)') '### 3x3 BLOCK (libfistr_hip) METHOD ', info%method, ', PRECOND ', &
-        info%precond, ', ', hecMAT%Iarray(5)
+      write(*,'(a,i0,a,i0,a,i0,a,i0,a,i0)') '### ', hecMAT%NDOF, 'x', hecMAT%NDOF, ' BLOCK (libfistr_hip) METHOD ', &
+        info%method, ', PRECOND ', info%precond, ', ', hecMAT%Iarray(5)
     endif
     if (hecMESH%my_rank == 0 .and. hecMAT%Iarray(21) == 1) then
       do i = 1, info%n_hist

@@ -144,6 +144,76 @@ print('self halo ok', len(res[(1, 'rccl')][0]), res[(1, 'rccl')][0][-1])
     assert p.returncode == 0 and "self halo ok" in p.stdout, p.stdout[-3000:]
 
 
+def test_rccl_self_neighbour_halo_exchange_generic_blocks(tmp_path):
+    """The same self-neighbour drive for the NDOF != 3 path (nn_halo: NDOF doubles per node): hecmw_matvec against numpy and a
+    CG + DIAG solve over RCCL against the host-callback transport, NDOF = 2 and 6."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r"""
+import ctypes as C, os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))
+import numpy as np
+from frontistr_amd import hecmw as hip
+from frontistr_amd.partition import cube_subdomain
+sub = cube_subdomain(6, (2, 1, 1), 0)
+hm = sub.hecmesh(hip)
+hm.elem_node_item = sub.conn.ravel()
+m0 = hip.hecmw_mat_con(hm, hip.hecmwST_matrix())
+N, NP = m0.N, m0.NP
+n_imp = NP - N
+HALO = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
+ARED = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int, C.c_void_p)
+for nd in (2, 6):
+    rng = np.random.default_rng(nd)
+    nd2 = nd * nd
+    m = hip.hecmwST_matrix.from_arrays(N, NP, m0.indexL, m0.itemL, m0.indexU, m0.itemU, rng.standard_normal(nd2 * NP),
+                                       0.05 * rng.standard_normal(nd2 * m0.NPL), 0.05 * rng.standard_normal(nd2 * m0.NPU),
+                                       rng.standard_normal(nd * NP), NDOF=nd)
+    m.D.reshape(NP, nd, nd)[:] += 8.0 * np.eye(nd)
+    exp_item = (1 + rng.permutation(N)[:n_imp]).astype(np.int32)
+    cut = np.array([0, n_imp // 3, n_imp], dtype=np.int32)
+    hm.my_rank, hm.PETOT, hm.n_neighbor_pe = 0, 1, 2
+    hm.neighbor_pe = np.zeros(2, dtype=np.int32)
+    hm.import_index = cut.copy(); hm.export_index = cut.copy(); hm.export_item = exp_item
+    def _halo(send, recv, _u, nd=nd):
+        C.memmove(recv, send, 8 * nd * n_imp)
+    cbs = (HALO(_halo), ARED(lambda v, n, u: None))
+    X = rng.standard_normal(nd * NP)
+    xf = X.copy().reshape(NP, nd); xf[hm.import_item - 1] = xf[exp_item - 1]
+    ref = np.einsum('nij,nj->ni', m.D.reshape(NP, nd, nd)[:N], xf[:N])
+    for i in range(N):
+        for j in range(m.indexL[i], m.indexL[i + 1]):
+            ref[i] += m.AL[nd2 * j:nd2 * j + nd2].reshape(nd, nd) @ xf[m.itemL[j] - 1]
+        for j in range(m.indexU[i], m.indexU[i + 1]):
+            ref[i] += m.AU[nd2 * j:nd2 * j + nd2].reshape(nd, nd) @ xf[m.itemU[j] - 1]
+    res = {}
+    for transport in ('rccl', 'host'):
+        ctx = hip.SolverContext()
+        if transport == 'rccl':
+            ctx.comm_init(hip.comm_unique_id(), 0, 1)
+        else:
+            assert hip.lib().fx_comm_set_host_callbacks(ctx.h, 0, 1, cbs[0], cbs[1], None) == 0
+        Y = np.zeros(nd * NP); Xc = X.copy()
+        hip.hecmw_matvec(hm, m, Xc, Y, ctx=ctx)
+        assert np.abs(Y[:nd * N] - ref.ravel()).max() < 1e-12 * np.abs(ref).max(), (nd, transport)
+        assert np.array_equal(Xc.reshape(NP, nd)[hm.import_item - 1], X.reshape(NP, nd)[exp_item - 1])   # halo of X updated
+        m.Iarray[0], m.Iarray[1], m.Iarray[2] = 25, 2, 3
+        m.Rarray[0] = 1e-30
+        m.Iarray[96] = m.Iarray[97] = 1
+        m.X[:] = 0.0
+        hip.hecmw_solve(hm, m, ctx=ctx)
+        res[transport] = (ctx.history.copy(), m.X.copy())
+        ctx.close()
+    assert len(res['rccl'][0]) == len(res['host'][0]) >= 25 and np.allclose(res['rccl'][0], res['host'][0], rtol=1e-9)
+    assert np.abs(res['rccl'][1] - res['host'][1]).max() <= 1e-9 * np.abs(res['host'][1]).max()
+print('self halo nn ok')
+""" % (ROOT, ROOT)
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0 and "self halo nn ok" in p.stdout, p.stdout[-3000:]
+
+
 def test_hip_on_reference_partitioner_files(oracle, tmp_path):
     """configs[3] plumbing: 4 ranks read the HECMW-DIST files hecmw_part1 wrote and solve through the
     library; the field equals the serial solve of the undecomposed mesh."""

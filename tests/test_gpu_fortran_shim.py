@@ -60,3 +60,20 @@ def test_shim_refuses_what_is_not_on_the_gpu_path():
     assert "libfistr_hip-E: not on the GPU path" in r["stdout"] and "X" not in r     # hecmw_abort: no solution is written
     r = refrun.run_solve(A, I, R, exe_name="shim_solve", extra_env={"HECMW_GPU_UNSUPPORTED": "reference"})
     assert r["returncode"] == 0 and "reference CPU solver used" in r["stdout"] and r["Iarray"][80] == 1
+
+
+@pytest.mark.parametrize("nd,meth,pc", [(1, 1, 3), (2, 2, 1), (6, 1, 1)])
+def test_shim_generic_block_sizes(nd, meth, pc):
+    """hecMAT%NDOF /= 3 through the same Fortran call: the generic-block GPU path, against the reference's golden vectors."""
+    from nn_cases import nn_system, nn_tag
+    from oracle import refrun
+    if not refrun.have_ref("shim_solve"):
+        pytest.skip("oracle/_ref/shim_solve not built")
+    g = load_golden("nn")
+    A = nn_system(nd)
+    I, R = refrun.default_params(method=meth, precond=pc)
+    r = refrun.run_solve(A, I, R, exe_name="shim_solve")
+    assert r["returncode"] == 0 and "%dx%d BLOCK (libfistr_hip) METHOD" % (nd, nd) in r["stdout"], r["stdout"][-2000:]
+    tag = nn_tag(nd, meth, pc)
+    assert abs(r["iter"] - int(g[tag + "iter"])) <= 1 if "iter" in r else True
+    assert np.abs(r["X"] - g[tag + "X"]).max() <= 1e-8 * np.abs(g[tag + "X"]).max() and r["Iarray"][80] == 1
