@@ -26,6 +26,8 @@ Graph build_graph(int32_t N, const int32_t *indexL, const int32_t *itemL, const 
 std::vector<int32_t> rcm_sequence(const Graph &g);
 void multicolor(const Graph &g, const std::vector<int32_t> &seq, int ncolor_in, std::vector<int32_t> &perm,
                 std::vector<int32_t> &colorindex);
+bool color_elements(int32_t n_elem, int nn, const int32_t *conn, int32_t NP, std::vector<int32_t> &order,
+                    std::vector<int32_t> &offsets);
 }  // namespace fxo
 
 thread_local std::string g_fx_error;
@@ -250,6 +252,8 @@ extern "C" void fx_destroy(fx_context *c) {
   graphs_destroy(c);
   nl_free(c);
   nn_free(c);
+  dev_free(c->asm_colors.order);
+  c->asm_colors = ElemColors();
   free_precond(c);
   free_matrix(c);
   dev_free(c->halo.export_item); dev_free(c->halo.import_item);

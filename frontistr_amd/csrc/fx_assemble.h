@@ -102,13 +102,17 @@ __global__ __launch_bounds__(FXA_BLOCK) void k_assemble_c3d8(int32_t n_elem, con
                                                              double *__restrict__ AL, double *__restrict__ AU,
                                                              double *__restrict__ Kout, int32_t *__restrict__ err,
                                                              const int32_t *__restrict__ elem_mat,
-                                                             const double *__restrict__ mat_tab) {
+                                                             const double *__restrict__ mat_tab,
+                                                             const int32_t *__restrict__ elem_list, int32_t e0) {
+  // elem_list != nullptr: positions [e0, n_elem) of elem_list are the elements of ONE colour (no shared nodes), scattered
+  // without atomics; nullptr: elements e0..n_elem-1 in their own order with hardware fp64 atomics
   constexpr int NJ = (ELEMOPT == 1) ? 11 : 8;
   __shared__ double Ksh[(ELEMOPT == 1) ? FXA_EPB : 1][9][34];
   __shared__ double Xinv[(ELEMOPT == 1) ? FXA_EPB : 1][9][10];
   const int el = threadIdx.x >> 4, a = threadIdx.x & 15;
-  const int32_t elem = blockIdx.x * FXA_EPB + el;
-  const bool active = (elem < n_elem) && (a < NJ);
+  const int32_t epos = e0 + blockIdx.x * FXA_EPB + el;
+  const bool active = (epos < n_elem) && (a < NJ);
+  const int32_t elem = (elem_list && epos < n_elem) ? elem_list[epos] : epos;
   double K[NJ][9];
 #pragma unroll
   for (int b = 0; b < NJ; b++)
@@ -298,8 +302,13 @@ __global__ __launch_bounds__(FXA_BLOCK) void k_assemble_c3d8(int32_t n_elem, con
       if (k < 0) { if (err) atomicExch(err, 2); continue; }
       dst = AU + (size_t)9 * k;
     }
+    if (elem_list) {
 #pragma unroll
-    for (int e = 0; e < 9; e++) unsafeAtomicAdd(dst + e, K[b][e]);
+      for (int e = 0; e < 9; e++) dst[e] += K[b][e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 9; e++) unsafeAtomicAdd(dst + e, K[b][e]);
+    }
   }
 }
 

@@ -70,14 +70,65 @@ static void elastic_constants(double E, double nu, double &D11, double &D12, dou
   D44 = E / (1.0 + nu) * 0.5;
 }
 
+// Colour the elements of a mesh once (fx_order.cpp: color_elements) and keep the grouped element list on the device; the
+// stiffness kernels then scatter colour by colour without atomics.  FX_ASM_ATOMIC=1 keeps the single-launch atomic scatter.
+static void elem_colors_free(ElemColors &ec) {
+  dev_free(ec.order);
+  ec = ElemColors();
+}
+static int ensure_elem_colors(fx_context *c, ElemColors &ec, int32_t n_elem, const int32_t *conn, int32_t NP) {
+  static const bool force_atomic = getenv("FX_ASM_ATOMIC") && atoi(getenv("FX_ASM_ATOMIC")) != 0;
+  if (force_atomic || n_elem < 1) { elem_colors_free(ec); return 0; }
+  // checksum of the connectivity: per-chunk FNV-1a, chunks combined in order
+  const int64_t nw = (int64_t)8 * n_elem;
+  const int nchunk = 64;
+  uint64_t part[nchunk];
+  bool bad[nchunk];
+  parallel_for(nchunk, [&](int64_t a, int64_t b) {
+    for (int64_t q = a; q < b; q++) {
+      uint64_t h = 1469598103934665603ull;
+      bool oob = false;
+      for (int64_t i = nw * q / nchunk; i < nw * (q + 1) / nchunk; i++) {
+        h = (h ^ (uint32_t)conn[i]) * 1099511628211ull;
+        oob |= (conn[i] < 1 || conn[i] > NP);
+      }
+      part[q] = h; bad[q] = oob;
+    }
+  });
+  uint64_t key = 1469598103934665603ull;
+  for (int q = 0; q < nchunk; q++) {
+    if (bad[q]) { g_fx_error = "element connectivity: node id out of range"; return FX_ERROR_RUNTIME; }
+    key = (key ^ part[q]) * 1099511628211ull;
+  }
+  if (ec.order && ec.n_elem == n_elem && ec.key == key && !ec.offsets.empty()) return 0;
+  elem_colors_free(ec);
+  std::vector<int32_t> order, off;
+  if (!fxo::color_elements(n_elem, 8, conn, NP, order, off)) return 0;  // a node in more than 64 elements: atomics
+  if (dev_alloc(&ec.order, (size_t)n_elem)) return FX_ERROR_RUNTIME;
+  HIP_TRY(hipMemcpyAsync(ec.order, order.data(), (size_t)n_elem * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  ec.n_elem = n_elem; ec.key = key; ec.offsets = off;
+  return 0;
+}
+
 template <int EO>
 static void launch_assemble(fx_context *c, int32_t n_elem, const double *coord, const int32_t *conn, double D11, double D12,
                             double D44, double *Kout, int32_t *err, const int32_t *elem_mat = nullptr,
-                            const double *mat_tab = nullptr) {
+                            const double *mat_tab = nullptr, const ElemColors *ec = nullptr) {
   const DevCSR &A = c->A;
+  if (ec && !ec->offsets.empty() && !Kout) {
+    for (size_t k = 0; k + 1 < ec->offsets.size(); k++) {
+      const int32_t e0 = ec->offsets[k], e1 = ec->offsets[k + 1];
+      if (e1 <= e0) continue;
+      hipLaunchKernelGGL((k_assemble_c3d8<EO>), dim3((e1 - e0 + FXA_EPB - 1) / FXA_EPB), dim3(FXA_BLOCK), 0, c->stream, e1, coord,
+                         conn, D11, D12, D44, A.indexL, A.itemL, A.indexU, A.itemU, A.D, A.AL, A.AU, Kout, err, elem_mat, mat_tab,
+                         (const int32_t *)ec->order, e0);
+    }
+    return;
+  }
   hipLaunchKernelGGL((k_assemble_c3d8<EO>), dim3((n_elem + FXA_EPB - 1) / FXA_EPB), dim3(FXA_BLOCK), 0, c->stream, n_elem,
                      coord, conn, D11, D12, D44, A.indexL, A.itemL, A.indexU, A.itemU, A.D, A.AL, A.AU, Kout, err, elem_mat,
-                     mat_tab);
+                     mat_tab, (const int32_t *)nullptr, 0);
 }
 
 static int assemble_c3d8_common(fx_context *c, const fx_mesh_view *mesh, double E, double nu, int32_t n_mat, const double *Es,
@@ -97,6 +148,7 @@ static int assemble_c3d8_common(fx_context *c, const fx_mesh_view *mesh, double 
   HIP_TRY(hipMemcpyAsync(d_coord, mesh->coord, (size_t)3 * mesh->n_node * 8, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(d_conn, mesh->conn, (size_t)8 * mesh->n_elem * 4, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemsetAsync(d_err, 0, 4, c->stream));
+  if (ensure_elem_colors(c, c->asm_colors, mesh->n_elem, mesh->conn, mesh->n_node)) return FX_ERROR_RUNTIME;  // cached per mesh
   double D11 = 0.0, D12 = 0.0, D44 = 0.0;
   int32_t *d_emat = nullptr;
   double *d_mtab = nullptr;
@@ -117,9 +169,9 @@ static int assemble_c3d8_common(fx_context *c, const fx_mesh_view *mesh, double 
   HIP_TRY(hipMemsetAsync(A.D, 0, (size_t)9 * A.NP * 8, c->stream));
   HIP_TRY(hipMemsetAsync(A.AL, 0, (size_t)9 * A.NPL * 8, c->stream));
   HIP_TRY(hipMemsetAsync(A.AU, 0, (size_t)9 * A.NPU * 8, c->stream));
-  if (elemopt == 1) launch_assemble<1>(c, mesh->n_elem, d_coord, d_conn, D11, D12, D44, nullptr, d_err, d_emat, d_mtab);
-  else if (elemopt == 2) launch_assemble<2>(c, mesh->n_elem, d_coord, d_conn, D11, D12, D44, nullptr, d_err, d_emat, d_mtab);
-  else launch_assemble<3>(c, mesh->n_elem, d_coord, d_conn, D11, D12, D44, nullptr, d_err, d_emat, d_mtab);
+  if (elemopt == 1) launch_assemble<1>(c, mesh->n_elem, d_coord, d_conn, D11, D12, D44, nullptr, d_err, d_emat, d_mtab, &c->asm_colors);
+  else if (elemopt == 2) launch_assemble<2>(c, mesh->n_elem, d_coord, d_conn, D11, D12, D44, nullptr, d_err, d_emat, d_mtab, &c->asm_colors);
+  else launch_assemble<3>(c, mesh->n_elem, d_coord, d_conn, D11, D12, D44, nullptr, d_err, d_emat, d_mtab, &c->asm_colors);
   HIP_TRY(hipGetLastError());
   if (load) HIP_TRY(hipMemcpyAsync(A.B, load, (size_t)3 * A.NP * 8, hipMemcpyHostToDevice, c->stream));
   else HIP_TRY(hipMemsetAsync(A.B, 0, (size_t)3 * A.NP * 8, c->stream));
@@ -189,7 +241,7 @@ extern "C" int fx_element_stiffness_c3d8(fx_context *c, int elemopt, const doubl
   double *nud = nullptr;
 #define ONE(EO)                                                                                                         \
   hipLaunchKernelGGL((k_assemble_c3d8<EO>), dim3(1), dim3(FXA_BLOCK), 0, c->stream, 1, d_coord, d_conn, D11, D12, D44, nul, \
-                     nul, nul, nul, nud, nud, nud, d_k, d_err, nul, (const double *)nullptr)
+                     nul, nul, nul, nud, nud, nud, d_k, d_err, nul, (const double *)nullptr, nul, 0)
   if (elemopt == 1) ONE(1);
   else if (elemopt == 2) ONE(2);
   else if (elemopt == 3) ONE(3);

@@ -128,8 +128,17 @@ struct NlMat {
 };
 
 // fstr_solid members of the nonlinear static loop (m_fstr.f90:560-700) for one TYPE=361 B-bar group, resident.
+// Elements grouped by colour (fxo::color_elements): the atomic-free scatter of the stiffness kernels.
+struct ElemColors {
+  int32_t n_elem = 0;
+  uint64_t key = 0;                 // checksum of the connectivity the colouring belongs to
+  int32_t *order = nullptr;         // device: element ids, colour by colour
+  std::vector<int32_t> offsets;     // host: first position of each colour (+ end); empty = not coloured (atomics)
+};
+
 struct NlDev {
   bool ready = false;
+  ElemColors colors;
   int32_t n_elem = 0, n_bc = 0;
   NlMat mat = {};
   double *tab = nullptr;
@@ -226,6 +235,7 @@ struct fx_context {
   double *h_send = nullptr, *h_recv = nullptr;  // pinned staging
   HaloDev halo;
   NlDev nl;
+  ElemColors asm_colors;  // fx_assemble_c3d8
   void *nn = nullptr;  // NnDev (fx_nn_host.h): systems with NDOF != 3
   // timing
   hipEvent_t ev0 = nullptr, ev1 = nullptr;

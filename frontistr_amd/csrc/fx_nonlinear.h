@@ -204,11 +204,14 @@ __global__ __launch_bounds__(FXN_BLOCK) void k_nl_stiffness(int32_t n_elem, cons
                                                             const int32_t *__restrict__ itemL, const int32_t *__restrict__ indexU,
                                                             const int32_t *__restrict__ itemU, double *__restrict__ D,
                                                             double *__restrict__ AL, double *__restrict__ AU,
-                                                            double *__restrict__ Kout, int32_t *__restrict__ err) {
+                                                            double *__restrict__ Kout, int32_t *__restrict__ err,
+                                                            const int32_t *__restrict__ elem_list, int32_t e0) {
+  // elem_list: positions [e0, n_elem) hold the elements of one colour (atomic-free scatter), see k_assemble_c3d8
   const int lane8 = threadIdx.x & 7;
-  int32_t elem = blockIdx.x * FXN_EPB + (threadIdx.x >> 3);
-  const bool active = elem < n_elem;
-  if (!active) elem = n_elem - 1;  // keep the 8-lane group converged for the shuffles; results discarded
+  int32_t epos = e0 + blockIdx.x * FXN_EPB + (threadIdx.x >> 3);
+  const bool active = epos < n_elem;
+  if (!active) epos = n_elem - 1;  // keep the 8-lane group converged for the shuffles; results discarded
+  const int32_t elem = elem_list ? elem_list[epos] : epos;
   int32_t nod[8];
   double gd[8][3], bbar[8][3], Dm[21], S[6], F[9], wg;
   {
@@ -345,8 +348,13 @@ __global__ __launch_bounds__(FXN_BLOCK) void k_nl_stiffness(int32_t n_elem, cons
       if (k < 0) { if (err) atomicExch(err, 2); continue; }
       dst = AU + (size_t)9 * k;
     }
+    if (elem_list) {
 #pragma unroll
-    for (int e = 0; e < 9; e++) unsafeAtomicAdd(dst + e, K[b][e]);
+      for (int e = 0; e < 9; e++) dst[e] += K[b][e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 9; e++) unsafeAtomicAdd(dst + e, K[b][e]);
+    }
   }
 }
 
