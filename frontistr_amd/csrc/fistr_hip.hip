@@ -233,6 +233,8 @@ static void free_matrix(fx_context *c) {
   c->wlen = 0;
   c->max_partials = 0;
   c->have_profile = c->have_values = c->bell_valid = false;
+  dev_free(c->asm_colors.order); dev_free(c->asm_colors.pos);  // the scatter map belongs to the profile
+  c->asm_colors = ElemColors();
 }
 
 static void free_precond(fx_context *c) {
@@ -252,7 +254,7 @@ extern "C" void fx_destroy(fx_context *c) {
   graphs_destroy(c);
   nl_free(c);
   nn_free(c);
-  dev_free(c->asm_colors.order);
+  dev_free(c->asm_colors.order); dev_free(c->asm_colors.pos);
   c->asm_colors = ElemColors();
   free_precond(c);
   free_matrix(c);
@@ -526,6 +528,7 @@ extern "C" int fx_upload(fx_context *c, const fx_matrix_view *m, const fx_comm_v
   if (what & FX_UP_PROFILE) {
     free_precond(c);
     free_matrix(c);
+    nl_free(c);  // the nonlinear state (and its scatter map) belongs to the old profile: fx_nl_init again
     A.N = m->N; A.NP = m->NP; A.NPL = m->NPL; A.NPU = m->NPU;
     if (dev_alloc(&A.indexL, (size_t)A.NP + 1) || dev_alloc(&A.indexU, (size_t)A.NP + 1) ||
         dev_alloc(&A.itemL, (size_t)A.NPL) || dev_alloc(&A.itemU, (size_t)A.NPU) ||

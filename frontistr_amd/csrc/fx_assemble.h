@@ -92,6 +92,22 @@ __device__ __forceinline__ int32_t item_search(const int32_t *item, int32_t lo, 
   return -1;
 }
 
+// Position of every (row node a, column node b) block of every element in AL / AU, found once per (profile, mesh) so that the
+// assembly kernels do not repeat 56 binary searches per element in every Newton iteration: pos[64 * elem + 8 * a + b]
+// (-1: not in the profile; the diagonal entries a == b are unused).
+__global__ void k_scatter_map(int32_t n_elem, const int32_t *__restrict__ conn, const int32_t *__restrict__ indexL,
+                              const int32_t *__restrict__ itemL, const int32_t *__restrict__ indexU,
+                              const int32_t *__restrict__ itemU, int32_t *__restrict__ pos) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)64 * n_elem) return;
+  const int32_t elem = (int32_t)(t >> 6), a = (int)(t >> 3) & 7, b = (int)t & 7;
+  const int32_t inod = conn[(size_t)8 * elem + a], jnod = conn[(size_t)8 * elem + b];
+  int32_t k = 0;
+  if (jnod < inod) k = item_search(itemL, indexL[inod - 1], indexL[inod], jnod);
+  else if (jnod > inod) k = item_search(itemU, indexU[inod - 1], indexU[inod], jnod);
+  pos[t] = k;
+}
+
 template <int ELEMOPT>
 __global__ __launch_bounds__(FXA_BLOCK) void k_assemble_c3d8(int32_t n_elem, const double *__restrict__ coord,
                                                              const int32_t *__restrict__ conn, double D11, double D12,
@@ -103,7 +119,8 @@ __global__ __launch_bounds__(FXA_BLOCK) void k_assemble_c3d8(int32_t n_elem, con
                                                              double *__restrict__ Kout, int32_t *__restrict__ err,
                                                              const int32_t *__restrict__ elem_mat,
                                                              const double *__restrict__ mat_tab,
-                                                             const int32_t *__restrict__ elem_list, int32_t e0) {
+                                                             const int32_t *__restrict__ elem_list, int32_t e0,
+                                                             const int32_t *__restrict__ pos_map) {
   // elem_list != nullptr: positions [e0, n_elem) of elem_list are the elements of ONE colour (no shared nodes), scattered
   // without atomics; nullptr: elements e0..n_elem-1 in their own order with hardware fp64 atomics
   constexpr int NJ = (ELEMOPT == 1) ? 11 : 8;
@@ -294,11 +311,11 @@ __global__ __launch_bounds__(FXA_BLOCK) void k_assemble_c3d8(int32_t n_elem, con
     double *dst;
     if (inod == jnod) dst = D + (size_t)9 * (inod - 1);
     else if (jnod < inod) {
-      const int32_t k = item_search(itemL, indexL[inod - 1], indexL[inod], jnod);
+      const int32_t k = pos_map ? pos_map[(size_t)64 * elem + 8 * a + b] : item_search(itemL, indexL[inod - 1], indexL[inod], jnod);
       if (k < 0) { if (err) atomicExch(err, 2); continue; }
       dst = AL + (size_t)9 * k;
     } else {
-      const int32_t k = item_search(itemU, indexU[inod - 1], indexU[inod], jnod);
+      const int32_t k = pos_map ? pos_map[(size_t)64 * elem + 8 * a + b] : item_search(itemU, indexU[inod - 1], indexU[inod], jnod);
       if (k < 0) { if (err) atomicExch(err, 2); continue; }
       dst = AU + (size_t)9 * k;
     }

@@ -74,7 +74,19 @@ static void elastic_constants(double E, double nu, double &D11, double &D12, dou
 // stiffness kernels then scatter colour by colour without atomics.  FX_ASM_ATOMIC=1 keeps the single-launch atomic scatter.
 static void elem_colors_free(ElemColors &ec) {
   dev_free(ec.order);
+  dev_free(ec.pos);
   ec = ElemColors();
+}
+// the position map of k_scatter_map for the resident profile and the device connectivity d_conn (FX_ASM_MAP=0: search every time)
+static int ensure_scatter_map(fx_context *c, ElemColors &ec, int32_t n_elem, const int32_t *d_conn) {
+  static const bool off = getenv("FX_ASM_MAP") && atoi(getenv("FX_ASM_MAP")) == 0;
+  if (off || ec.pos || ec.offsets.empty()) return 0;
+  if (dev_alloc(&ec.pos, (size_t)64 * n_elem)) { (void)hipGetLastError(); ec.pos = nullptr; return 0; }  // no memory: keep searching
+  const DevCSR &A = c->A;
+  hipLaunchKernelGGL(k_scatter_map, dim3((unsigned)(((int64_t)64 * n_elem + 255) / 256)), dim3(256), 0, c->stream, n_elem, d_conn,
+                     A.indexL, A.itemL, A.indexU, A.itemU, ec.pos);
+  HIP_TRY(hipGetLastError());
+  return 0;
 }
 static int ensure_elem_colors(fx_context *c, ElemColors &ec, int32_t n_elem, const int32_t *conn, int32_t NP) {
   static const bool force_atomic = getenv("FX_ASM_ATOMIC") && atoi(getenv("FX_ASM_ATOMIC")) != 0;
@@ -122,13 +134,13 @@ static void launch_assemble(fx_context *c, int32_t n_elem, const double *coord, 
       if (e1 <= e0) continue;
       hipLaunchKernelGGL((k_assemble_c3d8<EO>), dim3((e1 - e0 + FXA_EPB - 1) / FXA_EPB), dim3(FXA_BLOCK), 0, c->stream, e1, coord,
                          conn, D11, D12, D44, A.indexL, A.itemL, A.indexU, A.itemU, A.D, A.AL, A.AU, Kout, err, elem_mat, mat_tab,
-                         (const int32_t *)ec->order, e0);
+                         (const int32_t *)ec->order, e0, (const int32_t *)ec->pos);
     }
     return;
   }
   hipLaunchKernelGGL((k_assemble_c3d8<EO>), dim3((n_elem + FXA_EPB - 1) / FXA_EPB), dim3(FXA_BLOCK), 0, c->stream, n_elem,
                      coord, conn, D11, D12, D44, A.indexL, A.itemL, A.indexU, A.itemU, A.D, A.AL, A.AU, Kout, err, elem_mat,
-                     mat_tab, (const int32_t *)nullptr, 0);
+                     mat_tab, (const int32_t *)nullptr, 0, (const int32_t *)nullptr);
 }
 
 static int assemble_c3d8_common(fx_context *c, const fx_mesh_view *mesh, double E, double nu, int32_t n_mat, const double *Es,
@@ -148,7 +160,9 @@ static int assemble_c3d8_common(fx_context *c, const fx_mesh_view *mesh, double 
   HIP_TRY(hipMemcpyAsync(d_coord, mesh->coord, (size_t)3 * mesh->n_node * 8, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(d_conn, mesh->conn, (size_t)8 * mesh->n_elem * 4, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemsetAsync(d_err, 0, 4, c->stream));
-  if (ensure_elem_colors(c, c->asm_colors, mesh->n_elem, mesh->conn, mesh->n_node)) return FX_ERROR_RUNTIME;  // cached per mesh
+  if (ensure_elem_colors(c, c->asm_colors, mesh->n_elem, mesh->conn, mesh->n_node) ||
+      ensure_scatter_map(c, c->asm_colors, mesh->n_elem, d_conn))
+    return FX_ERROR_RUNTIME;  // both cached per (profile, mesh)
   double D11 = 0.0, D12 = 0.0, D44 = 0.0;
   int32_t *d_emat = nullptr;
   double *d_mtab = nullptr;
@@ -241,7 +255,7 @@ extern "C" int fx_element_stiffness_c3d8(fx_context *c, int elemopt, const doubl
   double *nud = nullptr;
 #define ONE(EO)                                                                                                         \
   hipLaunchKernelGGL((k_assemble_c3d8<EO>), dim3(1), dim3(FXA_BLOCK), 0, c->stream, 1, d_coord, d_conn, D11, D12, D44, nul, \
-                     nul, nul, nul, nud, nud, nud, d_k, d_err, nul, (const double *)nullptr, nul, 0)
+                     nul, nul, nul, nud, nud, nud, d_k, d_err, nul, (const double *)nullptr, nul, 0, nul)
   if (elemopt == 1) ONE(1);
   else if (elemopt == 2) ONE(2);
   else if (elemopt == 3) ONE(3);

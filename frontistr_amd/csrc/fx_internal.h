@@ -134,6 +134,7 @@ struct ElemColors {
   uint64_t key = 0;                 // checksum of the connectivity the colouring belongs to
   int32_t *order = nullptr;         // device: element ids, colour by colour
   std::vector<int32_t> offsets;     // host: first position of each colour (+ end); empty = not coloured (atomics)
+  int32_t *pos = nullptr;           // device: 64 per element, position of block (a, b) in AL / AU (k_scatter_map), or null
 };
 
 struct NlDev {

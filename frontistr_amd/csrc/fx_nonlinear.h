@@ -205,7 +205,8 @@ __global__ __launch_bounds__(FXN_BLOCK) void k_nl_stiffness(int32_t n_elem, cons
                                                             const int32_t *__restrict__ itemU, double *__restrict__ D,
                                                             double *__restrict__ AL, double *__restrict__ AU,
                                                             double *__restrict__ Kout, int32_t *__restrict__ err,
-                                                            const int32_t *__restrict__ elem_list, int32_t e0) {
+                                                            const int32_t *__restrict__ elem_list, int32_t e0,
+                                                            const int32_t *__restrict__ pos_map) {
   // elem_list: positions [e0, n_elem) hold the elements of one colour (atomic-free scatter), see k_assemble_c3d8
   const int lane8 = threadIdx.x & 7;
   int32_t epos = e0 + blockIdx.x * FXN_EPB + (threadIdx.x >> 3);
@@ -340,11 +341,11 @@ __global__ __launch_bounds__(FXN_BLOCK) void k_nl_stiffness(int32_t n_elem, cons
     double *dst;
     if (inod == jnod) dst = D + (size_t)9 * (inod - 1);
     else if (jnod < inod) {
-      const int32_t k = item_search(itemL, indexL[inod - 1], indexL[inod], jnod);
+      const int32_t k = pos_map ? pos_map[(size_t)64 * elem + 8 * a + b] : item_search(itemL, indexL[inod - 1], indexL[inod], jnod);
       if (k < 0) { if (err) atomicExch(err, 2); continue; }
       dst = AL + (size_t)9 * k;
     } else {
-      const int32_t k = item_search(itemU, indexU[inod - 1], indexU[inod], jnod);
+      const int32_t k = pos_map ? pos_map[(size_t)64 * elem + 8 * a + b] : item_search(itemU, indexU[inod - 1], indexU[inod], jnod);
       if (k < 0) { if (err) atomicExch(err, 2); continue; }
       dst = AU + (size_t)9 * k;
     }

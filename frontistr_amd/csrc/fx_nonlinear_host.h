@@ -9,7 +9,7 @@ static void nl_free(fx_context *c) {
   dev_free(n.plstrain); dev_free(n.fstat); dev_free(n.istat);
   dev_free(n.unode); dev_free(n.dunode); dev_free(n.qforce); dev_free(n.GL);
   dev_free(n.bc_flag); dev_free(n.bc_val); dev_free(n.bc_node); dev_free(n.bc_dof); dev_free(n.bc_v); dev_free(n.err);
-  dev_free(n.colors.order);
+  dev_free(n.colors.order); dev_free(n.colors.pos);
   n = NlDev();
 }
 
@@ -39,7 +39,8 @@ extern "C" int fx_nl_init(fx_context *c, const fx_mesh_view *mesh, const fx_mate
     return FX_ERROR_RUNTIME;
   HIP_TRY(hipMemcpyAsync(n.coord, mesh->coord, np3 * 8, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(n.conn, mesh->conn, npt * 4, hipMemcpyHostToDevice, c->stream));
-  if (ensure_elem_colors(c, n.colors, mesh->n_elem, mesh->conn, mesh->n_node)) return FX_ERROR_RUNTIME;
+  if (ensure_elem_colors(c, n.colors, mesh->n_elem, mesh->conn, mesh->n_node) || ensure_scatter_map(c, n.colors, mesh->n_elem, n.conn))
+    return FX_ERROR_RUNTIME;
   if (mat->ntab > 0) HIP_TRY(hipMemcpyAsync(n.tab, mat->tab, (size_t)2 * mat->ntab * 8, hipMemcpyHostToDevice, c->stream));
   for (double *p : {n.stress, n.strain, n.stress_bak, n.strain_bak}) HIP_TRY(hipMemsetAsync(p, 0, 6 * npt * 8, c->stream));
   for (double *p : {n.plstrain, n.fstat}) HIP_TRY(hipMemsetAsync(p, 0, npt * 8, c->stream));
@@ -70,13 +71,13 @@ static void nl_launch_stiffness(fx_context *c, double *Kout) {
       if (e1 <= e0) continue;
       hipLaunchKernelGGL((k_nl_stiffness<G>), dim3((e1 - e0 + FXN_EPB - 1) / FXN_EPB), dim3(FXN_BLOCK), 0, c->stream, e1, n.coord,
                          n.conn, n.unode, n.dunode, n.mat, n.latch, n.stress, n.fstat, n.istat, A.indexL, A.itemL, A.indexU, A.itemU,
-                         A.D, A.AL, A.AU, Kout, n.err, (const int32_t *)n.colors.order, e0);
+                         A.D, A.AL, A.AU, Kout, n.err, (const int32_t *)n.colors.order, e0, (const int32_t *)n.colors.pos);
     }
     return;
   }
   hipLaunchKernelGGL((k_nl_stiffness<G>), dim3((n.n_elem + FXN_EPB - 1) / FXN_EPB), dim3(FXN_BLOCK), 0, c->stream, n.n_elem, n.coord,
                      n.conn, n.unode, n.dunode, n.mat, n.latch, n.stress, n.fstat, n.istat, A.indexL, A.itemL, A.indexU, A.itemU, A.D,
-                     A.AL, A.AU, Kout, n.err, (const int32_t *)nullptr, 0);
+                     A.AL, A.AU, Kout, n.err, (const int32_t *)nullptr, 0, (const int32_t *)nullptr);
 }
 template <int G>
 static void nl_launch_update(fx_context *c, double *qf_out) {

@@ -556,3 +556,50 @@ def test_scaling_option_matches_reference_golden(hip, case):
     ctx.download_matrix(m)
     assert relerr(m.D, D0) < 1e-14 and relerr(m.B, B0) < 1e-14
     ctx.close()
+
+
+def test_assembly_coloured_scatter_is_reproducible_and_equals_atomic_scatter(hip, tmp_path):
+    """The stiffness scatter runs colour by colour without atomics: two assemblies are bitwise identical, and the
+    single-launch atomic scatter (FX_ASM_ATOMIC=1, fresh process) gives the same matrix to rounding."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from frontistr_amd.mesh import CubeMesh
+    mesh = CubeMesh(7, skew=0.12)
+
+    def assemble(eo):
+        hm = hip.hecmwST_local_mesh(n_node=mesh.n_node)
+        hm.elem_node_item = mesh.conn.ravel()
+        m = hip.hecmw_mat_con(hm, hip.hecmwST_matrix())
+        ctx = hip.SolverContext()
+        ctx.upload(m, what=hip.FX_UP_PROFILE)
+        ctx.assemble_c3d8(mesh.coord, mesh.conn, 210000.0, 0.3, elemopt=eo, load=mesh.load(), bc=mesh.dirichlet())
+        ctx.download_matrix(m)
+        ctx.close()
+        return m
+    for eo in (1, 2):
+        a, b = assemble(eo), assemble(eo)
+        assert np.array_equal(a.D, b.D) and np.array_equal(a.AL, b.AL) and np.array_equal(a.AU, b.AU)
+        np.savez(tmp_path / ("col%d.npz" % eo), D=a.D, AL=a.AL, AU=a.AU)
+    code = r"""
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+from frontistr_amd import hecmw as hip
+from frontistr_amd.mesh import CubeMesh
+mesh = CubeMesh(7, skew=0.12)
+for eo in (1, 2):
+    hm = hip.hecmwST_local_mesh(n_node=mesh.n_node); hm.elem_node_item = mesh.conn.ravel()
+    m = hip.hecmw_mat_con(hm, hip.hecmwST_matrix())
+    ctx = hip.SolverContext(); ctx.upload(m, what=hip.FX_UP_PROFILE)
+    ctx.assemble_c3d8(mesh.coord, mesh.conn, 210000.0, 0.3, elemopt=eo, load=mesh.load(), bc=mesh.dirichlet())
+    ctx.download_matrix(m)
+    g = np.load(os.path.join(%r, 'col%%d.npz' %% eo))
+    s = np.abs(g['D']).max()
+    assert max(np.abs(m.D - g['D']).max(), np.abs(m.AL - g['AL']).max(), np.abs(m.AU - g['AU']).max()) <= 1e-13 * s
+print('atomic scatter ok')
+""" % (ROOT, str(tmp_path))
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FX_ASM_ATOMIC="1"), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0 and "atomic scatter ok" in p.stdout, p.stdout[-2000:]
