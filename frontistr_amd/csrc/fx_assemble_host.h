@@ -63,6 +63,21 @@ extern "C" int fx_mat_con(int32_t NP, int32_t n_elem, int32_t nn, const int32_t 
   return 0;
 }
 
+extern "C" int fx_color_elements(int32_t NP, int32_t n_elem, int32_t nn, const int32_t *conn, int32_t *order, int32_t *offsets,
+                                 int32_t *ncolor) {
+  for (int64_t k = 0; k < (int64_t)n_elem * nn; k++)
+    if (conn[k] < 1 || conn[k] > NP) { g_fx_error = "fx_color_elements: node id out of range"; return FX_ERROR_RUNTIME; }
+  std::vector<int32_t> ord, off;
+  *ncolor = 0;
+  for (int k = 0; k < 65; k++) offsets[k] = 0;
+  if (!fxo::color_elements(n_elem, nn, conn, NP, ord, off)) return 0;
+  *ncolor = (int32_t)off.size() - 1;
+  std::copy(ord.begin(), ord.end(), order);
+  for (size_t k = 0; k < off.size(); k++) offsets[k] = off[k];
+  for (size_t k = off.size(); k < 65; k++) offsets[k] = off.back();
+  return 0;
+}
+
 static void elastic_constants(double E, double nu, double &D11, double &D12, double &D44) {
   // calElasticMatrix, 3-D case (ElasticLinear.f90:43-55)
   D11 = E * (1.0 - nu) / (1.0 - 2.0 * nu) / (1.0 + nu);

@@ -148,6 +148,13 @@ int fx_dot_host(fx_context *ctx, const double *x, const double *y, double *resul
 int fx_mat_con(int32_t NP, int32_t n_elem, int32_t nn, const int32_t *conn, int32_t *indexL,
                int32_t *indexU, int32_t *itemL, int32_t *itemU);
 
+/* Host only: the element colouring behind the atomic-free stiffness scatter (no two elements of a colour share a node;
+ * the reference serialises the same conflicts with `!$omp atomic`, hecmw_mat_ass.f90:72-134).  order: n_elem element ids
+ * (0-based) grouped by colour; offsets: 65 entries, offsets[k]..offsets[k+1] = colour k; *ncolor = 0 when a node belongs
+ * to more than 64 elements (the device then falls back to atomics). */
+int fx_color_elements(int32_t NP, int32_t n_elem, int32_t nn, const int32_t *conn, int32_t *order, int32_t *offsets,
+                      int32_t *ncolor);
+
 /* fstr_StiffMatrix (fistr1/src/analysis/static/fstr_StiffMatrix.f90:18-212) for one
  * TYPE=361 element group with one isotropic linear-elastic material, then
  * hecmw_mat_ass_bc (matrix/hecmw_mat_ass.f90:292) for the listed dofs:

@@ -61,3 +61,42 @@ def test_mat_con_larger_mesh(oracle):
     assert np.array_equal(mat.indexU, iU) and np.array_equal(mat.itemU, jU)
     N, NPL, NPU, nb = cube_blocks(12)
     assert (mat.N, mat.NPL, mat.NPU) == (N, NPL, NPU)
+
+
+def test_color_elements_is_a_valid_colouring():
+    """Host-only fx_color_elements: every element appears once, no two elements of a colour share a node, 8 colours on a
+    structured hex mesh, graceful answer (ncolor = 0 -> atomics on the device) when a node sits in more than 64 elements."""
+    import ctypes as C
+    from frontistr_amd import hecmw
+    from frontistr_amd.mesh import CubeMesh
+    L = hecmw.lib()
+
+    def colour(conn, NP):
+        conn = np.ascontiguousarray(conn, dtype=np.int32)
+        order = np.zeros(conn.shape[0], dtype=np.int32)
+        off = np.zeros(65, dtype=np.int32)
+        nc = C.c_int32(0)
+        assert L.fx_color_elements(NP, conn.shape[0], conn.shape[1], hecmw._ptr(conn), hecmw._ptr(order), hecmw._ptr(off),
+                                   C.byref(nc)) == 0
+        return order, off, nc.value
+
+    m = CubeMesh(6, skew=0.1)
+    order, off, nc = colour(m.conn, m.n_node)
+    assert nc == 8 and off[nc] == m.conn.shape[0] and np.array_equal(np.sort(order), np.arange(m.conn.shape[0]))
+    rng = np.random.default_rng(0)
+    conn = m.conn[rng.permutation(m.conn.shape[0])]                 # an element order that is not the natural one
+    g = load_golden("exA_A361")
+    for cn, NP in ((conn, m.n_node), (g["conn"], g["coord"].shape[0])):
+        order, off, nc = colour(cn, NP)
+        assert nc >= 8 and np.array_equal(np.sort(order), np.arange(cn.shape[0]))
+        for k in range(nc):
+            nodes = cn[order[off[k]:off[k + 1]]].ravel()
+            assert np.unique(nodes).size == nodes.size, k
+    star = np.stack([np.r_[1, 2 + 7 * e + np.arange(7)] for e in range(70)]).astype(np.int32)   # node 1 in 70 elements
+    assert colour(star, 1 + 7 * 70)[2] == 0
+    bad = m.conn.copy()
+    bad[0, 0] = m.n_node + 1
+    order = np.zeros(bad.shape[0], dtype=np.int32)
+    off = np.zeros(65, dtype=np.int32)
+    nc = C.c_int32(0)
+    assert L.fx_color_elements(m.n_node, bad.shape[0], 8, hecmw._ptr(bad), hecmw._ptr(order), hecmw._ptr(off), C.byref(nc)) != 0
