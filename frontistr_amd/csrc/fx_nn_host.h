@@ -442,7 +442,12 @@ static int nn_ssor_setup(fx_context *c, int ncolor_in) {
   n->color_slice.assign(1, 0);
   std::vector<int32_t> slot_new;  // slot -> new index or -1
   for (int k = 0; k < n->ncolor; k++) {
-    for (int32_t q = cidx[k]; q < cidx[k + 1]; q++) { rows.push_back(perm[q]); slot_new.push_back(q); }
+    // rows of one colour are mutually independent: visiting them in ascending row id changes no result and keeps the gathers
+    // of neighbouring lanes close in memory (the reference's order inside a colour is the RCM visiting order)
+    std::vector<std::pair<int32_t, int32_t>> byrow;
+    for (int32_t q = cidx[k]; q < cidx[k + 1]; q++) byrow.push_back({perm[q], q});
+    std::sort(byrow.begin(), byrow.end());
+    for (auto &pr : byrow) { rows.push_back(pr.first); slot_new.push_back(pr.second); }
     while (rows.size() % 64) { rows.push_back(-1); slot_new.push_back(-1); }
     n->color_slice.push_back((int32_t)(rows.size() / 64));
   }
