@@ -5,7 +5,7 @@
 // (STF_C3D8IC), static_LIB_C3D8.f90:23-200 (STF_C3D8Bbar), static_LIB_3d.f90:47-205
 // (STF_C3), hecmw_mat_ass.f90:31-134 (scatter), :292-429 (BC).
 //
-// Work decomposition: 16 lanes per element (4 elements per wave64).  Lane a owns the
+// Work decomposition: 16 lanes per element for the IC element (4 elements per wave64), 8 lanes per element for B-bar / FI.  Lane a owns the
 // 3-row block of "node" a of the element matrix: a = 0..7 are the corner nodes,
 // a = 8..10 the three incompatible modes of the IC element.  Each lane accumulates its
 // row block over the 2x2x2 Gauss points in registers (<= 11 blocks x 9 doubles); the
@@ -19,7 +19,8 @@
 #include "fx_internal.h"
 
 #define FXA_BLOCK 256
-#define FXA_EPB (FXA_BLOCK / 16)  // elements per block
+#define FXA_LPE(EO) ((EO) == 1 ? 16 : 8)           // lanes per element: 11 row blocks for IC (8 nodes + 3 modes), 8 otherwise
+#define FXA_EPB(EO) (FXA_BLOCK / FXA_LPE(EO))    // elements per block
 
 __device__ __forceinline__ void hex8_shape_deriv(double xi, double et, double ze, double (&dN)[8][3]) {
   // hex8n.f90:24-53
@@ -124,10 +125,11 @@ __global__ __launch_bounds__(FXA_BLOCK) void k_assemble_c3d8(int32_t n_elem, con
   // elem_list != nullptr: positions [e0, n_elem) of elem_list are the elements of ONE colour (no shared nodes), scattered
   // without atomics; nullptr: elements e0..n_elem-1 in their own order with hardware fp64 atomics
   constexpr int NJ = (ELEMOPT == 1) ? 11 : 8;
-  __shared__ double Ksh[(ELEMOPT == 1) ? FXA_EPB : 1][9][34];
-  __shared__ double Xinv[(ELEMOPT == 1) ? FXA_EPB : 1][9][10];
-  const int el = threadIdx.x >> 4, a = threadIdx.x & 15;
-  const int32_t epos = e0 + blockIdx.x * FXA_EPB + el;
+  __shared__ double Ksh[(ELEMOPT == 1) ? FXA_EPB(1) : 1][9][34];
+  __shared__ double Xinv[(ELEMOPT == 1) ? FXA_EPB(1) : 1][9][10];
+  constexpr int LPE = FXA_LPE(ELEMOPT);
+  const int el = threadIdx.x / LPE, a = threadIdx.x % LPE;
+  const int32_t epos = e0 + blockIdx.x * FXA_EPB(ELEMOPT) + el;
   const bool active = (epos < n_elem) && (a < NJ);
   const int32_t elem = (elem_list && epos < n_elem) ? elem_list[epos] : epos;
   double K[NJ][9];

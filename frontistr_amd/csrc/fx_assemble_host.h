@@ -147,13 +147,13 @@ static void launch_assemble(fx_context *c, int32_t n_elem, const double *coord, 
     for (size_t k = 0; k + 1 < ec->offsets.size(); k++) {
       const int32_t e0 = ec->offsets[k], e1 = ec->offsets[k + 1];
       if (e1 <= e0) continue;
-      hipLaunchKernelGGL((k_assemble_c3d8<EO>), dim3((e1 - e0 + FXA_EPB - 1) / FXA_EPB), dim3(FXA_BLOCK), 0, c->stream, e1, coord,
+      hipLaunchKernelGGL((k_assemble_c3d8<EO>), dim3((e1 - e0 + FXA_EPB(EO) - 1) / FXA_EPB(EO)), dim3(FXA_BLOCK), 0, c->stream, e1, coord,
                          conn, D11, D12, D44, A.indexL, A.itemL, A.indexU, A.itemU, A.D, A.AL, A.AU, Kout, err, elem_mat, mat_tab,
                          (const int32_t *)ec->order, e0, (const int32_t *)ec->pos);
     }
     return;
   }
-  hipLaunchKernelGGL((k_assemble_c3d8<EO>), dim3((n_elem + FXA_EPB - 1) / FXA_EPB), dim3(FXA_BLOCK), 0, c->stream, n_elem,
+  hipLaunchKernelGGL((k_assemble_c3d8<EO>), dim3((n_elem + FXA_EPB(EO) - 1) / FXA_EPB(EO)), dim3(FXA_BLOCK), 0, c->stream, n_elem,
                      coord, conn, D11, D12, D44, A.indexL, A.itemL, A.indexU, A.itemU, A.D, A.AL, A.AU, Kout, err, elem_mat,
                      mat_tab, (const int32_t *)nullptr, 0, (const int32_t *)nullptr);
 }
