@@ -1564,11 +1564,16 @@ extern "C" int fx_solve(fx_context *c, const fx_matrix_view *m, const fx_comm_vi
 extern "C" int fx_matvec(fx_context *c, const fx_matrix_view *m, const fx_comm_view *cm, double *x, double *y,
                          double *commtime) {
   if (m->NDOF != 3) return nn_matvec(c, m, cm, x, y, commtime);
-  int what = 0;
-  if (!c->have_profile) what |= FX_UP_PROFILE;
-  if (!c->have_values) what |= FX_UP_VALUES;
-  if (what || c->A.N != m->N || c->A.NPL != m->NPL) {
-    int e = fx_upload(c, m, cm, what ? what : FX_UP_PROFILE);
+  // hecmw_matvec carries no "matrix changed" flag (Iarray(97/98) belong to hecmw_solve), and its external callers (implicit
+  // dynamics, eigen output) change hecMAT between calls: the values the caller passes are uploaded on every call.
+  // mat->D == NULL says "use the resident values" (repeated products with one matrix).
+  int what = m->D ? FX_UP_VALUES : 0;
+  if (!c->have_profile || c->A.N != m->N || c->A.NP != m->NP || c->A.NPL != m->NPL || c->A.NPU != m->NPU) what |= FX_UP_PROFILE;
+  if (!m->D && (!c->have_values || (what & FX_UP_PROFILE))) { g_fx_error = "fx_matvec: mat->D is NULL but no matrix values are resident"; return FX_ERROR_RUNTIME; }
+  if (what) {
+    fx_matrix_view mv = *m;
+    mv.B = nullptr; mv.X = nullptr;
+    int e = fx_upload(c, &mv, cm, what);
     if (e) return e;
   }
   HIP_TRY(hipSetDevice(c->device));

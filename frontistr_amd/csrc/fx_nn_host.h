@@ -698,7 +698,12 @@ static int nn_matvec(fx_context *c, const fx_matrix_view *m, const fx_comm_view 
   NnDev *n0 = nn_of(c);
   fx_matrix_view mv = *m;
   mv.B = nullptr; mv.X = nullptr;
-  if (nn_upload(c, &mv, cm, !n0->have_matrix)) return FX_ERROR_RUNTIME;
+  if (!m->D) {  // "use the resident values" (see fx_matvec)
+    if (!n0->have_matrix || n0->ndof != m->NDOF || n0->N != m->N || n0->NP != m->NP || n0->NPL != m->NPL || n0->NPU != m->NPU) {
+      g_fx_error = "fx_matvec: mat->D is NULL but no matrix values are resident";
+      return FX_ERROR_RUNTIME;
+    }
+  } else if (nn_upload(c, &mv, cm, true)) return FX_ERROR_RUNTIME;  // no change flag on this entry: values uploaded every call
   NnDev *n = nn_of(c);
   const size_t len = (size_t)n->ndof * n->NP * 8;
   HIP_TRY(hipMemcpyAsync(n->W[6], x, len, hipMemcpyHostToDevice, c->stream));

@@ -102,7 +102,9 @@ int fx_solve(fx_context *ctx, const fx_matrix_view *mat, const fx_comm_view *com
 
 /* hecmw_matvec(hecMESH, hecMAT, X, Y, COMMtime), las/hecmw_solver_las.f90:57:
  * halo update of X (X's halo part is written, as hecmw_update_3_R does), then
- * Y(1:3N) = (D + AL + AU) X.  x, y are host arrays of 3*NP doubles. */
+ * Y(1:NDOF*N) = (D + AL + AU) X.  x, y are host arrays of NDOF*NP doubles.  The reference's hecmw_matvec has no
+ * "matrix changed" flag and its external callers modify hecMAT between calls, so the values in `mat` are uploaded on every
+ * call; mat->D == NULL means "the resident values" (repeated products with one matrix: no PCIe traffic but x and y). */
 int fx_matvec(fx_context *ctx, const fx_matrix_view *mat, const fx_comm_view *comm, double *x,
               double *y, double *commtime);
 

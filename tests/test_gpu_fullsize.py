@@ -39,7 +39,7 @@ def spmv(hip, ctx, m, x):
 def test_rigid_body_modes_and_symmetry(n):
     from frontistr_amd import hecmw as hip
     mesh, m, ctx = build(hip, n, bc=False)
-    m.D = np.zeros(1); m.AL = np.zeros(1); m.AU = np.zeros(1)   # views only carry sizes; values stay on the device
+    m.D = m.AL = m.AU = None            # mat->D == NULL: the values assembled on the device are used as they are
     c = mesh.coord
     scale = None
     rng = np.random.default_rng(0)
@@ -134,7 +134,7 @@ def test_nonlinear_patch_test_fullsize(n):
     del s, s2
     # tangent of that state (no BC): symmetric, translations in the null space
     fstr.fstr_StiffMatrix(solid)
-    m.D = np.zeros(1); m.AL = np.zeros(1); m.AU = np.zeros(1)
+    m.D = m.AL = m.AU = None            # resident values (mat->D == NULL)
     rng = np.random.default_rng(1)
     w, v = rng.standard_normal(3 * m.NP), rng.standard_normal(3 * m.NP)
     Aw, Av = spmv(hip, ctx, m, w), spmv(hip, ctx, m, v)

@@ -106,3 +106,33 @@ def test_nn_recycled_preconditioner_and_new_values(hip, oracle):
     o = oracle.solve_iterative(A, I, m.Rarray, nthreads=4)
     assert np.abs(m.X - o["X"]).max() <= 1e-8 * np.abs(o["X"]).max() and abs(ctx.info.iterations - o["iter"]) <= 1
     ctx.close()
+
+
+def test_matvec_follows_changed_values_and_block_sizes_interleave(hip, oracle):
+    """hecmw_matvec has no 'matrix changed' flag: values passed are used on every call (3x3 and generic blocks); a NULL D means
+    the resident values.  One context serves a 3x3 system, a generic-block system and the 3x3 system again."""
+    from conftest import golden_matrix, load_golden
+    g = load_golden("cube4")
+    A3 = golden_matrix(g)
+    ctx = hip.SolverContext()
+    for A in (A3, nn_system(4)):
+        nd = A.NDOF
+        m = to_hip(hip, A)
+        x = np.random.default_rng(3).standard_normal(nd * A.NP)
+        y = np.zeros(nd * A.NP)
+        hip.hecmw_matvec(None, m, x.copy(), y, ctx=ctx)
+        assert np.abs(y - oracle.matvec(A, x)).max() <= 1e-13 * np.abs(y).max()
+        m.D = m.D * 2.0                                        # the caller changes hecMAT between two products
+        A2 = type(A)(A.N, A.NP, A.indexL, A.itemL, A.indexU, A.itemU, m.D, A.AL, A.AU, A.B, NDOF=nd)
+        hip.hecmw_matvec(None, m, x.copy(), y, ctx=ctx)
+        ref2 = oracle.matvec(A2, x)
+        assert np.abs(y - ref2).max() <= 1e-13 * np.abs(ref2).max()
+        m.D = m.AL = m.AU = None                               # resident values
+        y2 = np.zeros_like(y)
+        hip.hecmw_matvec(None, m, x.copy(), y2, ctx=ctx)
+        assert np.array_equal(y, y2)
+    m = to_hip(hip, A3)                                        # back to 3x3 on the same context: solve
+    m.Iarray[0], m.Iarray[2] = 10000, 1
+    assert hip.hecmw_solve(None, m, ctx=ctx) == 0
+    assert np.abs(m.X - g["sol_m1_p1_t4_X"]).max() < 1e-8 * np.abs(g["sol_m1_p1_t4_X"]).max()
+    ctx.close()
