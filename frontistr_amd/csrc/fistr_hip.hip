@@ -556,7 +556,8 @@ extern "C" int fx_upload(fx_context *c, const fx_matrix_view *m, const fx_comm_v
     HIP_TRY(hipMemcpyAsync(A.AU, m->AU, (size_t)9 * A.NPU * 8, hipMemcpyHostToDevice, c->stream));
     c->have_values = true;
     c->bell_valid = false;
-    c->precond_valid = false;
+    // the preconditioner keeps its own copy of what it was built from: new values alone do not invalidate it -- it is
+    // refreshed when Iarray(97) / (98) ask, after the recycle policy (hecmw_matrix_misc.f90:678-697), as in the reference
   }
   if ((what & FX_UP_RHS) && m->B)
     HIP_TRY(hipMemcpyAsync(A.B, m->B, (size_t)3 * A.NP * 8, hipMemcpyHostToDevice, c->stream));
@@ -1446,7 +1447,8 @@ extern "C" int fx_solve_resident(fx_context *c, int32_t *Iarray, double *Rarray,
     else Iarray[95] = 0;
   }
   // preconditioner: rebuild when the flags ask for it, reuse otherwise (SSOR_33.f90:71-79)
-  if (!c->precond_valid || Iarray[97] == 1 || Iarray[96] == 1) {
+  const int want_kind = (iterpremax <= 0) ? 0 : ((precond == 1 || precond == 2) ? 1 : precond);
+  if (!c->precond_valid || Iarray[97] == 1 || Iarray[96] == 1 || c->precond_kind != want_kind) {  // each preconditioner type has its own state in the reference
     int e = fx_precond_setup(c, Iarray, Rarray);
     if (e) return e;
   }

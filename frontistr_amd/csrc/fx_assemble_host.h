@@ -233,8 +233,7 @@ static int assemble_c3d8_common(fx_context *c, const fx_mesh_view *mesh, double 
   if (herr == 1) { g_fx_error = "PIVOT ERROR in the incompatible-mode condensation (calInverse)"; return FX_ERROR_RUNTIME; }
   if (herr == 2) { g_fx_error = "###ERROR### : cannot find connectivity (element not covered by the profile)"; return FX_ERROR_RUNTIME; }
   c->have_values = true;
-  c->bell_valid = false;
-  c->precond_valid = false;
+  c->bell_valid = false;   // the preconditioner is refreshed by the flags / recycle policy of the next solve, not here
   return 0;
 }
 

@@ -344,7 +344,7 @@ static int nn_upload(fx_context *c, const fx_matrix_view *m, const fx_comm_view 
     });
     if (nn_bell_build(c, n->M, nd, rows, ent)) return FX_ERROR_RUNTIME;
     n->have_matrix = true;
-    n->precond_valid = false;
+    if (shape) n->precond_valid = false;  // new values alone: the flags / recycle policy of the solve decide (as the 3x3 path)
   }
   if (m->B) HIP_TRY(hipMemcpy(n->B, m->B, (size_t)nd * m->NP * 8, hipMemcpyHostToDevice));
   if (m->X) HIP_TRY(hipMemcpy(n->X, m->X, (size_t)nd * m->NP * 8, hipMemcpyHostToDevice));

@@ -133,8 +133,7 @@ extern "C" int fx_nl_stiffness(fx_context *c, int32_t n_bc, const int32_t *bc_no
   if (ms_assemble) HIP_TRY(hipEventElapsedTime(ms_assemble, c->ev0, c->ev1));
   if (herr == 2) { g_fx_error = "###ERROR### : cannot find connectivity (element not covered by the profile)"; return FX_ERROR_RUNTIME; }
   c->have_values = true;
-  c->bell_valid = false;
-  c->precond_valid = false;
+  c->bell_valid = false;   // the preconditioner is refreshed by the flags / recycle policy of the next solve, not here
   return 0;
 }
 

@@ -769,6 +769,15 @@ static void scaling_33(int back, int32_t N, int32_t NP, const int32_t *indexL, c
 
 /* hecmw_solve_iterative, hecmw_solver_Iterative.f90:13-210 (serial + comm hooks).
  * Error codes: hecmw_solve_error.f90:9-15. */
+/* Preconditioner kept across calls (SSOR_33.f90:71-79 `INITIALIZED` + flags): off by default (every call builds its own),
+ * switched on by the tests of the recycle policy. */
+static int g_persist = 0;
+static orc_precond *g_P = NULL;
+void orc_persist_precond(int mode) { /* 1 start (drop what was kept), 2 resume, 3 suspend (keep), 0 stop and drop */
+  if (mode == 1 || mode == 0) { if (g_P) { orc_precond_free(g_P); g_P = NULL; } }
+  g_persist = (mode == 1 || mode == 2);
+}
+
 int orc_solve_iterative(const orc_matrix *A, const orc_comm *c, const double *B, double *X,
                         int32_t *Iarray, double *Rarray, int nthreads, int *iter_out,
                         double *resid_out, double *hist) {
@@ -829,7 +838,15 @@ int orc_solve_iterative(const orc_matrix *A, const orc_comm *c, const double *B,
     if (scaling) scaling_33(0, N, NP, A->indexL, A->itemL, A->indexU, A->itemU, sD, sAL, sAU, sB, X, scale, c);
     orc_precond *P = NULL;
     if (iterPREmax > 0) {
-      P = orc_precond_setup(A, PRECOND, SIGMA_DIAG, NCOLOR_IN, nthreads);
+      if (g_persist) { /* the module-level `save` state of the reference's preconditioners: rebuilt only when the flags ask */
+        if (!g_P || F1(Iarray, 98) == 1 || F1(Iarray, 97) == 1) {
+          orc_precond_free(g_P);
+          g_P = orc_precond_setup(A, PRECOND, SIGMA_DIAG, NCOLOR_IN, nthreads);
+        }
+        P = g_P;
+      } else {
+        P = orc_precond_setup(A, PRECOND, SIGMA_DIAG, NCOLOR_IN, nthreads);
+      }
       if (!P) return 1001;
       F1(Iarray, 98) = 0; F1(Iarray, 97) = 0;
     }
@@ -841,8 +858,8 @@ int orc_solve_iterative(const orc_matrix *A, const orc_comm *c, const double *B,
       error = orc_solve_gmres(A, c, P, iterPREmax, B, X, ITER, RESID, F1(Iarray, 6), &iter_run, &resid_run, hist, NULL);
     else if (METHOD == 4)
       error = orc_solve_gpbicg(A, c, P, iterPREmax, B, X, ITER, RESID, &iter_run, &resid_run, hist);
-    else { orc_precond_free(P); return 1001; }
-    orc_precond_free(P);
+    else { if (!g_persist) orc_precond_free(P); return 1001; }
+    if (!g_persist) orc_precond_free(P);
     if (scaling) scaling_33(1, N, NP, A->indexL, A->itemL, A->indexU, A->itemU, sD, sAL, sAU, sB, X, scale, c);
     if (error == ERR_DIVERGE_PC || error == ERR_DIVERGE_MAT) { /* :145-156 */
       F1(Iarray, 82) = 1;

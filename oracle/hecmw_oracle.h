@@ -81,6 +81,8 @@ int orc_solve_gpbicg(const orc_matrix *A, const orc_comm *c, orc_precond *P, int
                      double *X, int maxit, double tol, int *iter_out, double *resid_out, double *hist);
 /* hecmw_solver_Iterative.f90:13-210: Iarray/Rarray protocol, zero-RHS / zero-diag checks,
  * final ||b-Ax||/||b|| -> Iarray(81).  nthreads selects the SSOR ordering path. */
+/* keep the preconditioner across orc_solve_iterative calls and rebuild it only when Iarray(97)/(98) ask (recycle policy) */
+void orc_persist_precond(int on);
 int orc_solve_iterative(const orc_matrix *A, const orc_comm *c, const double *B, double *X,
                         int32_t *Iarray, double *Rarray, int nthreads, int *iter_out,
                         double *resid_out, double *hist);

@@ -148,6 +148,29 @@ def solve_iterative(m, I, R, nthreads=1, comm=None):
     return dict(code=code, iter=it.value, resid=rs.value, history=hist[:n].copy(), X=X, Iarray=I)
 
 
+def solve_sequence(m, I, R, nsolve, nthreads=1, growth=1.1):
+    """The recycle policy of the preconditioner over a sequence of solves, as oracle/ref_solve_driver.f90 mode 4 runs it through
+    the reference: solve; then (D *= growth, X = X0, Iarray(97) = 1, Iarray(98) = 0, solve) nsolve - 1 times.
+    Returns (iteration counts, last X, Iarray)."""
+    from .refrun import BSR
+    I = np.ascontiguousarray(I, dtype=np.int32).copy()
+    D = np.ascontiguousarray(m.D, dtype=np.float64).copy()
+    lib().orc_persist_precond(1)
+    iters = []
+    try:
+        for k in range(nsolve):
+            if k > 0:
+                D = D * growth
+                I[96], I[97] = 1, 0
+            Ak = BSR(m.N, m.NP, m.indexL, m.itemL, m.indexU, m.itemU, D, m.AL, m.AU, m.B, m.X, NDOF=getattr(m, "NDOF", 3))
+            o = solve_iterative(Ak, I, R, nthreads=nthreads)
+            I = o["Iarray"]
+            iters.append(o["iter"])
+    finally:
+        lib().orc_persist_precond(0)
+    return iters, o["X"], I
+
+
 def mat_con(NP, conn):
     conn = np.ascontiguousarray(conn, dtype=np.int32)
     n_elem, nn = conn.shape
@@ -338,6 +361,16 @@ class NonlinearModel:
         log = []
         I = np.ascontiguousarray(I, dtype=np.int32).copy()
         bc_idx = 3 * (np.asarray(bc_node, dtype=np.int64) - 1) + np.asarray(bc_dof, dtype=np.int64) - 1
+        # the preconditioner lives across the solves of a run and is refreshed by the recycle policy only
+        # (hecmw_matrix_misc.f90:678-697: Iarray(97) = 1 re-uses it up to maxrecycle = 3 times)
+        lib().orc_persist_precond(2 if getattr(self, "_persist", False) else 1)
+        self._persist = True
+        try:
+            return self._run_steps(bc_node, bc_dof, bc_val, cload, nsub, max_iter, converg, I, R, nthreads, factors, log, bc_idx)
+        finally:
+            lib().orc_persist_precond(3)
+
+    def _run_steps(self, bc_node, bc_dof, bc_val, cload, nsub, max_iter, converg, I, R, nthreads, factors, log, bc_idx):
         for sub in range(1, nsub + 1):
             f1, f2 = ((sub - 1) / nsub, sub / nsub) if factors is None else factors
             self.dunode[:] = 0.0

@@ -92,6 +92,21 @@ program ref_solve
 #endif
     enddo
     Y = hecMAT%X
+  case (4)   ! a sequence of solves with changing values and Iarray(97) = 1: the recycle policy of the preconditioner
+    do irep = 1, max(nrepeat, 1)   ! (hecmw_mat_recycle_precond_setting, hecmw_matrix_misc.f90:678-697) as in a Newton loop
+      if (irep > 1) then
+        hecMAT%D = hecMAT%D * 1.1d0
+        hecMAT%X = X0
+        hecMAT%Iarray(97) = 1
+        hecMAT%Iarray(98) = 0
+      endif
+#ifdef USE_SHIM
+      call hecmw_solve(hecMESH, hecMAT)
+#else
+      call hecmw_solve_iterative(hecMESH, hecMAT)
+#endif
+    enddo
+    Y = hecMAT%X
   case (2)
     tcomm = 0.d0
     do irep = 1, max(nrepeat, 1)

@@ -112,6 +112,7 @@ def parse_stdout(text):
         if m:
             info["iter"] = int(m.group(1))
             info["resid"] = float(m.group(2))
+            info.setdefault("iters", []).append(int(m.group(1)))      # one entry per solve (mode 4 runs several)
         m = re.match(r"### Relative residual =\s*([0-9.E+-]+)", line)
         if m:
             info["rel_resid"] = float(m.group(1))

@@ -84,8 +84,9 @@ def test_nn_flags_errors_and_reuse(hip, oracle):
 
 
 def test_nn_recycled_preconditioner_and_new_values(hip, oracle):
-    """Second solve with changed values and Iarray(97) = 1 rebuilds layout + preconditioner; with the flags down the
-    resident ones are reused (same answer for the same matrix)."""
+    """Second solve with changed values and Iarray(97) = 2 (force) rebuilds layout + preconditioner; with the flags down the
+    resident ones are reused (same answer for the same matrix).  Iarray(97) = 1 goes through the recycle policy:
+    tests/test_gpu_parity.py::test_preconditioner_recycle_policy."""
     A = nn_system(4)
     ctx = hip.SolverContext()
     m = to_hip(hip, A)
@@ -99,7 +100,7 @@ def test_nn_recycled_preconditioner_and_new_values(hip, oracle):
     m = to_hip(hip, A)
     m.Iarray[0] = 10000
     m.Iarray[97] = 0
-    m.Iarray[96] = 1
+    m.Iarray[96] = 2
     assert hip.hecmw_solve(None, m, ctx=ctx) == 0
     I = hip.hecmwST_matrix().Iarray
     I[0] = 10000

@@ -603,3 +603,33 @@ print('atomic scatter ok')
     p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FX_ASM_ATOMIC="1"), stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=300)
     assert p.returncode == 0 and "atomic scatter ok" in p.stdout, p.stdout[-2000:]
+
+
+@pytest.mark.parametrize("name,meth,pc,thr", __import__("test_oracle_golden").RECYCLE_CASES)
+def test_preconditioner_recycle_policy(hip, name, meth, pc, thr):
+    """hecmw_solve six times on one context, the diagonal blocks growing by 10 % and Iarray(97) = 1 before every further solve:
+    the preconditioner of solve 1 serves solves 2-4, solve 5 rebuilds it -- iteration counts of the REAL reference
+    (tests/golden/recycle.npz), +-1."""
+    import test_oracle_golden as T
+    from nn_cases import nn_system
+    g = load_golden("recycle")
+    A = nn_system(int(name[2:])) if name.startswith("nn") else golden_matrix(load_golden(name))
+    nd = getattr(A, "NDOF", 3)
+    m = hip.hecmwST_matrix.from_arrays(A.N, A.NP, A.indexL, A.itemL, A.indexU, A.itemU, A.D.copy(), A.AL, A.AU, A.B.copy(), NDOF=nd)
+    m.Iarray[0], m.Iarray[1], m.Iarray[2] = 10000, meth, pc
+    ctx = hip.SolverContext()
+    iters = []
+    for k in range(6):
+        if k > 0:
+            m.D = m.D * 1.1
+            m.X[:] = 0.0
+            m.Iarray[96], m.Iarray[97] = 1, 0
+        assert hip.hecmw_solve(None, m, ctx=ctx) == 0
+        iters.append(ctx.info.iterations)
+    tag = T.recycle_tag(name, meth, pc)
+    want = g[tag + "iters"]
+    tol = 1 if meth == 1 else 2
+    assert np.all(np.abs(np.array(iters) - want) <= tol), (iters, want.tolist())
+    assert np.array_equal(m.Iarray[95:98], g[tag + "Iarray"][95:98])
+    assert np.abs(m.X - g[tag + "X"]).max() <= 1e-7 * np.abs(g[tag + "X"]).max()
+    ctx.close()

@@ -186,3 +186,32 @@ def test_example_decks_known_answers(oracle, deck):
     o = oracle.solve_iterative(A, I, R)
     assert o["code"] == 0
     check_extrema(o["X"], g["expect"])
+
+
+# (system, METHOD, PRECOND, reference threads): cube4 is the 3x3 deck, nn2 / nn6 the generic-block systems of tests/nn_cases.py
+RECYCLE_CASES = [("cube4", 1, 1, 4), ("cube4", 1, 3, 1), ("cube4", 2, 10, 1), ("cube3s", 2, 1, 4), ("nn2", 1, 1, 4), ("nn6", 1, 3, 1)]
+
+
+def recycle_tag(name, meth, pc):
+    return "%s_m%d_p%d_" % (name, meth, pc)
+
+
+@pytest.mark.parametrize("name,meth,pc,thr", RECYCLE_CASES)
+def test_preconditioner_recycle_policy_matches_reference(oracle, name, meth, pc, thr):
+    """Six solves with growing diagonal blocks and Iarray(97) = 1: solves 2-4 re-use the first preconditioner, solve 5 rebuilds
+    (tests/golden/make_recycle_golden.py ran the same sequence through the real reference)."""
+    from nn_cases import nn_system
+    from oracle.refrun import default_params
+    g = load_golden("recycle")
+    A = nn_system(int(name[2:])) if name.startswith("nn") else golden_matrix(load_golden(name))
+    I, R = default_params(method=meth, precond=pc)
+    iters, X, Iout = oracle.solve_sequence(A, I, R, 6, nthreads=thr)
+    tag = recycle_tag(name, meth, pc)
+    assert iters == g[tag + "iters"].tolist()
+    if name == "nn6":       # the hand-unrolled DIAG_66 and the generic restatement differ in the last bits over the sequence
+        assert np.abs(X - g[tag + "X"]).max() <= 1e-12 * np.abs(X).max()
+    else:
+        assert np.array_equal(X, g[tag + "X"])
+    assert np.array_equal(Iout[95:98], g[tag + "Iarray"][95:98])
+    fresh = oracle.solve_sequence(A, I, R, 1, nthreads=thr)[0]
+    assert fresh[0] == iters[0]
