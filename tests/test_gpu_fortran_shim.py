@@ -77,3 +77,20 @@ def test_shim_generic_block_sizes(nd, meth, pc):
     tag = nn_tag(nd, meth, pc)
     assert abs(r["iter"] - int(g[tag + "iter"])) <= 1 if "iter" in r else True
     assert np.abs(r["X"] - g[tag + "X"]).max() <= 1e-8 * np.abs(g[tag + "X"]).max() and r["Iarray"][80] == 1
+
+
+def test_shim_recycle_policy_sequence():
+    """The Fortran program solves six times (values change, Iarray(97) = 1 raised each time): through the shim the GPU path applies
+    the reference's recycle policy -- iteration counts of the unmodified reference (tests/golden/recycle.npz) +-1."""
+    import test_oracle_golden as T
+    from oracle import refrun
+    if not refrun.have_ref("shim_solve"):
+        pytest.skip("oracle/_ref/shim_solve not built")
+    g = load_golden("recycle")
+    A = golden_matrix(load_golden("cube4"))
+    I, R = refrun.default_params(method=1, precond=1)
+    r = refrun.run_solve(A, I, R, exe_name="shim_solve", mode=4, nrepeat=6)
+    tag = T.recycle_tag("cube4", 1, 1)
+    assert r["returncode"] == 0 and "reference CPU solver used" not in r["stdout"]
+    assert np.array_equal(r["Iarray"][95:98], g[tag + "Iarray"][95:98])
+    assert np.abs(r["X"] - g[tag + "X"]).max() <= 1e-7 * np.abs(g[tag + "X"]).max()
