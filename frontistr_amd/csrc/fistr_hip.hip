@@ -1555,8 +1555,12 @@ extern "C" int fx_solve(fx_context *c, const fx_matrix_view *m, const fx_comm_vi
   int what = FX_UP_RHS | FX_UP_X;
   if (Iarray[97] >= 1 || !c->have_profile) what |= FX_UP_PROFILE;  // symbolic: profile changed
   if (Iarray[96] >= 1 || !c->have_values) what |= FX_UP_VALUES;    // numeric: values changed
+  // another hecMAT of the same shape without the flags raised (the reference would multiply with it, with the preconditioner
+  // it happens to have): recognised by the identity of the caller's arrays
+  if (m->D != c->host_D || m->AL != c->host_AL || m->AU != c->host_AU) what |= FX_UP_VALUES;
   int e = fx_upload(c, m, cm, what);
   if (e) return e;
+  if (what & FX_UP_VALUES) { c->host_D = m->D; c->host_AL = m->AL; c->host_AU = m->AU; }
   const int ret = fx_solve_resident(c, Iarray, Rarray, info, hist, hist_len);
   if (ret < 0 || ret == FX_ERROR_ZERO_DIAG || ret == FX_ERROR_INCONS_PC) return ret;
   e = fx_download_x(c, m->X, 3 * m->NP);

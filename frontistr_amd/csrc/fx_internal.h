@@ -238,6 +238,7 @@ struct fx_context {
   NlDev nl;
   ElemColors asm_colors;  // fx_assemble_c3d8
   void *nn = nullptr;  // NnDev (fx_nn_host.h): systems with NDOF != 3
+  const void *host_D = nullptr, *host_AL = nullptr, *host_AU = nullptr;  // the caller's arrays of the last value upload (fx_solve)
   // timing
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };

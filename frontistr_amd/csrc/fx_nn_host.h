@@ -618,8 +618,10 @@ static int nn_solve(fx_context *c, const fx_matrix_view *m, const fx_comm_view *
   if (Iarray[6] != 0) { g_fx_error = "NDOF != 3: SCALING is not on the GPU path"; return FX_ERROR_UNSUPPORTED; }
   const double t0 = now_s();
   NnDev *n0 = nn_of(c);
-  const bool values_changed = Iarray[97] >= 1 || Iarray[96] >= 1 || !n0->have_matrix;
+  const bool values_changed = Iarray[97] >= 1 || Iarray[96] >= 1 || !n0->have_matrix ||
+                              m->D != c->host_D || m->AL != c->host_AL || m->AU != c->host_AU;  // see fx_solve
   if (nn_upload(c, m, cm, values_changed)) return FX_ERROR_RUNTIME;
+  if (values_changed) { c->host_D = m->D; c->host_AL = m->AL; c->host_AU = m->AU; }
   NnDev *n = nn_of(c);
   const int nd = n->ndof;
   int ret = 0;

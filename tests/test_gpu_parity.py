@@ -633,3 +633,26 @@ def test_preconditioner_recycle_policy(hip, name, meth, pc, thr):
     assert np.array_equal(m.Iarray[95:98], g[tag + "Iarray"][95:98])
     assert np.abs(m.X - g[tag + "X"]).max() <= 1e-7 * np.abs(g[tag + "X"]).max()
     ctx.close()
+
+
+def test_two_matrices_of_one_shape_alternate_without_flags(hip, oracle):
+    """Two hecMAT of the same profile solved in turn with Iarray(97) = Iarray(98) = 0 after their first solves: each solve multiplies
+    with ITS matrix (as the reference, which reads hecMAT on every product), whatever preconditioner is resident."""
+    from oracle.refrun import BSR, default_params
+    A1 = golden_matrix(load_golden("cube4"))
+    A2 = BSR(A1.N, A1.NP, A1.indexL, A1.itemL, A1.indexU, A1.itemU, A1.D * 1.7, A1.AL, A1.AU, A1.B)
+    ctx = hip.SolverContext()
+    ms = []
+    for A in (A1, A2):
+        m = hip.hecmwST_matrix.from_arrays(A.N, A.NP, A.indexL, A.itemL, A.indexU, A.itemU, A.D, A.AL, A.AU, A.B.copy())
+        m.Iarray[0], m.Iarray[2] = 10000, 3
+        assert hip.hecmw_solve(None, m, ctx=ctx) == 0
+        ms.append(m)
+    I, R = default_params(method=1, precond=3)
+    for m, A in ((ms[0], A1), (ms[1], A2), (ms[0], A1)):
+        m.X[:] = 0.0
+        assert m.Iarray[96] == 0 and m.Iarray[97] == 0
+        assert hip.hecmw_solve(None, m, ctx=ctx) == 0 and m.Iarray[80] == 1
+        o = oracle.solve_iterative(A, I, R)
+        assert np.abs(m.X - o["X"]).max() <= 1e-7 * np.abs(o["X"]).max()
+    ctx.close()
