@@ -139,7 +139,14 @@ struct ElemColors {
 
 struct NlDev {
   bool ready = false;
-  ElemColors colors;
+  ElemColors colors;                  // order: elements grouped by NLGEOM flag, then by colour; pos: scatter position map
+  std::vector<int32_t> grp_off[3];    // per NLGEOM flag (0 INFINITE, 1 TOTALLAG, 2 UPDATELAG): positions of its colours in order (+ end)
+  bool scatter_atomic = false;        // colouring failed (a node in more than 64 elements): one range per group, fp64 atomics
+  int32_t n_mat = 1;
+  NlMat *mats = nullptr;              // device, n_mat entries (several sections); null with one material
+  int32_t *emat = nullptr;            // device, 1-based material id per element; null with one material
+  std::vector<NlMat> h_mats;
+  std::vector<double *> tabs;         // device tables of the materials
   int32_t n_elem = 0, n_bc = 0;
   NlMat mat = {};
   double *tab = nullptr;

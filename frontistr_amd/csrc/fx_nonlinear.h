@@ -206,13 +206,16 @@ __global__ __launch_bounds__(FXN_BLOCK) void k_nl_stiffness(int32_t n_elem, cons
                                                             double *__restrict__ AL, double *__restrict__ AU,
                                                             double *__restrict__ Kout, int32_t *__restrict__ err,
                                                             const int32_t *__restrict__ elem_list, int32_t e0,
-                                                            const int32_t *__restrict__ pos_map) {
-  // elem_list: positions [e0, n_elem) hold the elements of one colour (atomic-free scatter), see k_assemble_c3d8
+                                                            const int32_t *__restrict__ pos_map, int atomic,
+                                                            const NlMat *__restrict__ mats, const int32_t *__restrict__ emat) {
+  // positions [e0, n_elem) of elem_list: elements of one NLGEOM group; atomic == 0: they are of one colour (no shared node),
+  // scattered without atomics, see k_assemble_c3d8.  mats / emat: several sections, element e uses mats[emat[e] - 1].
   const int lane8 = threadIdx.x & 7;
   int32_t epos = e0 + blockIdx.x * FXN_EPB + (threadIdx.x >> 3);
   const bool active = epos < n_elem;
   if (!active) epos = n_elem - 1;  // keep the 8-lane group converged for the shuffles; results discarded
   const int32_t elem = elem_list ? elem_list[epos] : epos;
+  if (mats) m = mats[emat[elem] - 1];
   int32_t nod[8];
   double gd[8][3], bbar[8][3], Dm[21], S[6], F[9], wg;
   {
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(FXN_BLOCK) void k_nl_stiffness(int32_t n_elem, cons
       if (k < 0) { if (err) atomicExch(err, 2); continue; }
       dst = AU + (size_t)9 * k;
     }
-    if (elem_list) {
+    if (!atomic) {
 #pragma unroll
       for (int e = 0; e < 9; e++) dst[e] += K[b][e];
     } else {
@@ -367,11 +370,16 @@ __global__ __launch_bounds__(FXN_BLOCK) void k_nl_update(int32_t n_elem, const d
                                                          double *__restrict__ strain, const double *__restrict__ stress_bak,
                                                          const double *__restrict__ strain_bak, const double *__restrict__ plstrain,
                                                          double *__restrict__ fstat, int32_t *__restrict__ istat,
-                                                         double *__restrict__ qforce, double *__restrict__ qf_out) {
+                                                         double *__restrict__ qforce, double *__restrict__ qf_out,
+                                                         const int32_t *__restrict__ elem_list, int32_t e0,
+                                                         const NlMat *__restrict__ mats, const int32_t *__restrict__ emat) {
+  // positions [e0, n_elem) of elem_list: the elements of this NLGEOM group; mats / emat: several sections
   const int LX = threadIdx.x & 7;
-  int32_t elem = blockIdx.x * FXN_EPB + (threadIdx.x >> 3);
-  const bool active = elem < n_elem;
-  if (!active) elem = n_elem - 1;
+  int32_t epos = e0 + blockIdx.x * FXN_EPB + (threadIdx.x >> 3);
+  const bool active = epos < n_elem;
+  if (!active) epos = n_elem - 1;
+  const int32_t elem = elem_list ? elem_list[epos] : epos;
+  if (mats) m = mats[emat[elem] - 1];
   int32_t nod[8];
   double ec[8][3], td[8][3], e1[8][3];  // integration configuration, displacement driving the strain, end configuration
 #pragma unroll
@@ -533,10 +541,13 @@ __global__ void k_nl_residual(int64_t n3, const double *__restrict__ GL, const d
 // fstr_UpdateState: plstrain = fstatus(1) (updateEPState), strain_bak/stress_bak = strain/stress
 __global__ void k_nl_commit(int64_t npt, int plastic, const double *__restrict__ fstat, double *__restrict__ plstrain,
                             const double *__restrict__ stress, const double *__restrict__ strain, double *__restrict__ stress_bak,
-                            double *__restrict__ strain_bak) {
+                            double *__restrict__ strain_bak, const NlMat *__restrict__ mats, const int32_t *__restrict__ emat) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < 6 * npt; i += (int64_t)gridDim.x * blockDim.x) {
     stress_bak[i] = stress[i];
     strain_bak[i] = strain[i];
-    if (plastic && i < npt) plstrain[i] = fstat[i];
+    if (i < npt) {  // isElastoplastic(pMaterial%mtype) of the point's element (fstr_Update.f90:323-326)
+      const int pl = mats ? mats[emat[i >> 3] - 1].plastic : plastic;
+      if (pl) plstrain[i] = fstat[i];
+    }
   }
 }

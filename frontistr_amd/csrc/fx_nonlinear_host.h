@@ -10,51 +10,128 @@ static void nl_free(fx_context *c) {
   dev_free(n.unode); dev_free(n.dunode); dev_free(n.qforce); dev_free(n.GL);
   dev_free(n.bc_flag); dev_free(n.bc_val); dev_free(n.bc_node); dev_free(n.bc_dof); dev_free(n.bc_v); dev_free(n.err);
   dev_free(n.colors.order); dev_free(n.colors.pos);
+  dev_free(n.mats); dev_free(n.emat);
+  for (double *t : n.tabs) { double *q = t; dev_free(q); }
   n = NlDev();
 }
 
 // fstr_solid / tGaussStatus set-up for one TYPE=361 B-bar group with one material (fstr_setup.f90:325-400,
 // fstr_init_gauss mechgauss.f90:37-71): zero state, zero displacement.
-extern "C" int fx_nl_init(fx_context *c, const fx_mesh_view *mesh, const fx_material_view *mat) {
-  HIP_TRY(hipSetDevice(c->device));
-  if (!c->have_profile) { g_fx_error = "fx_nl_init: upload the profile first (fx_upload FX_UP_PROFILE)"; return FX_ERROR_RUNTIME; }
-  if (mesh->n_node != c->A.NP) { g_fx_error = "fx_nl_init: mesh/profile size mismatch"; return FX_ERROR_RUNTIME; }
+static int nl_check_material(const fx_material_view *mat) {
   if (mat->harden < 0 || mat->harden > 3 || mat->nlgeom < 0 || mat->nlgeom > 2) {
     g_fx_error = "fx_nl_init: only Mises yield with BILINEAR/MULTILINEAR/SWIFT/RAMBERG-OSGOOD hardening is on the hot path";
     return FX_ERROR_UNSUPPORTED;
   }
   if (mat->plastic && mat->harden == 1 && (mat->ntab < 1 || !mat->tab)) { g_fx_error = "fx_nl_init: MULTILINEAR hardening needs a table"; return FX_ERROR_RUNTIME; }
+  return 0;
+}
+
+static int nl_init_common(fx_context *c, const fx_mesh_view *mesh, int32_t n_mat, const fx_material_view *mats,
+                          const int32_t *elem_mat) {
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->have_profile) { g_fx_error = "fx_nl_init: upload the profile first (fx_upload FX_UP_PROFILE)"; return FX_ERROR_RUNTIME; }
+  if (mesh->n_node != c->A.NP) { g_fx_error = "fx_nl_init: mesh/profile size mismatch"; return FX_ERROR_RUNTIME; }
+  if (n_mat < 1 || !mats || (n_mat > 1 && !elem_mat)) { g_fx_error = "fx_nl_init: materials missing"; return FX_ERROR_RUNTIME; }
+  for (int32_t k = 0; k < n_mat; k++)
+    if (int e = nl_check_material(&mats[k])) return e;
   if (mesh->n_elem < 1 || mesh->n_node < 1) { g_fx_error = "fx_nl_init: empty mesh"; return FX_ERROR_RUNTIME; }
   for (int64_t k = 0; k < (int64_t)8 * mesh->n_elem; k++)
     if (mesh->conn[k] < 1 || mesh->conn[k] > mesh->n_node) { g_fx_error = "fx_nl_init: node id out of range"; return FX_ERROR_RUNTIME; }
+  if (n_mat > 1)
+    for (int32_t e = 0; e < mesh->n_elem; e++)
+      if (elem_mat[e] < 1 || elem_mat[e] > n_mat) { g_fx_error = "fx_nl_init_sections: material id out of range"; return FX_ERROR_RUNTIME; }
   nl_free(c);
   NlDev &n = c->nl;
   n.n_elem = mesh->n_elem;
+  n.n_mat = n_mat;
   const size_t np3 = (size_t)3 * c->A.NP, npt = (size_t)8 * mesh->n_elem;
   if (dev_alloc(&n.coord, np3) || dev_alloc(&n.conn, npt) || dev_alloc(&n.stress, 6 * npt) || dev_alloc(&n.strain, 6 * npt) ||
       dev_alloc(&n.stress_bak, 6 * npt) || dev_alloc(&n.strain_bak, 6 * npt) || dev_alloc(&n.plstrain, npt) ||
       dev_alloc(&n.fstat, npt) || dev_alloc(&n.istat, npt) || dev_alloc(&n.unode, np3) || dev_alloc(&n.dunode, np3) ||
       dev_alloc(&n.qforce, np3) || dev_alloc(&n.GL, np3) || dev_alloc(&n.bc_flag, np3) || dev_alloc(&n.bc_val, np3) ||
-      dev_alloc(&n.err, 1) || dev_alloc(&n.tab, (size_t)2 * std::max(mat->ntab, 1)))
+      dev_alloc(&n.err, 1))
     return FX_ERROR_RUNTIME;
   HIP_TRY(hipMemcpyAsync(n.coord, mesh->coord, np3 * 8, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(n.conn, mesh->conn, npt * 4, hipMemcpyHostToDevice, c->stream));
-  if (ensure_elem_colors(c, n.colors, mesh->n_elem, mesh->conn, mesh->n_node) || ensure_scatter_map(c, n.colors, mesh->n_elem, n.conn))
-    return FX_ERROR_RUNTIME;
-  if (mat->ntab > 0) HIP_TRY(hipMemcpyAsync(n.tab, mat->tab, (size_t)2 * mat->ntab * 8, hipMemcpyHostToDevice, c->stream));
+  // materials: one NlMat per section, hardening tables on the device
+  n.h_mats.resize((size_t)n_mat);
+  for (int32_t k = 0; k < n_mat; k++) {
+    const fx_material_view &mv = mats[k];
+    double *tab = nullptr;
+    if (dev_alloc(&tab, (size_t)2 * std::max(mv.ntab, 1))) return FX_ERROR_RUNTIME;
+    n.tabs.push_back(tab);
+    if (mv.ntab > 0) HIP_TRY(hipMemcpyAsync(tab, mv.tab, (size_t)2 * mv.ntab * 8, hipMemcpyHostToDevice, c->stream));
+    NlMat &m = n.h_mats[k];
+    m.E = mv.E; m.nu = mv.nu;
+    for (int i = 0; i < 3; i++) m.pl[i] = mv.plconst[i];
+    m.plastic = mv.plastic ? 1 : 0; m.harden = mv.harden; m.nlgeom = mv.nlgeom; m.ntab = mv.ntab;
+    m.tab = tab;
+  }
+  n.mat = n.h_mats[0];
+  n.tab = nullptr;
+  if (n_mat > 1) {
+    if (dev_alloc(&n.mats, (size_t)n_mat) || dev_alloc(&n.emat, (size_t)mesh->n_elem)) return FX_ERROR_RUNTIME;
+    HIP_TRY(hipMemcpyAsync(n.mats, n.h_mats.data(), (size_t)n_mat * sizeof(NlMat), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(n.emat, elem_mat, (size_t)mesh->n_elem * 4, hipMemcpyHostToDevice, c->stream));
+  }
+  // element lists: grouped by the NLGEOM flag of the element's material (one kernel instantiation per flag), inside a group
+  // colour by colour (fx_order.cpp: color_elements) for the atomic-free scatter
+  {
+    static const bool force_atomic = getenv("FX_ASM_ATOMIC") && atoi(getenv("FX_ASM_ATOMIC")) != 0;
+    std::vector<int32_t> order, off;
+    const bool coloured = !force_atomic && fxo::color_elements(mesh->n_elem, 8, mesh->conn, mesh->n_node, order, off);
+    if (!coloured) {
+      order.resize((size_t)mesh->n_elem);
+      for (int32_t e = 0; e < mesh->n_elem; e++) order[e] = e;
+      off = {0, mesh->n_elem};
+    }
+    n.scatter_atomic = !coloured;
+    std::vector<int32_t> grouped;
+    grouped.reserve((size_t)mesh->n_elem);
+    for (int g = 0; g < 3; g++) {
+      n.grp_off[g].clear();
+      bool any = false;
+      for (size_t k = 0; k + 1 < off.size(); k++) {
+        const size_t before = grouped.size();
+        for (int32_t q = off[k]; q < off[k + 1]; q++) {
+          const int32_t e = order[q];
+          const int flag = n.h_mats[n_mat > 1 ? elem_mat[e] - 1 : 0].nlgeom;
+          if (flag == g) grouped.push_back(e);
+        }
+        if (grouped.size() > before || any) {
+          if (!any) n.grp_off[g].push_back((int32_t)before);
+          any = true;
+          n.grp_off[g].push_back((int32_t)grouped.size());
+        }
+      }
+    }
+    if (dev_alloc(&n.colors.order, (size_t)mesh->n_elem)) return FX_ERROR_RUNTIME;
+    HIP_TRY(hipMemcpyAsync(n.colors.order, grouped.data(), (size_t)mesh->n_elem * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // grouped is a host temporary
+    n.colors.n_elem = mesh->n_elem;
+    n.colors.offsets = {0, mesh->n_elem};       // marks the lists as built (ensure_scatter_map)
+    if (ensure_scatter_map(c, n.colors, mesh->n_elem, n.conn)) return FX_ERROR_RUNTIME;
+  }
   for (double *p : {n.stress, n.strain, n.stress_bak, n.strain_bak}) HIP_TRY(hipMemsetAsync(p, 0, 6 * npt * 8, c->stream));
   for (double *p : {n.plstrain, n.fstat}) HIP_TRY(hipMemsetAsync(p, 0, npt * 8, c->stream));
   HIP_TRY(hipMemsetAsync(n.istat, 0, npt * 4, c->stream));
   for (double *p : {n.unode, n.dunode, n.qforce, n.GL, n.bc_val}) HIP_TRY(hipMemsetAsync(p, 0, np3 * 8, c->stream));
   HIP_TRY(hipMemsetAsync(n.bc_flag, 0, np3, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  n.mat.E = mat->E; n.mat.nu = mat->nu;
-  for (int i = 0; i < 3; i++) n.mat.pl[i] = mat->plconst[i];
-  n.mat.plastic = mat->plastic ? 1 : 0; n.mat.harden = mat->harden; n.mat.nlgeom = mat->nlgeom; n.mat.ntab = mat->ntab;
-  n.mat.tab = n.tab;
   n.latch = 0;
   n.ready = true;
   return 0;
+}
+
+extern "C" int fx_nl_init(fx_context *c, const fx_mesh_view *mesh, const fx_material_view *mat) {
+  return nl_init_common(c, mesh, 1, mat, nullptr);
+}
+
+// Several sections (hecMESH%section_ID -> fstrSOLID%materials, fstr_setup.f90:325-400): elem_mat[e] in 1..n_mat.  The materials may
+// carry different NLGEOM flags (an elastic TOTALLAG part next to an elastoplastic UPDATELAG part).
+extern "C" int fx_nl_init_sections(fx_context *c, const fx_mesh_view *mesh, int32_t n_mat, const fx_material_view *mats,
+                                   const int32_t *elem_mat) {
+  return nl_init_common(c, mesh, n_mat, mats, elem_mat);
 }
 
 #define NL_READY(name)                                                                              \
@@ -62,29 +139,41 @@ extern "C" int fx_nl_init(fx_context *c, const fx_mesh_view *mesh, const fx_mate
   if (!c->nl.ready) { g_fx_error = name ": call fx_nl_init first"; return FX_ERROR_RUNTIME; }
 
 template <int G>
-static void nl_launch_stiffness(fx_context *c, double *Kout) {
+static void nl_launch_stiffness_group(fx_context *c, double *Kout) {
   NlDev &n = c->nl;
   const DevCSR &A = c->A;
-  if (!Kout && !n.colors.offsets.empty()) {  // colour by colour, no atomics (fx_assemble_host.h: ensure_elem_colors)
-    for (size_t k = 0; k + 1 < n.colors.offsets.size(); k++) {
-      const int32_t e0 = n.colors.offsets[k], e1 = n.colors.offsets[k + 1];
-      if (e1 <= e0) continue;
+  const std::vector<int32_t> &off = n.grp_off[G];
+  if (off.empty()) return;
+  const bool one_range = Kout || n.scatter_atomic;  // element matrices out, or atomics: the group's colours in one launch
+  for (size_t k = 0; k + 1 < off.size(); k++) {
+    const int32_t e0 = one_range ? off.front() : off[k], e1 = one_range ? off.back() : off[k + 1];
+    if (e1 > e0)
       hipLaunchKernelGGL((k_nl_stiffness<G>), dim3((e1 - e0 + FXN_EPB - 1) / FXN_EPB), dim3(FXN_BLOCK), 0, c->stream, e1, n.coord,
                          n.conn, n.unode, n.dunode, n.mat, n.latch, n.stress, n.fstat, n.istat, A.indexL, A.itemL, A.indexU, A.itemU,
-                         A.D, A.AL, A.AU, Kout, n.err, (const int32_t *)n.colors.order, e0, (const int32_t *)n.colors.pos);
-    }
-    return;
+                         A.D, A.AL, A.AU, Kout, n.err, (const int32_t *)n.colors.order, e0, (const int32_t *)n.colors.pos,
+                         n.scatter_atomic ? 1 : 0, (const NlMat *)n.mats, (const int32_t *)n.emat);
+    if (one_range) break;
   }
-  hipLaunchKernelGGL((k_nl_stiffness<G>), dim3((n.n_elem + FXN_EPB - 1) / FXN_EPB), dim3(FXN_BLOCK), 0, c->stream, n.n_elem, n.coord,
-                     n.conn, n.unode, n.dunode, n.mat, n.latch, n.stress, n.fstat, n.istat, A.indexL, A.itemL, A.indexU, A.itemU, A.D,
-                     A.AL, A.AU, Kout, n.err, (const int32_t *)nullptr, 0, (const int32_t *)nullptr);
+}
+static void nl_launch_stiffness(fx_context *c, double *Kout) {  // one kernel instantiation per NLGEOM flag present
+  nl_launch_stiffness_group<0>(c, Kout);
+  nl_launch_stiffness_group<1>(c, Kout);
+  nl_launch_stiffness_group<2>(c, Kout);
 }
 template <int G>
-static void nl_launch_update(fx_context *c, double *qf_out) {
+static void nl_launch_update_group(fx_context *c, double *qf_out) {
   NlDev &n = c->nl;
-  hipLaunchKernelGGL((k_nl_update<G>), dim3((n.n_elem + FXN_EPB - 1) / FXN_EPB), dim3(FXN_BLOCK), 0, c->stream, n.n_elem, n.coord,
-                     n.conn, n.unode, n.dunode, n.mat, n.stress, n.strain, n.stress_bak, n.strain_bak, n.plstrain, n.fstat, n.istat,
-                     n.qforce, qf_out);
+  const std::vector<int32_t> &off = n.grp_off[G];
+  if (off.empty() || off.back() <= off.front()) return;
+  const int32_t e0 = off.front(), e1 = off.back();
+  hipLaunchKernelGGL((k_nl_update<G>), dim3((e1 - e0 + FXN_EPB - 1) / FXN_EPB), dim3(FXN_BLOCK), 0, c->stream, e1, n.coord, n.conn,
+                     n.unode, n.dunode, n.mat, n.stress, n.strain, n.stress_bak, n.strain_bak, n.plstrain, n.fstat, n.istat, n.qforce,
+                     qf_out, (const int32_t *)n.colors.order, e0, (const NlMat *)n.mats, (const int32_t *)n.emat);
+}
+static void nl_launch_update(fx_context *c, double *qf_out) {
+  nl_launch_update_group<0>(c, qf_out);
+  nl_launch_update_group<1>(c, qf_out);
+  nl_launch_update_group<2>(c, qf_out);
 }
 
 // fstr_StiffMatrix + fstr_AddBC (fstr_StiffMatrix.f90:18-212, fstr_AddBC.f90:17-190): tangent of the current
@@ -102,9 +191,7 @@ extern "C" int fx_nl_stiffness(fx_context *c, int32_t n_bc, const int32_t *bc_no
   HIP_TRY(hipMemsetAsync(A.D, 0, (size_t)9 * A.NP * 8, c->stream));  // hecmw_mat_clear
   HIP_TRY(hipMemsetAsync(A.AL, 0, (size_t)9 * A.NPL * 8, c->stream));
   HIP_TRY(hipMemsetAsync(A.AU, 0, (size_t)9 * A.NPU * 8, c->stream));
-  if (n.mat.nlgeom == 0) nl_launch_stiffness<0>(c, nullptr);
-  else if (n.mat.nlgeom == 1) nl_launch_stiffness<1>(c, nullptr);
-  else nl_launch_stiffness<2>(c, nullptr);
+  nl_launch_stiffness(c, nullptr);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemsetAsync(n.bc_flag, 0, (size_t)3 * A.NP, c->stream));
   HIP_TRY(hipMemsetAsync(n.bc_val, 0, (size_t)3 * A.NP * 8, c->stream));
@@ -183,9 +270,7 @@ extern "C" int fx_nl_update(fx_context *c, double out[4], float *ms_update) {
   hipLaunchKernelGGL(k_axpy_plain, dim3(grid_for(np3)), dim3(256), 0, c->stream, np3, 1.0, c->A.X, n.dunode);
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
   HIP_TRY(hipMemsetAsync(n.qforce, 0, (size_t)np3 * 8, c->stream));
-  if (n.mat.nlgeom == 0) nl_launch_update<0>(c, nullptr);
-  else if (n.mat.nlgeom == 1) nl_launch_update<1>(c, nullptr);
-  else nl_launch_update<2>(c, nullptr);
+  nl_launch_update(c, nullptr);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev1, c->stream));
   if (n.mat.plastic) n.latch = 1;  // MatlMatrix(..., isEp=1) has now been called (calMatMatrix.f90:43-45)
@@ -210,7 +295,7 @@ extern "C" int fx_nl_commit(fx_context *c) {
   const int64_t np3 = (int64_t)3 * c->A.NP, npt = (int64_t)8 * n.n_elem;
   hipLaunchKernelGGL(k_axpy_plain, dim3(grid_for(np3)), dim3(256), 0, c->stream, np3, 1.0, n.dunode, n.unode);
   hipLaunchKernelGGL(k_nl_commit, dim3(grid_for(6 * npt)), dim3(256), 0, c->stream, npt, n.mat.plastic, n.fstat, n.plstrain, n.stress,
-                     n.strain, n.stress_bak, n.strain_bak);
+                     n.strain, n.stress_bak, n.strain_bak, (const NlMat *)n.mats, (const int32_t *)n.emat);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
@@ -250,9 +335,7 @@ extern "C" int fx_nl_element_tangents(fx_context *c, double *ke) {
   DevScratch tmp;
   double *d = nullptr;
   if (tmp.alloc(&d, (size_t)576 * n.n_elem)) return FX_ERROR_RUNTIME;
-  if (n.mat.nlgeom == 0) nl_launch_stiffness<0>(c, d);
-  else if (n.mat.nlgeom == 1) nl_launch_stiffness<1>(c, d);
-  else nl_launch_stiffness<2>(c, d);
+  nl_launch_stiffness(c, d);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(ke, d, (size_t)576 * n.n_elem * 8, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -264,9 +347,7 @@ extern "C" int fx_nl_element_update(fx_context *c, double *qf) {
   DevScratch tmp;
   double *d = nullptr;
   if (tmp.alloc(&d, (size_t)24 * n.n_elem)) return FX_ERROR_RUNTIME;
-  if (n.mat.nlgeom == 0) nl_launch_update<0>(c, d);
-  else if (n.mat.nlgeom == 1) nl_launch_update<1>(c, d);
-  else nl_launch_update<2>(c, d);
+  nl_launch_update(c, d);
   HIP_TRY(hipGetLastError());
   if (n.mat.plastic) n.latch = 1;
   HIP_TRY(hipMemcpyAsync(qf, d, (size_t)24 * n.n_elem * 8, hipMemcpyDeviceToHost, c->stream));

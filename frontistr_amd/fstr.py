@@ -12,7 +12,7 @@
     fstr_Newton          fistr1/src/analysis/static/fstr_solve_NonLinear.f90:29
     fstr_solve_NLGEOM    fistr1/src/analysis/static/fstr_solve_NLGEOM.f90:32 (sub-step loop, linear load ramp)
 
-for one TYPE=361 B-bar group with one isotropic (Mises elastoplastic or elastic) material.  Everything is
+for one TYPE=361 B-bar group with one isotropic (Mises elastoplastic or elastic) material per section.  Everything is
 resident on the GPU; there is NO CPU fallback.
 """
 import ctypes as C
@@ -62,13 +62,23 @@ class tMaterial:
 class fstr_solid:
     """The resident nonlinear state of one context (created by fx_nl_init)."""
 
-    def __init__(self, ctx, hecMESH_coord, hecMESH_conn, material):
+    def __init__(self, ctx, hecMESH_coord, hecMESH_conn, material, elem_mat=None):
+        """material: one tMaterial, or a list of them with elem_mat (1-based material id per element = the section's
+        material, hecMESH%section_ID -> fstrSOLID%materials)."""
         self.ctx = ctx
         self.coord = np.ascontiguousarray(hecMESH_coord, dtype=np.float64)
         self.conn = np.ascontiguousarray(hecMESH_conn, dtype=np.int32)
         self.material = material
         self.n_node, self.n_elem = self.coord.shape[0], self.conn.shape[0]
         mv = hecmw._MeshView(self.n_node, self.n_elem, _ptr(self.coord), _ptr(self.conn))
+        if isinstance(material, (list, tuple)):
+            views = [m.view() for m in material]
+            arr = (_MaterialView * len(views))(*views)
+            self.elem_mat = np.ascontiguousarray(elem_mat, dtype=np.int32)
+            if self.elem_mat.shape != (self.n_elem,):
+                raise ValueError("elem_mat: one material id per element")
+            _chk(lib().fx_nl_init_sections(ctx.h, C.byref(mv), len(views), arr, _ptr(self.elem_mat)))
+            return
         m = material.view()
         _chk(lib().fx_nl_init(ctx.h, C.byref(mv), C.byref(m)))
 

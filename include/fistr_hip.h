@@ -206,6 +206,11 @@ typedef struct fx_nl_state_view { /* host arrays, any may be NULL (skipped).  tG
 } fx_nl_state_view;
 /* fstr_solid / gauss-point set-up (zero state).  Needs a profile (fx_upload FX_UP_PROFILE). */
 int fx_nl_init(fx_context *ctx, const fx_mesh_view *mesh, const fx_material_view *mat);
+/* The same for a group whose elements belong to several sections / materials: elem_mat[e] in 1..n_mat selects mats[m-1]
+ * (hecMESH%section_ID -> fstrSOLID%materials, fstr_setup.f90:325-400; every tGaussStatus%pMaterial points at its section's
+ * tMaterial).  The materials may carry different NLGEOM flags (an ELASTIC TOTALLAG part next to a PLASTIC UPDATELAG part). */
+int fx_nl_init_sections(fx_context *ctx, const fx_mesh_view *mesh, int32_t n_mat, const fx_material_view *mats,
+                        const int32_t *elem_mat);
 /* fstr_Newton :63-68 + fstr_ass_load: dunode = 0, GL (3*NP, may be NULL), B = GL - QFORCE. */
 int fx_nl_begin_substep(fx_context *ctx, const double *GL);
 /* fstr_StiffMatrix (fstr_StiffMatrix.f90:18-212) + fstr_AddBC (fstr_AddBC.f90:17-190) with the

@@ -370,6 +370,13 @@ void orc_update_c3d8bbar(const orc_material *m, const double *ecoord, const doub
 }
 
 /* fstr_StiffMatrix.f90:38-207 for one TYPE=361 B-bar group: clear, element tangents, scatter. */
+/* Several sections (hecMESH%section_ID -> fstrSOLID%materials, fstr_setup.f90:325-400): when set, element e uses
+ * mats[elem_mat[e] - 1] and the `m` argument of the three loops below is ignored.  NULL switches back to one material. */
+static const orc_material *g_mats = NULL;
+static const int32_t *g_emat = NULL;
+void orc_nl_set_sections(const orc_material *mats, const int32_t *elem_mat) { g_mats = mats; g_emat = elem_mat; }
+#define MAT_OF(e) (g_mats ? &g_mats[g_emat[e] - 1] : m)
+
 void orc_nl_stiffness(const orc_material *m, int32_t NP, int32_t n_elem, const double *coord, const int32_t *conn,
                       const double *unode, const double *dunode, const orc_gauss_state *st,
                       const int32_t *indexL, const int32_t *itemL, const int32_t *indexU, const int32_t *itemU,
@@ -385,7 +392,7 @@ void orc_nl_stiffness(const orc_material *m, int32_t NP, int32_t n_elem, const d
         ec[3 * j + i] = coord[3 * (nd[j] - 1) + i];
         u[3 * j + i] = unode[3 * (nd[j] - 1) + i] + dunode[3 * (nd[j] - 1) + i];
       }
-    orc_stf_c3d8bbar_nl(m, ec, u, st->stress + 48 * e, st->istat + 8 * e, st->fstat + 8 * e, stiff);
+    orc_stf_c3d8bbar_nl(MAT_OF(e), ec, u, st->stress + 48 * e, st->istat + 8 * e, st->fstat + 8 * e, stiff);
     orc_mat_ass_elem(NP, indexL, itemL, indexU, itemU, D, AL, AU, 8, nd, stiff);
   }
 }
@@ -403,7 +410,7 @@ void orc_nl_update(const orc_material *m, int32_t n_node, int32_t n_elem, const 
         u[3 * j + i] = unode[3 * (nd[j] - 1) + i];
         du[3 * j + i] = dunode[3 * (nd[j] - 1) + i];
       }
-    orc_update_c3d8bbar(m, ec, u, du, st->stress + 48 * e, st->strain + 48 * e, st->stress_bak + 48 * e,
+    orc_update_c3d8bbar(MAT_OF(e), ec, u, du, st->stress + 48 * e, st->strain + 48 * e, st->stress_bak + 48 * e,
                         st->strain_bak + 48 * e, st->plstrain + 8 * e, st->istat + 8 * e, st->fstat + 8 * e, qf);
     for (int j = 0; j < 8; j++)
       for (int i = 0; i < 3; i++) qforce[3 * (nd[j] - 1) + i] += qf[3 * j + i];
@@ -413,7 +420,7 @@ void orc_nl_update(const orc_material *m, int32_t n_node, int32_t n_elem, const 
 /* fstr_UpdateState, fstr_Update.f90:296-345 + updateEPState Elastoplastic.f90:563-567 */
 void orc_nl_commit(const orc_material *m, int32_t n_elem, orc_gauss_state *st) {
   for (int64_t k = 0; k < (int64_t)8 * n_elem; k++) {
-    if (m->plastic) st->plstrain[k] = st->fstat[k];
+    if (MAT_OF(k / 8)->plastic) st->plstrain[k] = st->fstat[k];
     for (int i = 0; i < 6; i++) {
       st->strain_bak[6 * k + i] = st->strain[6 * k + i];
       st->stress_bak[6 * k + i] = st->stress[6 * k + i];

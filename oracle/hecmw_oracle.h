@@ -150,6 +150,8 @@ void orc_nl_stiffness(const orc_material *m, int32_t NP, int32_t n_elem, const d
 void orc_nl_update(const orc_material *m, int32_t n_node, int32_t n_elem, const double *coord, const int32_t *conn,
                    const double *unode, const double *dunode, orc_gauss_state *st, double *qforce);
 void orc_nl_commit(const orc_material *m, int32_t n_elem, orc_gauss_state *st);
+/* several sections: element e uses mats[elem_mat[e] - 1] in the three loops above (NULL: the single material argument) */
+void orc_nl_set_sections(const orc_material *mats, const int32_t *elem_mat);
 
 #ifdef __cplusplus
 }

@@ -319,8 +319,15 @@ class NonlinearModel:
     """Mesh-level restatement: fstr_StiffMatrix + fstr_AddBC, fstr_UpdateNewton + fstr_Update_NDForce,
     fstr_UpdateState, and the fstr_Newton / fstr_solve_NLGEOM control flow around them."""
 
-    def __init__(self, mat, coord, conn):
+    def __init__(self, mat, coord, conn, elem_mat=None):
+        """mat: one material, or a list of materials with elem_mat (1-based material id per element: several sections)."""
         from .refrun import BSR
+        self.mats = list(mat) if isinstance(mat, (list, tuple)) else None
+        if self.mats is not None:
+            self.elem_mat = np.ascontiguousarray(elem_mat, dtype=np.int32)
+            self._cms = [cmaterial(x) for x in self.mats]
+            self._cmarr = (_Material * len(self._cms))(*self._cms)
+            mat = self.mats[0]
         self.mat, self.cm = mat, cmaterial(mat)
         self.coord = np.ascontiguousarray(coord, dtype=np.float64)
         self.conn = np.ascontiguousarray(conn, dtype=np.int32)
@@ -334,7 +341,14 @@ class NonlinearModel:
         self.qforce = np.zeros(3 * self.NP)
         nl_reset_latch()
 
+    def _sections(self):
+        if self.mats is not None:
+            lib().orc_nl_set_sections(self._cmarr, _ip(self.elem_mat))
+        else:
+            lib().orc_nl_set_sections(None, None)
+
     def stiffness(self):
+        self._sections()
         m, cs = self.m, cstate(self.state)
         lib().orc_nl_stiffness(C.byref(self.cm), self.NP, self.ne, _dp(self.coord), _ip(self.conn), _dp(self.unode),
                                _dp(self.dunode), C.byref(cs), _ip(m.indexL), _ip(m.itemL), _ip(m.indexU),
@@ -347,11 +361,13 @@ class NonlinearModel:
                                  _dp(m.AL), _dp(m.AU), _dp(m.B), int(n_), int(d_), C.c_double(v_))
 
     def update(self):
+        self._sections()
         cs = cstate(self.state)
         lib().orc_nl_update(C.byref(self.cm), self.NP, self.ne, _dp(self.coord), _ip(self.conn), _dp(self.unode),
                             _dp(self.dunode), C.byref(cs), _dp(self.qforce))
 
     def commit(self):
+        self._sections()
         cs = cstate(self.state)
         lib().orc_nl_commit(C.byref(self.cm), self.ne, C.byref(cs))
 

@@ -39,6 +39,11 @@ program ref_nl
   type(hecmwST_local_mesh) :: hecMESH
   type(hecmwST_matrix)     :: hecMAT
   type(tMaterial), target  :: matl
+  type(tMaterial), allocatable, target :: matls(:)   ! several sections: material 1 is the header's, 2.. follow the mesh data
+  integer(kind=4) :: n_mat, harden2, ntab2, nlgeom2, plastic2, im
+  integer(kind=4), allocatable :: elem_mat(:)
+  real(kind=8) :: EE2, PP2, pl2(3)
+  real(kind=8), allocatable :: tab2(:,:)
   type(tGaussStatus), allocatable :: gs(:,:)
   type(tTable) :: tbl
   character(len=1024) :: fin, fout
@@ -72,35 +77,29 @@ program ref_nl
   read(u) bc_dof
   read(u) bc_val
   read(u) cload
+  n_mat = 1
+  if (mode >= 10) then    ! mode = 10 + mode: n_mat, then (EE, PP, pl, harden, ntab, nlgeom, plastic, tab) per further material, elem_mat
+    mode = mode - 10
+    read(u) n_mat
+  endif
+  allocate(matls(n_mat), elem_mat(n_elem))
+  elem_mat = 1
 
   ! ---- material, as fstr_ctrl_get_ELASTICITY / fstr_ctrl_get_PLASTICITY leave it (fstr_ctrl_material.f90:60-106, :341-480)
-  call initMaterial(matl)
-  matl%mtype = ELASTIC
-  matl%nlgeom_flag = nlgeom
-  matl%variables(M_YOUNGS) = EE
-  matl%variables(M_POISSON) = PP
-  fval(1,1) = EE; fval(2,1) = PP
-  call init_table(tbl, 0, 2, 1, fval)
-  call dict_add_key(matl%dict, MC_ISOELASTIC, tbl)
-  call finalize_table(tbl)
-  if (plastic == 1) then
-    call setDigit(1, 1, matl%mtype)
-    call setDigit(2, 2, matl%mtype)
-    call setDigit(5, harden, matl%mtype)
-    call setDigit(4, 0, matl%mtype)
-    matl%variables(M_PLCONST1) = pl(1)
-    matl%variables(M_PLCONST2) = pl(2)
-    matl%variables(M_PLCONST3) = pl(3)
-    if (harden == 1) then
-      call init_table(tbl, 1, 2, ntab, tab(:,1:ntab))
-      call dict_add_key(matl%dict, MC_YIELD, tbl)
-      call finalize_table(tbl)
-    endif
-  endif
+  call make_material(matls(1), EE, PP, pl, harden, ntab, nlgeom, plastic, tab)
+  do im = 2, n_mat
+    read(u) EE2, PP2, pl2
+    read(u) harden2, ntab2, nlgeom2, plastic2
+    allocate(tab2(2,max(ntab2,1)))
+    if (ntab2 > 0) read(u) tab2(:,1:ntab2)
+    call make_material(matls(im), EE2, PP2, pl2, harden2, ntab2, nlgeom2, plastic2, tab2)
+    deallocate(tab2)
+  enddo
+  if (n_mat > 1) read(u) elem_mat
   allocate(gs(8,n_elem))
   do icel = 1, n_elem
     do i = 1, 8
-      gs(i,icel)%pMaterial => matl
+      gs(i,icel)%pMaterial => matls(elem_mat(icel))
       call fstr_init_gauss(gs(i,icel))
     enddo
   enddo
@@ -254,7 +253,7 @@ program ref_nl
     unode = unode + dunode
     do icel = 1, n_elem                ! fstr_UpdateState
       do i = 1, 8
-        if (plastic == 1) call updateEPState(gs(i,icel))
+        if (isElastoplastic(gs(i,icel)%pMaterial%mtype)) call updateEPState(gs(i,icel))   ! fstr_Update.f90:323-326
         gs(i,icel)%strain_bak = gs(i,icel)%strain
         gs(i,icel)%stress_bak = gs(i,icel)%stress
       enddo
@@ -280,6 +279,36 @@ program ref_nl
   close(u)
 
 contains
+
+  subroutine make_material(m, E_, P_, pl_, harden_, ntab_, nlgeom_, plastic_, tab_)
+    type(tMaterial), intent(inout) :: m
+    real(kind=8), intent(in) :: E_, P_, pl_(3), tab_(:,:)
+    integer(kind=4), intent(in) :: harden_, ntab_, nlgeom_, plastic_
+    real(kind=8) :: fv(2,1)
+    call initMaterial(m)
+    m%mtype = ELASTIC
+    m%nlgeom_flag = nlgeom_
+    m%variables(M_YOUNGS) = E_
+    m%variables(M_POISSON) = P_
+    fv(1,1) = E_; fv(2,1) = P_
+    call init_table(tbl, 0, 2, 1, fv)
+    call dict_add_key(m%dict, MC_ISOELASTIC, tbl)
+    call finalize_table(tbl)
+    if (plastic_ == 1) then
+      call setDigit(1, 1, m%mtype)
+      call setDigit(2, 2, m%mtype)
+      call setDigit(5, harden_, m%mtype)
+      call setDigit(4, 0, m%mtype)
+      m%variables(M_PLCONST1) = pl_(1)
+      m%variables(M_PLCONST2) = pl_(2)
+      m%variables(M_PLCONST3) = pl_(3)
+      if (harden_ == 1) then
+        call init_table(tbl, 1, 2, ntab_, tab_(:,1:ntab_))
+        call dict_add_key(m%dict, MC_YIELD, tbl)
+        call finalize_table(tbl)
+      endif
+    endif
+  end subroutine make_material
 
   subroutine gather(ic)
     integer(kind=4), intent(in) :: ic
@@ -326,8 +355,8 @@ contains
   subroutine getst()
     integer(kind=4) :: ic, ii
     a1 = 0.d0; ist = 0
-    if (plastic /= 1) return
     do ic = 1, n_elem
+      if (.not. isElastoplastic(gs(1,ic)%pMaterial%mtype)) cycle
       do ii = 1, 8
         a1(ii,ic) = gs(ii,ic)%fstatus(1)
         ist(ii,ic) = gs(ii,ic)%istatus(1)

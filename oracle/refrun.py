@@ -216,7 +216,12 @@ class Material:
         self.nlgeom = int(nlgeom)
 
 
-def _write_nl_head(f, mode, mat, coord, conn, bc_node, bc_dof, bc_val, cload, nsub, max_iter, converg, I, R):
+def _write_nl_head(f, mode, mat, coord, conn, bc_node, bc_dof, bc_val, cload, nsub, max_iter, converg, I, R, elem_mat=None):
+    """mat: one Material, or a list with elem_mat (1-based ids): mode + 10 tells the driver that further materials follow."""
+    mats = list(mat) if isinstance(mat, (list, tuple)) else [mat]
+    mat = mats[0]
+    if len(mats) > 1:
+        mode += 10
     n_node, n_elem = coord.shape[0], conn.shape[0]
     np.array([MAGIC_NL, mode, n_node, n_elem, len(bc_node), nsub, max_iter, mat.harden, mat.table.shape[0],
               mat.nlgeom, int(mat.plastic)], dtype=np.int32).tofile(f)
@@ -230,6 +235,13 @@ def _write_nl_head(f, mode, mat, coord, conn, bc_node, bc_dof, bc_val, cload, ns
     np.ascontiguousarray(bc_dof, dtype=np.int32).tofile(f)
     np.ascontiguousarray(bc_val, dtype=np.float64).tofile(f)
     np.ascontiguousarray(cload, dtype=np.float64).tofile(f)
+    if len(mats) > 1:
+        np.array([len(mats)], dtype=np.int32).tofile(f)
+        for m2 in mats[1:]:
+            np.array([m2.E, m2.nu, *m2.plconst], dtype=np.float64).tofile(f)
+            np.array([m2.harden, m2.table.shape[0], m2.nlgeom, int(m2.plastic)], dtype=np.int32).tofile(f)
+            m2.table.tofile(f)
+        np.ascontiguousarray(elem_mat, dtype=np.int32).tofile(f)
 
 
 def run_nl_elements(mat, coord, conn, unode, dunode, state, workdir=None):
@@ -268,7 +280,7 @@ def run_nl_elements(mat, coord, conn, unode, dunode, state, workdir=None):
 
 
 def run_nl_steps(mat, coord, conn, bc_node, bc_dof, bc_val, cload, nsub, max_iter, converg, I, R,
-                 threads=2, workdir=None, timeout=None):
+                 threads=2, workdir=None, timeout=None, elem_mat=None):
     """Reference load-step loop (see oracle/ref_nl_driver.f90).  Returns dict(log, unode, qforce, state)."""
     exe = os.path.join(REFDIR, "ref_nl")
     if not os.path.exists(exe):
@@ -277,7 +289,7 @@ def run_nl_steps(mat, coord, conn, bc_node, bc_dof, bc_val, cload, nsub, max_ite
     with tempfile.TemporaryDirectory(dir=workdir) as td:
         fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
         with open(fin, "wb") as f:
-            _write_nl_head(f, 2, mat, coord, conn, bc_node, bc_dof, bc_val, cload, nsub, max_iter, converg, I, R)
+            _write_nl_head(f, 2, mat, coord, conn, bc_node, bc_dof, bc_val, cload, nsub, max_iter, converg, I, R, elem_mat)
         p = subprocess.run([exe, fin, fout], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                            env=dict(os.environ, OMP_NUM_THREADS=str(threads)), timeout=timeout)
         if p.returncode != 0 or not os.path.exists(fout):

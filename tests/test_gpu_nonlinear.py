@@ -26,13 +26,15 @@ def _fmat(mat):
                           table=mat.table if mat.table.size else None, nlgeom_flag=mat.nlgeom)
 
 
-def _solid(hip, mat, m):
+def _solid(hip, mat, m, elem_mat=None):
     from frontistr_amd import fstr
     hm = hip.hecmwST_local_mesh(n_node=m.n_node)
     hm.elem_node_item = m.conn.ravel()
     hecMAT = hip.hecmw_mat_con(hm, hip.hecmwST_matrix())
     ctx = hip.SolverContext()
     ctx.upload(hecMAT, what=hip.FX_UP_PROFILE)
+    if isinstance(mat, (list, tuple)):
+        return ctx, hecMAT, fstr.fstr_solid(ctx, m.coord, m.conn, [_fmat(x) for x in mat], elem_mat=elem_mat)
     return ctx, hecMAT, fstr.fstr_solid(ctx, m.coord, m.conn, _fmat(mat))
 
 
@@ -108,6 +110,27 @@ def test_load_steps_vs_reference_golden(hip, name):
     hecMAT.Rarray[:] = R
     log = fstr.fstr_solve_NLGEOM(solid, hecMAT, bc, cload, 3, 12, T.STEP_CONVERG[name])
     _check_steps(log, solid.get_state(), g, mat.plastic)
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", ["ul", "mixed"])
+def test_load_steps_several_sections_vs_reference_golden(hip, name):
+    """Several sections / materials in one element group (fx_nl_init_sections): Mises bilinear + Mises multilinear + elastic (all
+    UPDATELAG), and Mises UPDATELAG next to elastic TOTALLAG (mixed NLGEOM flags: one kernel instantiation per flag) -- against the
+    reference's own run of the same decks (tests/golden/make_nl_sections_golden.py)."""
+    from frontistr_amd import fstr
+    T = _T()
+    ms, emat, m, bc, cload, I, R, conv = T.sections_case(name)
+    g = np.load(os.path.join(GOLD, "nl_steps_sections_%s.npz" % name))
+    ctx, hecMAT, solid = _solid(hip, ms, m, elem_mat=emat)
+    hecMAT.Iarray[:] = I
+    hecMAT.Rarray[:] = R
+    log = fstr.fstr_solve_NLGEOM(solid, hecMAT, bc, cload, 3, 12, conv)
+    _check_steps(log, solid.get_state(), g, True)
+    with pytest.raises(Exception):         # a material id outside 1..n_mat is refused
+        bad = emat.copy()
+        bad[0] = len(ms) + 1
+        fstr.fstr_solid(ctx, m.coord, m.conn, [_fmat(x) for x in ms], elem_mat=bad)
     ctx.close()
 
 

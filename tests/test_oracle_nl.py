@@ -106,6 +106,35 @@ def check_steps(model, log, want):
     assert np.array_equal(model.state["istat"], want["istat"])
 
 
+SECTION_CASES = ["ul", "mixed"]
+
+
+def sections_case(name):
+    """The bilinear step deck with several sections: (materials, elem_mat, mesh, bc, cload, I, R, converg)."""
+    mats = materials()
+    mat, m, bc, cload, I, R = step_case("mises_bilinear_ul")
+    ne = m.conn.shape[0]
+    if name == "ul":
+        ms = [mat, mats["mises_multilinear_ul"], mats["elastic_ul"]]
+    else:
+        ms = [mat, mats["elastic_tl"]]
+    emat = (1 + (np.arange(ne) % len(ms))).astype(np.int32)
+    return ms, emat, m, bc, cload, I, R, STEP_CONVERG["mises_bilinear_ul"]
+
+
+@pytest.mark.parametrize("name", SECTION_CASES)
+def test_load_steps_several_sections_vs_golden(name):
+    """Three / two materials in one element group, one of the decks with mixed NLGEOM flags
+    (tests/golden/make_nl_sections_golden.py ran them through the reference routines)."""
+    ms, emat, m, bc, cload, I, R, conv = sections_case(name)
+    g = np.load(os.path.join(GOLD, "nl_steps_sections_%s.npz" % name))
+    assert np.array_equal(g["elem_mat"], emat)
+    model = pyoracle.NonlinearModel(ms, m.coord, m.conn, elem_mat=emat)
+    log = model.run_steps(*bc, cload, 3, 12, conv, I, R, nthreads=2)
+    check_steps(model, log, g)
+    assert g["plstrain"].max() > 1e-3 and (g["plstrain"].reshape(-1, 8)[emat == len(ms)] == 0).all()   # the elastic section stays elastic
+
+
 @pytest.mark.parametrize("name", STEP_CASES)
 def test_load_steps_vs_golden(name):
     mat, m, bc, cload, I, R = step_case(name)
