@@ -166,9 +166,12 @@ static void nl_launch_update_group(fx_context *c, double *qf_out) {
   const std::vector<int32_t> &off = n.grp_off[G];
   if (off.empty() || off.back() <= off.front()) return;
   const int32_t e0 = off.front(), e1 = off.back();
+  // a group that holds every element is walked in the elements' own order (contiguous history arrays); the internal force is
+  // scattered with atomics either way
+  const int32_t *list = (e0 == 0 && e1 == n.n_elem) ? nullptr : n.colors.order;
   hipLaunchKernelGGL((k_nl_update<G>), dim3((e1 - e0 + FXN_EPB - 1) / FXN_EPB), dim3(FXN_BLOCK), 0, c->stream, e1, n.coord, n.conn,
                      n.unode, n.dunode, n.mat, n.stress, n.strain, n.stress_bak, n.strain_bak, n.plstrain, n.fstat, n.istat, n.qforce,
-                     qf_out, (const int32_t *)n.colors.order, e0, (const NlMat *)n.mats, (const int32_t *)n.emat);
+                     qf_out, list, e0, (const NlMat *)n.mats, (const int32_t *)n.emat);
 }
 static void nl_launch_update(fx_context *c, double *qf_out) {
   nl_launch_update_group<0>(c, qf_out);
