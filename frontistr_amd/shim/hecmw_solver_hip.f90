@@ -162,4 +162,26 @@ contains
     endif
   end subroutine hecmw_solve
 
+  !> The second public procedure of the reference's module (hecmw_solver.f90:80-122, no caller in fistr1): solve hecMATorig as a
+  !> system with NDOF unknowns per node.  Kept so that the module interface is complete; the solve itself is hecmw_solve above.
+  subroutine hecmw_substitute_solver(hecMESH, hecMATorig, NDOF)
+    use hecmw_util
+    use hecmw_matrix_contact
+    implicit none
+    type (hecmwST_local_mesh)      :: hecMESH
+    type (hecmwST_matrix)          :: hecMATorig
+    integer(kind=kint)             :: NDOF
+    type (hecmwST_matrix), pointer :: work
+    work => null()
+    if (NDOF < hecMATorig%NDOF) call hecmw_abort(hecmw_comm_get_comm())
+    if (NDOF == hecMATorig%NDOF) then
+      call hecmw_clone_matrix(hecMATorig, work)
+    else
+      call hecmw_blockmatrix_expand(hecMATorig, work, NDOF)
+      call hecmw_cmat_init(work%cmat)
+    endif
+    call hecmw_solve(hecMESH, work)
+    if (NDOF /= hecMATorig%NDOF) call hecmw_vector_contract(hecMATorig, work, NDOF)
+  end subroutine hecmw_substitute_solver
+
 end module hecmw_solver
