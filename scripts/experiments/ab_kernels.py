@@ -1,7 +1,7 @@
 """A/B timing of the SpMV and SSOR-apply kernels under env switches (one process per variant
 is required because the switches are read at context creation; the GPU box is otherwise idle)."""
 import os, sys, json, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from frontistr_amd import hecmw as hip
 from frontistr_amd.mesh import CubeMesh

@@ -1,15 +1,16 @@
-"""Same-process A/B of the wave-split colour sweep for CG + SSOR at 10.1M DOF (box-to-box variance is larger
-than the effect): FX_SPLIT_MAX_SLICES x FX_SPLIT_WPS, two rounds."""
+"""In-process A/B of the SSOR numbering modes (and SpMV) at 10M DOF: alternating contexts."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
 from frontistr_amd import hecmw as hip
 from frontistr_amd.mesh import CubeMesh
-mesh = CubeMesh(149)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 149
+mesh = CubeMesh(n)
 hm = hip.hecmwST_local_mesh(n_node=mesh.n_node); hm.elem_node_item = mesh.conn.ravel()
 m = hip.hecmw_mat_con(hm, hip.hecmwST_matrix())
 for rnd in range(2):
-    for split, wps in ((0, 4), (2048, 4), (2048, 8), (100000, 4), (100000, 2)):
-        os.environ["FX_SPLIT_MAX_SLICES"] = str(split); os.environ["FX_SPLIT_WPS"] = str(wps)
+    for mode in (0, 1):
+        os.environ["FX_SSOR_MODE"] = str(mode)
         ctx = hip.SolverContext()
         ctx.upload(m, what=hip.FX_UP_PROFILE)
         ctx.assemble_c3d8(mesh.coord, mesh.conn, 210000.0, 0.3, elemopt=1, load=mesh.load(), bc=mesh.dirichlet())
@@ -17,6 +18,6 @@ for rnd in range(2):
         ctx.precond_setup(m)
         ctx.krylov_begin(m); ctx.krylov_steps(10); ctx.synchronize()
         t0 = time.perf_counter(); it, st, rs = ctx.krylov_steps(100); ctx.synchronize(); dt = time.perf_counter() - t0
-        b = [ctx.precond_apply_ms(10) for _ in range(3)]
-        print("split %6d wps %d: %.1f it/s  ssor ms %s resid %.6e" % (split, wps, 100 / dt, ["%.4f" % x for x in b], rs), flush=True)
+        sp = ctx.matvec_resident_ms(20); pr = ctx.precond_apply_ms(10)
+        print("mode %d: %.1f it/s (%.3f ms/it)  spmv %.4f ms  ssor %.4f ms  resid %.6e" % (mode, 100 / dt, 10 * dt, sp, pr, rs), flush=True)
         ctx.close()

@@ -1,6 +1,6 @@
 """A/B of non-temporal matrix-stream loads: two library builds, alternating processes."""
 import os, sys, subprocess
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 code = r'''
 import os, sys, time
 sys.path.insert(0, %r)

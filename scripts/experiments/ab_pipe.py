@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from frontistr_amd import hecmw as hip
 from frontistr_amd.mesh import CubeMesh

@@ -1,6 +1,6 @@
 """Does the placement of the value stream change the SpMV time? (one process, natural order, DIAG)"""
 import os, sys, time, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from frontistr_amd import hecmw as hip
 from frontistr_amd.mesh import CubeMesh

@@ -1,7 +1,7 @@
 """SpMV workgroup size 64 vs 256 (FX_SPMV_BS) with the spatial slice order, pipelined row loop; 4 alternating rounds
 in one process to average the allocation-placement effect out."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from frontistr_amd import hecmw as hip
 from frontistr_amd.mesh import CubeMesh
 mesh = CubeMesh(149)

@@ -1,7 +1,7 @@
 """Diagnostic: per-iteration deviation of the GPU residual history from the oracle's."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import numpy as np
 from frontistr_amd import hecmw as hip
 from frontistr_amd.mesh import CubeMesh
