@@ -5,22 +5,22 @@
 // (STF_C3D8IC), static_LIB_C3D8.f90:23-200 (STF_C3D8Bbar), static_LIB_3d.f90:47-205
 // (STF_C3), hecmw_mat_ass.f90:31-134 (scatter), :292-429 (BC).
 //
-// Work decomposition: 16 lanes per element for the IC element (4 elements per wave64), 8 lanes per element for B-bar / FI.  Lane a owns the
-// 3-row block of "node" a of the element matrix: a = 0..7 are the corner nodes,
-// a = 8..10 the three incompatible modes of the IC element.  Each lane accumulates its
-// row block over the 2x2x2 Gauss points in registers (<= 11 blocks x 9 doubles); the
-// Jacobian is recomputed per lane (72 FMAs) rather than exchanged.  The IC element's
-// static condensation goes through LDS: rows 24..32 are published by lanes 8..10, one
-// lane inverts the 9x9 mode block (Gauss-Jordan with partial pivoting, as calInverse
-// utilities.f90:247-316), lanes 0..7 then condense their own rows.  The scatter is a
-// binary search in the row's item list + hardware fp64 atomic adds (the reference uses
+// Work decomposition: 8 lanes per element (8 elements per wave64).  Lane a owns the 3-row block of node a of the element
+// matrix against all its column blocks (8 nodes; for the IC element also its 3 incompatible modes) and accumulates it over
+// the 2x2x2 Gauss points in registers; the Jacobian is recomputed per lane (72 FMAs) rather than exchanged.  The IC
+// element's static condensation goes through LDS: the mode rows against the node columns are the transposes of what the
+// node lanes hold (symmetry), the 9x9 mode block is accumulated by lanes 0..2, one lane inverts it (Gauss-Jordan with
+// partial pivoting, as calInverse utilities.f90:247-316), all lanes then condense their own rows.  The scatter goes colour
+// by colour (no two elements of a launch share a node) with plain read-modify-writes at positions looked up in a map built
+// once per profile and mesh; hardware fp64 atomics + binary searches remain as the fallback (the reference uses
 // `!$omp atomic` for the same purpose).
 #pragma once
 #include "fx_internal.h"
 
 #define FXA_BLOCK 256
-#define FXA_LPE(EO) ((EO) == 1 ? 16 : 8)           // lanes per element: 11 row blocks for IC (8 nodes + 3 modes), 8 otherwise
-#define FXA_EPB(EO) (FXA_BLOCK / FXA_LPE(EO))    // elements per block
+#define FXA_LPE(EO) 8                               // lanes per element: lane a owns the 3-row block of node a
+#define FXA_BS(EO) ((EO) == 1 ? 128 : 256)          // workgroup size (IC: 16 elements x 3.2 KB of LDS for the condensation)
+#define FXA_EPB(EO) (FXA_BS(EO) / FXA_LPE(EO))     // elements per block
 
 __device__ __forceinline__ void hex8_shape_deriv(double xi, double et, double ze, double (&dN)[8][3]) {
   // hex8n.f90:24-53
@@ -110,7 +110,7 @@ __global__ void k_scatter_map(int32_t n_elem, const int32_t *__restrict__ conn, 
 }
 
 template <int ELEMOPT>
-__global__ __launch_bounds__(FXA_BLOCK) void k_assemble_c3d8(int32_t n_elem, const double *__restrict__ coord,
+__global__ __launch_bounds__(FXA_BS(ELEMOPT)) void k_assemble_c3d8(int32_t n_elem, const double *__restrict__ coord,
                                                              const int32_t *__restrict__ conn, double D11, double D12,
                                                              double D44, const int32_t *__restrict__ indexL,
                                                              const int32_t *__restrict__ itemL,
@@ -137,6 +137,13 @@ __global__ __launch_bounds__(FXA_BLOCK) void k_assemble_c3d8(int32_t n_elem, con
   for (int b = 0; b < NJ; b++)
 #pragma unroll
     for (int e = 0; e < 9; e++) K[b][e] = 0.0;
+  // IC: rows 24..32 (the three incompatible modes) against the mode columns; lanes 0..2 own mode row block a.  Their entries
+  // against the node columns are the transposes of what the node lanes hold in K[8..10] (the element matrix is symmetric).
+  double Kmm[(ELEMOPT == 1) ? 3 : 1][9];
+#pragma unroll
+  for (int b = 0; b < ((ELEMOPT == 1) ? 3 : 1); b++)
+#pragma unroll
+    for (int e = 0; e < 9; e++) Kmm[b][e] = 0.0;
   int32_t nod[8];
   if (active && elem_mat) {  // several sections: (D11, D12, D44) of this element's material (hecMESH%section_ID)
     const int32_t mid = elem_mat[elem] - 1;
@@ -188,6 +195,13 @@ __global__ __launch_bounds__(FXA_BLOCK) void k_assemble_c3d8(int32_t n_elem, con
         }
         node_B(ga, h, Ba);
       }
+      double Bm[6][3];
+      if (ELEMOPT == 1) {  // B of this lane's mode (lanes 0..2)
+        double gm[3], h0[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int d = 0; d < 3; d++) gm[d] = (a == 0) ? gd[8][d] : ((a == 1) ? gd[9][d] : gd[10][d]);
+        node_B(gm, h0, Bm);
+      }
 #pragma unroll
       for (int b = 0; b < NJ; b++) {
         double Bb[6][3], hb[3] = {0.0, 0.0, 0.0};
@@ -213,18 +227,38 @@ __global__ __launch_bounds__(FXA_BLOCK) void k_assemble_c3d8(int32_t n_elem, con
             for (int q = 0; q < 6; q++) s += Ba[q][i] * DB[q][j];
             K[b][3 * i + j] += s * wg;
           }
+        if (ELEMOPT == 1 && b >= 8 && a < 3) {
+#pragma unroll
+          for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+              double s = 0.0;
+#pragma unroll
+              for (int q = 0; q < 6; q++) s += Bm[q][i] * DB[q][j];
+              Kmm[(ELEMOPT == 1) ? b - 8 : 0][3 * i + j] += s * wg;
+            }
+        }
       }
     }
   }
   if (ELEMOPT == 1) {
-    // publish rows 24..32 (lanes 8..10), invert the 9x9 mode block, condense (3dIC.f90:206-209)
-    if (active && a >= 8) {
+    // publish rows 24..32 (node columns: transposed from the node lanes; mode columns: lanes 0..2), invert the 9x9 mode
+    // block, condense (3dIC.f90:206-209)
+    if (active) {
 #pragma unroll
-      for (int b = 0; b < 11; b++)
+      for (int al = 0; al < 3; al++)
 #pragma unroll
         for (int i = 0; i < 3; i++)
 #pragma unroll
-          for (int j = 0; j < 3; j++) Ksh[el][3 * (a - 8) + i][3 * b + j] = K[b][3 * i + j];
+          for (int j = 0; j < 3; j++) Ksh[el][3 * al + i][3 * a + j] = K[(ELEMOPT == 1) ? 8 + al : 0][3 * j + i];
+      if (a < 3) {
+#pragma unroll
+        for (int be = 0; be < 3; be++)
+#pragma unroll
+          for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) Ksh[el][3 * a + i][24 + 3 * be + j] = Kmm[be][3 * i + j];
+      }
     }
     __syncthreads();
     if (active && a == 0) {

@@ -147,13 +147,13 @@ static void launch_assemble(fx_context *c, int32_t n_elem, const double *coord, 
     for (size_t k = 0; k + 1 < ec->offsets.size(); k++) {
       const int32_t e0 = ec->offsets[k], e1 = ec->offsets[k + 1];
       if (e1 <= e0) continue;
-      hipLaunchKernelGGL((k_assemble_c3d8<EO>), dim3((e1 - e0 + FXA_EPB(EO) - 1) / FXA_EPB(EO)), dim3(FXA_BLOCK), 0, c->stream, e1, coord,
+      hipLaunchKernelGGL((k_assemble_c3d8<EO>), dim3((e1 - e0 + FXA_EPB(EO) - 1) / FXA_EPB(EO)), dim3(FXA_BS(EO)), 0, c->stream, e1, coord,
                          conn, D11, D12, D44, A.indexL, A.itemL, A.indexU, A.itemU, A.D, A.AL, A.AU, Kout, err, elem_mat, mat_tab,
                          (const int32_t *)ec->order, e0, (const int32_t *)ec->pos);
     }
     return;
   }
-  hipLaunchKernelGGL((k_assemble_c3d8<EO>), dim3((n_elem + FXA_EPB(EO) - 1) / FXA_EPB(EO)), dim3(FXA_BLOCK), 0, c->stream, n_elem,
+  hipLaunchKernelGGL((k_assemble_c3d8<EO>), dim3((n_elem + FXA_EPB(EO) - 1) / FXA_EPB(EO)), dim3(FXA_BS(EO)), 0, c->stream, n_elem,
                      coord, conn, D11, D12, D44, A.indexL, A.itemL, A.indexU, A.itemU, A.D, A.AL, A.AU, Kout, err, elem_mat,
                      mat_tab, (const int32_t *)nullptr, 0, (const int32_t *)nullptr);
 }
@@ -268,7 +268,7 @@ extern "C" int fx_element_stiffness_c3d8(fx_context *c, int elemopt, const doubl
   const int32_t *nul = nullptr;
   double *nud = nullptr;
 #define ONE(EO)                                                                                                         \
-  hipLaunchKernelGGL((k_assemble_c3d8<EO>), dim3(1), dim3(FXA_BLOCK), 0, c->stream, 1, d_coord, d_conn, D11, D12, D44, nul, \
+  hipLaunchKernelGGL((k_assemble_c3d8<EO>), dim3(1), dim3(FXA_BS(EO)), 0, c->stream, 1, d_coord, d_conn, D11, D12, D44, nul, \
                      nul, nul, nul, nud, nud, nud, d_k, d_err, nul, (const double *)nullptr, nul, 0, nul)
   if (elemopt == 1) ONE(1);
   else if (elemopt == 2) ONE(2);
