@@ -9,8 +9,9 @@
 // matrix against all its column blocks (8 nodes; for the IC element also its 3 incompatible modes) and accumulates it over
 // the 2x2x2 Gauss points in registers; the Jacobian is recomputed per lane (72 FMAs) rather than exchanged.  The IC
 // element's static condensation goes through LDS: the mode rows against the node columns are the transposes of what the
-// node lanes hold (symmetry), the 9x9 mode block is accumulated by lanes 0..2, one lane inverts it (Gauss-Jordan with
-// partial pivoting, as calInverse utilities.f90:247-316), all lanes then condense their own rows.  The scatter goes colour
+// node lanes hold (symmetry), the 9x9 mode block is accumulated by lanes 0..2, one lane factors it (Cholesky; the reference
+// inverts it with calInverse utilities.f90:247-316 -- same condensed matrix to rounding), all lanes then condense their own rows
+// with two triangular solves.  The scatter goes colour
 // by colour (no two elements of a launch share a node) with plain read-modify-writes at positions looked up in a map built
 // once per profile and mesh; hardware fp64 atomics + binary searches remain as the fallback (the reference uses
 // `!$omp atomic` for the same purpose).
@@ -262,57 +263,47 @@ __global__ __launch_bounds__(FXA_BS(ELEMOPT)) void k_assemble_c3d8(int32_t n_ele
     }
     __syncthreads();
     if (active && a == 0) {
-      double (*X)[10] = Xinv[el];
-      for (int i = 0; i < 9; i++)
-        for (int j = 0; j < 9; j++) X[i][j] = Ksh[el][i][24 + j];
-      int ip[9];
-      for (int i = 0; i < 9; i++) ip[i] = i;
+      // Cholesky factor of the 9x9 mode block (symmetric positive definite for a valid element) instead of the explicit
+      // inverse of calInverse (utilities.f90:247-316): K_cond = K - K_a,alpha (K_alpha,alpha)^-1 K_alpha,b is the same
+      // to rounding, the serial part shrinks from ~1500 to ~250 flops.  L in Xinv[el][i][j] (j <= i), 1/L_ii in column 9.
+      double (*L)[10] = Xinv[el];
       for (int k = 0; k < 9; k++) {
-        double wmax = 0.0;
-        int lr = k;
-        for (int i = k; i < 9; i++) {
-          const double w = fabs(X[i][k]);
-          if (w > wmax) { wmax = w; lr = i; }
-        }
-        const double pivot = X[lr][k];
-        if (fabs(pivot) <= 1.0e-35) { if (err) atomicExch(err, 1); }
-        if (lr != k) {
-          const int iw = ip[k]; ip[k] = ip[lr]; ip[lr] = iw;
-          for (int j = 0; j < 9; j++) { const double w = X[k][j]; X[k][j] = X[lr][j]; X[lr][j] = w; }
-        }
-        for (int i = 0; i < 9; i++) X[k][i] = X[k][i] / pivot;
-        for (int i = 0; i < 9; i++) {
-          if (i != k) {
-            const double w = X[i][k];
-            if (w != 0.0) {
-              for (int j = 0; j < 9; j++)
-                if (j != k) X[i][j] = X[i][j] - w * X[k][j];
-              X[i][k] = -w / pivot;
-            }
-          }
-        }
-        X[k][k] = 1.0 / pivot;
-      }
-      for (int i = 0; i < 9; i++) {
-        const int k = ip[i];
-        if (k != i) {
-          const int iw = ip[k]; ip[k] = ip[i]; ip[i] = iw;
-          for (int j = 0; j < 9; j++) { const double w = X[j][i]; X[j][i] = X[j][k]; X[j][k] = w; }
+        double d = Ksh[el][k][24 + k];
+        for (int j = 0; j < k; j++) d -= L[k][j] * L[k][j];
+        if (!(d > 1.0e-35)) { if (err) atomicExch(err, 1); d = 1.0; }  // the reference's PIVOT ERROR threshold
+        const double lkk = sqrt(d), inv = 1.0 / lkk;
+        L[k][k] = lkk;
+        L[k][9] = inv;
+        for (int i = k + 1; i < 9; i++) {
+          double v = Ksh[el][i][24 + k];
+          for (int j = 0; j < k; j++) v -= L[i][j] * L[k][j];
+          L[i][k] = v * inv;
         }
       }
     }
     __syncthreads();
     if (active && a < 8) {
-      double tk[3][9];  // K_a,alpha * Xinv
+      double tk[3][9];  // row i of K_a,alpha (K_alpha,alpha)^-1: two triangular solves with the factor
 #pragma unroll
-      for (int i = 0; i < 3; i++)
+      for (int i = 0; i < 3; i++) {
+        double y[9];
 #pragma unroll
-        for (int j = 0; j < 9; j++) {
-          double s = 0.0;
+        for (int q = 0; q < 9; q++) y[q] = K[(ELEMOPT == 1) ? 8 + q / 3 : 0][3 * i + (q % 3)];
 #pragma unroll
-          for (int q = 0; q < 9; q++) s += K[8 + q / 3][3 * i + (q % 3)] * Xinv[el][q][j];
-          tk[i][j] = s;
+        for (int q = 0; q < 9; q++) {  // L y' = y
+#pragma unroll
+          for (int j = 0; j < q; j++) y[q] -= Xinv[el][q][j] * y[j];
+          y[q] *= Xinv[el][q][9];
         }
+#pragma unroll
+        for (int q = 8; q >= 0; q--) {  // L^T z = y'
+#pragma unroll
+          for (int j = q + 1; j < 9; j++) y[q] -= Xinv[el][j][q] * y[j];
+          y[q] *= Xinv[el][q][9];
+        }
+#pragma unroll
+        for (int q = 0; q < 9; q++) tk[i][q] = y[q];
+      }
 #pragma unroll
       for (int b = 0; b < 8; b++)
 #pragma unroll
