@@ -1355,7 +1355,7 @@ static int host_sum(fx_context *c, int nparts, int stride, double *v0, double *v
   hipLaunchKernelGGL((k_scalar<OP_PLAIN>), dim3(1), dim3(1024), 0, c->stream, c->partials, nparts, stride, c->st,
                      (double *)nullptr, c->red_out, 1, 1);
   if (multi_rank(c) && allreduce_dev(c, c->red_out, 2)) return FX_ERROR_RUNTIME;
-  double h[2];
+  double *h = (double *)(c->st_host + 2);  // pinned (st_host holds 4 KrylovState slots; polling uses the first)
   HIP_TRY(hipMemcpyAsync(h, c->red_out, 16, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   *v0 = h[0];

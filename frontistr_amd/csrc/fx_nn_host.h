@@ -417,8 +417,10 @@ static int nn_dot(fx_context *c, const double *x, const double *y, double *out) 
   hipLaunchKernelGGL(k_nn_reduce, dim3(1), dim3(256), 0, c->stream, np, n->partials, n->scal);
   HIP_TRY(hipGetLastError());
   if (multi_rank(c) && allreduce_dev(c, n->scal, 1)) return FX_ERROR_RUNTIME;
-  HIP_TRY(hipMemcpyAsync(out, n->scal, 8, hipMemcpyDeviceToHost, c->stream));
+  double *h = (double *)(c->st_host + 3);  // pinned staging word
+  HIP_TRY(hipMemcpyAsync(h, n->scal, 8, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  *out = *h;
   return 0;
 }
 
