@@ -85,20 +85,39 @@ static int hk_prepare(fx_context *c, int maxit, double tol, int extra) {
   return 0;
 }
 
+// The two solvers are written against a small set of operations so that the 3x3 path (Ops33: slot-ordered vectors, the
+// device-resident preconditioners) and the generic-block path (OpsNN in fx_nn_host.h) share them.
+struct Ops33 {
+  fx_context *c;
+  double *X() const { return c->Xs; }
+  double *B() const { return c->Bs; }
+  double *W(int k) const { return c->W[k]; }
+  double *extra(int k) const { return c->extra + (size_t)k * c->wlen; }
+  int64_t veclen() const { return (int64_t)3 * c->ord.nslots; }
+  size_t wbytes() const { return (size_t)c->wlen * 8; }
+  int64_t ndof_np() const { return (int64_t)3 * c->A.NP; }
+  int spmv(int mode, double *x, const double *b, double *y) const { return ::spmv(c, mode, 0, x, b, y, nullptr, 0); }
+  int precond(const double *r, double *z) const { int np; return precond_apply(c, r, z, false, &np); }
+  int dot(const double *x, const double *y, double *out) const { return hk_dot(c, x, y, out); }
+  int prepare(int maxit, double tol, int extra) const { return hk_prepare(c, maxit, tol, extra); }
+};
+
 #define VLAUNCH(kern, ...) hipLaunchKernelGGL(kern, dim3(vgrid), dim3(256), 0, c->stream, n3, __VA_ARGS__)
 
-static int gmres_solve(fx_context *c, int MAXIT, double TOL, int NREST, HostKrylov *out) {
-  if (NREST >= 3 * c->A.NP - 1) NREST = 3 * c->A.NP - 2;  // :88
+template <class Ops>
+static int gmres_solve_t(const Ops &o, int MAXIT, double TOL, int NREST, HostKrylov *out) {
+  fx_context *c = o.c;
+  if (NREST >= o.ndof_np() - 1) NREST = (int)(o.ndof_np() - 2);  // :88
   if (NREST < 1) NREST = 1;
-  if (hk_prepare(c, MAXIT, TOL, NREST + 1)) return FX_ERROR_RUNTIME;
-  const int64_t n3 = (int64_t)3 * c->ord.nslots;
+  if (o.prepare(MAXIT, TOL, NREST + 1)) return FX_ERROR_RUNTIME;
+  const int64_t n3 = o.veclen();
   const int vgrid = grid_for(n3, 256, 2048);
-  double *X = c->Xs, *B = c->Bs, *R = c->W[0], *ZQ = c->W[1], *W = c->W[2], *AV = c->W[3];
-  auto V = [&](int k) { return c->extra + (size_t)(k - 1) * c->wlen; };  // V(1..NREST+1)
+  double *X = o.X(), *B = o.B(), *R = o.W(0), *ZQ = o.W(1), *W = o.W(2), *AV = o.W(3);
+  auto V = [&](int k) { return o.extra(k - 1); };  // V(1..NREST+1)
   const int NRK = NREST + 7, CS = NREST + 1, SN = CS + 1;
   std::vector<double> Hm((size_t)NRK * NRK, 0.0), S((size_t)NRK + 2, 0.0), SS((size_t)NRK + 2), Y((size_t)NRK + 2);
   auto H = [&](int i, int j) -> double & { return Hm[(size_t)(i - 1) * NRK + (j - 1)]; };
-  int np, ITER = 0, I = 0, error = 0;
+  int ITER = 0, I = 0, error = 0;
   double RESID = 0.0, BNRM2, DNRM2, val;
   auto update_x = [&](int IROW) -> int {  // [H]{y} = {s}; {x} += Minv (V y)  (:264-292)
     for (int ik = 1; ik <= IROW; ik++) SS[ik] = S[ik];
@@ -107,19 +126,19 @@ static int gmres_solve(fx_context *c, int MAXIT, double TOL, int NREST, HostKryl
       for (int jj = IROW; jj >= kk + 1; jj--) SS[kk] = SS[kk] - H(kk, jj) * Y[jj];
       Y[kk] = SS[kk] / H(kk, kk);
     }
-    HIP_TRY(hipMemsetAsync(AV, 0, (size_t)c->wlen * 8, c->stream));
+    HIP_TRY(hipMemsetAsync(AV, 0, o.wbytes(), c->stream));
     for (int jj = 1; jj <= IROW; jj++) VLAUNCH(k_axpy_plain, Y[jj], V(jj), AV);
-    if (precond_apply(c, AV, ZQ, false, &np)) return FX_ERROR_RUNTIME;
+    if (o.precond(AV, ZQ)) return FX_ERROR_RUNTIME;
     VLAUNCH(k_axpy_plain, 1.0, ZQ, X);
     HIP_TRY(hipGetLastError());
     return 0;
   };
-  if (spmv(c, 1, 0, X, B, R, nullptr, 0)) return FX_ERROR_RUNTIME;  // :127
-  if (hk_dot(c, B, B, &BNRM2)) return FX_ERROR_RUNTIME;
-  if (BNRM2 == 0.0) { MAXIT = 0; RESID = 0.0; HIP_TRY(hipMemsetAsync(X, 0, (size_t)c->wlen * 8, c->stream)); }
+  if (o.spmv(1, X, B, R)) return FX_ERROR_RUNTIME;  // :127
+  if (o.dot(B, B, &BNRM2)) return FX_ERROR_RUNTIME;
+  if (BNRM2 == 0.0) { MAXIT = 0; RESID = 0.0; HIP_TRY(hipMemsetAsync(X, 0, o.wbytes(), c->stream)); }
   for (;;) {  // OUTER
     I = 0;
-    if (hk_dot(c, R, R, &DNRM2)) return FX_ERROR_RUNTIME;
+    if (o.dot(R, R, &DNRM2)) return FX_ERROR_RUNTIME;
     if (DNRM2 == 0.0) break;
     const double RNORM = sqrt(DNRM2);
     VLAUNCH(k_scale_copy, 1.0 / RNORM, R, V(1));
@@ -128,14 +147,14 @@ static int gmres_solve(fx_context *c, int MAXIT, double TOL, int NREST, HostKryl
     bool converged = false, failed = false;
     for (I = 1; I <= NREST; I++) {
       ITER++;
-      if (precond_apply(c, V(I), ZQ, false, &np)) return FX_ERROR_RUNTIME;  // :195
-      if (spmv(c, 0, 0, ZQ, nullptr, W, nullptr, 0)) return FX_ERROR_RUNTIME;
+      if (o.precond(V(I), ZQ)) return FX_ERROR_RUNTIME;  // :195
+      if (o.spmv(0, ZQ, nullptr, W)) return FX_ERROR_RUNTIME;
       for (int K = 1; K <= I; K++) {  // modified Gram-Schmidt :207-214
-        if (hk_dot(c, W, V(K), &val)) return FX_ERROR_RUNTIME;
+        if (o.dot(W, V(K), &val)) return FX_ERROR_RUNTIME;
         VLAUNCH(k_axpy_plain, -val, V(K), W);
         H(K, I) = val;
       }
-      if (hk_dot(c, W, W, &val)) return FX_ERROR_RUNTIME;
+      if (o.dot(W, W, &val)) return FX_ERROR_RUNTIME;
       if (val == 0.0) break;
       H(I + 1, I) = sqrt(val);
       VLAUNCH(k_scale_copy, 1.0 / H(I + 1, I), W, V(I + 1));
@@ -175,8 +194,8 @@ static int gmres_solve(fx_context *c, int MAXIT, double TOL, int NREST, HostKryl
     }
     if (converged || failed) break;
     if (update_x(NREST)) return FX_ERROR_RUNTIME;  // restart :311-351
-    if (spmv(c, 1, 0, X, B, R, nullptr, 0)) return FX_ERROR_RUNTIME;
-    if (hk_dot(c, R, R, &DNRM2)) return FX_ERROR_RUNTIME;
+    if (o.spmv(1, X, B, R)) return FX_ERROR_RUNTIME;
+    if (o.dot(R, R, &DNRM2)) return FX_ERROR_RUNTIME;
     if (I + 1 <= NRK) S[I + 1] = sqrt(DNRM2 / BNRM2);
     RESID = sqrt(DNRM2 / BNRM2);
     if (RESID <= TOL) break;
@@ -188,42 +207,43 @@ static int gmres_solve(fx_context *c, int MAXIT, double TOL, int NREST, HostKryl
   return 0;
 }
 
-static int gpbicg_solve(fx_context *c, int MAXIT, double TOL, HostKrylov *out) {
+template <class Ops>
+static int gpbicg_solve_t(const Ops &o, int MAXIT, double TOL, HostKrylov *out) {
+  fx_context *c = o.c;
   const int RECOMPUTE = 20;
-  if (hk_prepare(c, MAXIT, TOL, 5)) return FX_ERROR_RUNTIME;
-  const int64_t n3 = (int64_t)3 * c->ord.nslots;
+  if (o.prepare(MAXIT, TOL, 5)) return FX_ERROR_RUNTIME;
+  const int64_t n3 = o.veclen();
   const int vgrid = grid_for(n3, 256, 2048);
-  double *X = c->Xs, *B = c->Bs;
-  double *R = c->W[0], *RT = c->W[1], *T = c->W[2], *TT = c->W[3], *T0 = c->W[4], *P = c->W[5], *PT = c->W[6], *U = c->W[7];
-  double *W1 = c->extra, *Y = c->extra + (size_t)c->wlen, *Z = c->extra + (size_t)2 * c->wlen, *WK = c->extra + (size_t)3 * c->wlen,
-         *W2 = c->extra + (size_t)4 * c->wlen;
-  int np, iter = 0, error = 0;
+  double *X = o.X(), *B = o.B();
+  double *R = o.W(0), *RT = o.W(1), *T = o.W(2), *TT = o.W(3), *T0 = o.W(4), *P = o.W(5), *PT = o.W(6), *U = o.W(7);
+  double *W1 = o.extra(0), *Y = o.extra(1), *Z = o.extra(2), *WK = o.extra(3), *W2 = o.extra(4);
+  int iter = 0, error = 0;
   double RESID = 0.0, BETA = 0.0, ALPHA, QSI, ETA, RHO, RHO1, BNRM2, DNRM2, COEF1;
-  if (spmv(c, 1, 0, X, B, R, nullptr, 0)) return FX_ERROR_RUNTIME;  // :113
+  if (o.spmv(1, X, B, R)) return FX_ERROR_RUNTIME;  // :113
   VLAUNCH(k_copy, R, RT);
-  if (hk_dot(c, B, B, &BNRM2)) return FX_ERROR_RUNTIME;
-  if (BNRM2 == 0.0) { MAXIT = 0; RESID = 0.0; HIP_TRY(hipMemsetAsync(X, 0, (size_t)c->wlen * 8, c->stream)); }
-  if (hk_dot(c, RT, R, &RHO)) return FX_ERROR_RUNTIME;
+  if (o.dot(B, B, &BNRM2)) return FX_ERROR_RUNTIME;
+  if (BNRM2 == 0.0) { MAXIT = 0; RESID = 0.0; HIP_TRY(hipMemsetAsync(X, 0, o.wbytes(), c->stream)); }
+  if (o.dot(RT, R, &RHO)) return FX_ERROR_RUNTIME;
   for (iter = 1; iter <= MAXIT; iter++) {
     VLAUNCH(k_copy, R, WK);  // :155-159
-    if (precond_apply(c, WK, R, false, &np)) return FX_ERROR_RUNTIME;
+    if (o.precond(WK, R)) return FX_ERROR_RUNTIME;
     VLAUNCH(k_gp_p, BETA, (int)(iter == 1), R, U, P);
-    if (spmv(c, 0, 0, P, nullptr, PT, nullptr, 0)) return FX_ERROR_RUNTIME;  // :184
-    if (hk_dot(c, RT, PT, &RHO1)) return FX_ERROR_RUNTIME;
+    if (o.spmv(0, P, nullptr, PT)) return FX_ERROR_RUNTIME;  // :184
+    if (o.dot(RT, PT, &RHO1)) return FX_ERROR_RUNTIME;
     ALPHA = RHO / RHO1;
     VLAUNCH(k_gp_yt, ALPHA, WK, W1, PT, Y, T);
-    if (precond_apply(c, T, TT, false, &np)) return FX_ERROR_RUNTIME;  // :211-216
-    if (precond_apply(c, T0, W2, false, &np)) return FX_ERROR_RUNTIME;
+    if (o.precond(T, TT)) return FX_ERROR_RUNTIME;  // :211-216
+    if (o.precond(T0, W2)) return FX_ERROR_RUNTIME;
     VLAUNCH(k_copy, W2, T0);
-    if (precond_apply(c, PT, W2, false, &np)) return FX_ERROR_RUNTIME;
-    if (spmv(c, 0, 0, TT, nullptr, WK, nullptr, 0)) return FX_ERROR_RUNTIME;  // :221-225
+    if (o.precond(PT, W2)) return FX_ERROR_RUNTIME;
+    if (o.spmv(0, TT, nullptr, WK)) return FX_ERROR_RUNTIME;  // :221-225
     VLAUNCH(k_copy, WK, TT);
     {  // pol_coef_vanilla2 :457-503
       const double OMEGA = 0.707106781;
       double CG[6] = {0, 0, 0, 0, 0, 0}, gamma1 = 0.0, gamma2 = 0.0;
-      if (hk_dot(c, T, T, &CG[0]) || hk_dot(c, TT, TT, &CG[1]) || hk_dot(c, T, TT, &CG[2])) return FX_ERROR_RUNTIME;
+      if (o.dot(T, T, &CG[0]) || o.dot(TT, TT, &CG[1]) || o.dot(T, TT, &CG[2])) return FX_ERROR_RUNTIME;
       if (iter > 1) {
-        if (hk_dot(c, Y, Y, &CG[3]) || hk_dot(c, Y, TT, &CG[4]) || hk_dot(c, Y, T, &CG[5])) return FX_ERROR_RUNTIME;
+        if (o.dot(Y, Y, &CG[3]) || o.dot(Y, TT, &CG[4]) || o.dot(Y, T, &CG[5])) return FX_ERROR_RUNTIME;
         gamma1 = CG[5] / CG[3];
         gamma2 = CG[4] / CG[3];
       }
@@ -236,11 +256,11 @@ static int gpbicg_solve(fx_context *c, int MAXIT, double TOL, HostKrylov *out) {
     VLAUNCH(k_gp_uz, QSI, ETA, ALPHA, BETA, (int)(iter == 1), W2, T0, R, U, Z);
     VLAUNCH(k_gp_x, ALPHA, P, Z, T, X, T0);
     if (iter % RECOMPUTE == 0) {  // :268-274
-      if (spmv(c, 1, 0, X, B, R, nullptr, 0)) return FX_ERROR_RUNTIME;
+      if (o.spmv(1, X, B, R)) return FX_ERROR_RUNTIME;
     } else {
       VLAUNCH(k_gp_r, ETA, QSI, T, Y, TT, R);
     }
-    if (hk_dot(c, R, R, &DNRM2) || hk_dot(c, R, RT, &COEF1)) return FX_ERROR_RUNTIME;
+    if (o.dot(R, R, &DNRM2) || o.dot(R, RT, &COEF1)) return FX_ERROR_RUNTIME;
     BETA = ALPHA * COEF1 / (QSI * RHO);
     VLAUNCH(k_gp_w1, BETA, TT, PT, W1);
     RESID = sqrt(DNRM2 / BNRM2);
@@ -249,8 +269,8 @@ static int gpbicg_solve(fx_context *c, int MAXIT, double TOL, HostKrylov *out) {
     if (!std::isfinite(RESID)) { error = FX_ERROR_NOCONV_MAXIT; break; }  // breakdown: same guard as the BiCGSTAB path
     if (RESID <= TOL) {  // :300-307
       if (iter % RECOMPUTE == 0) break;
-      if (spmv(c, 1, 0, X, B, R, nullptr, 0)) return FX_ERROR_RUNTIME;
-      if (hk_dot(c, R, R, &DNRM2)) return FX_ERROR_RUNTIME;
+      if (o.spmv(1, X, B, R)) return FX_ERROR_RUNTIME;
+      if (o.dot(R, R, &DNRM2)) return FX_ERROR_RUNTIME;
       RESID = sqrt(DNRM2 / BNRM2);
       if (RESID <= TOL) break;
     }
@@ -262,3 +282,8 @@ static int gpbicg_solve(fx_context *c, int MAXIT, double TOL, HostKrylov *out) {
   return 0;
 }
 #undef VLAUNCH
+
+static int gmres_solve(fx_context *c, int MAXIT, double TOL, int NREST, HostKrylov *out) {
+  return gmres_solve_t(Ops33{c}, MAXIT, TOL, NREST, out);
+}
+static int gpbicg_solve(fx_context *c, int MAXIT, double TOL, HostKrylov *out) { return gpbicg_solve_t(Ops33{c}, MAXIT, TOL, out); }

@@ -5,6 +5,7 @@
 //   hecmw_precond_SSOR_nn_*    hecmw1/src/solver/precond/nn/hecmw_precond_SSOR_nn.f90:55-420   (RCM + multicolour ordering)
 //   hecmw_precond_nn_apply     hecmw1/src/solver/precond/nn/hecmw_precond_nn.f90 (additive Schwarz loop over iterPREmax)
 //   hecmw_solve_CG / BiCGSTAB  hecmw1/src/solver/iterative/hecmw_solver_CG.f90:19-312, hecmw_solver_BiCGSTAB.f90:16-297
+//   hecmw_solve_GMRES / GPBiCG hecmw_solver_GMRES.f90:17-458, hecmw_solver_GPBiCG.f90:17-505 (fx_krylov2_host.h through OpsNN)
 //   hecmw_solve_iterative      hecmw1/src/solver/iterative/hecmw_solver_Iterative.f90:13-210 (checks, flags, final residual)
 //
 // Layout: the same sliced block-ELL idea as the 3x3 path -- one thread per block row, 64 rows per slice, slice width =
@@ -36,6 +37,8 @@ struct NnDev {
   double *D = nullptr, *alu = nullptr, *B = nullptr, *X = nullptr;
   double *W[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   double *partials = nullptr, *scal = nullptr;
+  double *extra = nullptr;  // GMRES basis / GPBiCG work vectors (count * NDOF * NP)
+  int extra_n = 0, iterpremax = 1;
   // halo tables in the caller's numbering (0-based)
   int32_t n_neighbor = 0, n_export = 0, n_import = 0;
   std::vector<int32_t> neighbor, export_index, import_index;
@@ -67,7 +70,7 @@ static void nn_free(fx_context *c) {
   nn_bell_free(n->M); nn_bell_free(n->L); nn_bell_free(n->U);
   dev_free(n->D); dev_free(n->alu); dev_free(n->B); dev_free(n->X);
   for (auto &w : n->W) dev_free(w);
-  dev_free(n->partials); dev_free(n->scal);
+  dev_free(n->partials); dev_free(n->scal); dev_free(n->extra);
   dev_free(n->export_item); dev_free(n->import_item); dev_free(n->sendbuf); dev_free(n->recvbuf);
   if (n->h_send) (void)hipHostFree(n->h_send);
   if (n->h_recv) (void)hipHostFree(n->h_recv);
@@ -610,6 +613,34 @@ static int nn_bicgstab(fx_context *c, int MAXIT, double TOL, int iterpremax, NnR
   return 0;
 }
 
+// GMRES(m) and GPBiCG of fx_krylov2_host.h on the generic-block system
+struct OpsNN {
+  fx_context *c;
+  NnDev *n() const { return nn_of(c); }
+  double *X() const { return n()->X; }
+  double *B() const { return n()->B; }
+  double *W(int k) const { return n()->W[k]; }
+  double *extra(int k) const { return n()->extra + (size_t)k * n()->ndof * n()->NP; }
+  int64_t veclen() const { return (int64_t)n()->ndof * n()->N; }
+  size_t wbytes() const { return (size_t)n()->ndof * n()->NP * 8; }
+  int64_t ndof_np() const { return (int64_t)n()->ndof * n()->NP; }
+  int spmv(int mode, double *x, const double *b, double *y) const { return nn_spmv(c, mode, x, b, y); }
+  int precond(const double *r, double *z) const { return nn_precond_apply(c, n()->iterpremax, r, z); }
+  int dot(const double *x, const double *y, double *out) const { return nn_dot(c, x, y, out); }
+  int prepare(int, double, int count) const {
+    NnDev *d = n();
+    const size_t len = (size_t)d->ndof * d->NP;
+    for (int k = 0; k < 8; k++) HIP_TRY(hipMemsetAsync(d->W[k], 0, len * 8, c->stream));
+    if (d->extra_n < count) {
+      dev_free(d->extra);
+      if (dev_alloc(&d->extra, (size_t)count * len)) return FX_ERROR_RUNTIME;
+      d->extra_n = count;
+    }
+    HIP_TRY(hipMemsetAsync(d->extra, 0, (size_t)count * len * 8, c->stream));
+    return 0;
+  }
+};
+
 // hecmw_solve for NDOF != 3: host arrays in, host X out (fx_solve forwards here)
 static int nn_solve(fx_context *c, const fx_matrix_view *m, const fx_comm_view *cm, int32_t *Iarray, double *Rarray,
                     fx_solve_info *info, double *hist, int32_t hist_len) {
@@ -665,9 +696,14 @@ static int nn_solve(fx_context *c, const fx_matrix_view *m, const fx_comm_view *
     Iarray[80] = 0; Iarray[81] = 0;
     res = NnResult();
     int e;
+    n->iterpremax = iterpremax;
     if (method == 1) e = nn_cg(c, maxit, Rarray[0], iterpremax, &res);
     else if (method == 2) e = nn_bicgstab(c, maxit, Rarray[0], iterpremax, &res);
-    else { g_fx_error = "NDOF != 3: METHOD must be 1 (CG) or 2 (BiCGSTAB) on the GPU path"; return FX_ERROR_INCONS_PC; }
+    else if (method == 3 || method == 4) {
+      HostKrylov hk;
+      e = (method == 3) ? gmres_solve_t(OpsNN{c}, maxit, Rarray[0], Iarray[5], &hk) : gpbicg_solve_t(OpsNN{c}, maxit, Rarray[0], &hk);
+      res.iter = hk.iter; res.resid = hk.resid; res.error = hk.error; res.hist = hk.hist;
+    } else { g_fx_error = "METHOD must be 1 (CG), 2 (BiCGSTAB), 3 (GMRES) or 4 (GPBiCG)"; return FX_ERROR_INCONS_PC; }
     if (e) return e;
     if (res.error == FX_ERROR_DIVERGE_PC || res.error == FX_ERROR_DIVERGE_MAT) {  // Iterative.f90:145-156
       Iarray[81] = 1;

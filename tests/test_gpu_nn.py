@@ -68,7 +68,7 @@ def test_nn_flags_errors_and_reuse(hip, oracle):
     m.D[4 * 5 + 3] = 0.0
     with pytest.raises(hip.HecmwSolverError):
         hip.hecmw_solve(None, m, ctx=ctx)
-    for bad in ((1, 10), (3, 3)):        # block ILU / GMRES of the other block sizes are not on the GPU path
+    for bad in ((1, 10), (5, 3)):        # block ILU of the other block sizes / an unknown method are not on the GPU path
         m = to_hip(hip, A)
         m.Iarray[1], m.Iarray[2] = bad
         with pytest.raises(hip.HecmwSolverError):
@@ -136,4 +136,29 @@ def test_matvec_follows_changed_values_and_block_sizes_interleave(hip, oracle):
     m.Iarray[0], m.Iarray[2] = 10000, 1
     assert hip.hecmw_solve(None, m, ctx=ctx) == 0
     assert np.abs(m.X - g["sol_m1_p1_t4_X"]).max() < 1e-8 * np.abs(g["sol_m1_p1_t4_X"]).max()
+    ctx.close()
+
+
+@pytest.mark.parametrize("nd", [1, 4, 6])
+@pytest.mark.parametrize("meth,pc", [(3, 3), (3, 1), (4, 1), (4, 3)])
+def test_gmres_gpbicg_generic_blocks(hip, oracle, nd, meth, pc):
+    """GMRES(m) / GPBiCG (the host-scalar solvers of the 3x3 path, shared through an operations policy) on generic blocks against
+    the oracle, which is bit-identical to the real reference for these methods (tests/test_oracle_nn.py)."""
+    from oracle.refrun import default_params
+    A = nn_system(nd)
+    I, R = default_params(method=meth, precond=pc)
+    if nd == 6 and pc == 1:
+        I[0] = 40          # the reference's SSOR_66 quirk: unsymmetric preconditioner, compare a fixed number of steps
+    o = oracle.solve_iterative(A, I, R, nthreads=4)
+    m = to_hip(hip, A)
+    m.Iarray[:] = I
+    m.Rarray[:] = R
+    ctx = hip.SolverContext()
+    code = hip.hecmw_solve(None, m, ctx=ctx)
+    assert code == o["code"]
+    assert abs(ctx.info.iterations - o["iter"]) <= max(1, int(0.1 * o["iter"])), (ctx.info.iterations, o["iter"])
+    if code == 0:
+        assert m.Iarray[80] == 1 and np.abs(m.X - o["X"]).max() <= 1e-7 * np.abs(o["X"]).max()
+    k = min(5, len(ctx.history), len(o["history"]))
+    assert np.all(np.abs(ctx.history[:k] - o["history"][:k]) <= 1e-7 * o["history"][0] + 1e-6 * o["history"][:k])
     ctx.close()
