@@ -490,7 +490,7 @@ static int nn_precond_setup(fx_context *c, int precond, double sigma, int ncolor
   }
   n->sigma = sigma;
   HIP_TRY(hipMemsetAsync(n->alu, 0, (size_t)n->ndof * n->ndof * std::max(n->NP, 1) * 8, c->stream));
-  NN_DISPATCH(n->ndof, hipLaunchKernelGGL((k_nn_lu<ND>), dim3((n->N + 127) / 128), dim3(128), 0, c->stream, n->N, n->D, sigma, n->alu))
+  if (n->N > 0) { NN_DISPATCH(n->ndof, hipLaunchKernelGGL((k_nn_lu<ND>), dim3((n->N + 127) / 128), dim3(128), 0, c->stream, n->N, n->D, sigma, n->alu)) }
   HIP_TRY(hipGetLastError());
   n->precond_valid = true;
   return 0;
@@ -511,7 +511,7 @@ static int nn_precond_apply(fx_context *c, int iterpremax, const double *r, doub
   HIP_TRY(hipMemsetAsync(z, 0, (size_t)nd * n->NP * 8, c->stream));
   for (int it = 1; it <= iterpremax; it++) {
     if (n->precond_kind == 3) {
-      NN_DISPATCH(nd, hipLaunchKernelGGL((k_nn_diag_apply<ND>), dim3((n->N + 127) / 128), dim3(128), 0, c->stream, n->N, n->alu, zp))
+      if (n->N > 0) { NN_DISPATCH(nd, hipLaunchKernelGGL((k_nn_diag_apply<ND>), dim3((n->N + 127) / 128), dim3(128), 0, c->stream, n->N, n->alu, zp)) }
     } else {
       for (int k = 0; k < n->ncolor; k++) {
         NN_DISPATCH(nd, nn_rows_launch<ND, 2>(c, n->L, n->color_slice[k], n->color_slice[k + 1], zp, nullptr, zp, n->alu))
@@ -664,7 +664,8 @@ static int nn_solve(fx_context *c, const fx_matrix_view *m, const fx_comm_view *
   {  // hecmw_solve_check_zerodiag (:212-240)
     int32_t *flag = (int32_t *)(n->scal + 4), hflag = 0;
     HIP_TRY(hipMemsetAsync(flag, 0, 4, c->stream));
-    hipLaunchKernelGGL(k_nn_check_zero_diag, dim3(((int64_t)n->N * nd + 255) / 256), dim3(256), 0, c->stream, n->N, nd, n->D, flag);
+    if (n->N > 0)
+      hipLaunchKernelGGL(k_nn_check_zero_diag, dim3(((int64_t)n->N * nd + 255) / 256), dim3(256), 0, c->stream, n->N, nd, n->D, flag);
     HIP_TRY(hipMemcpyAsync(&hflag, flag, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (multi_rank(c)) {
