@@ -38,6 +38,7 @@ struct NnDev {
   double *W[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   double *partials = nullptr, *scal = nullptr;
   double *extra = nullptr;  // GMRES basis / GPBiCG work vectors (count * NDOF * NP)
+  double *scale = nullptr;  // SCALING=YES: 1 / sqrt(|d_ii|), NDOF * NP
   int extra_n = 0, iterpremax = 1;
   // halo tables in the caller's numbering (0-based)
   int32_t n_neighbor = 0, n_export = 0, n_import = 0;
@@ -70,7 +71,7 @@ static void nn_free(fx_context *c) {
   nn_bell_free(n->M); nn_bell_free(n->L); nn_bell_free(n->U);
   dev_free(n->D); dev_free(n->alu); dev_free(n->B); dev_free(n->X);
   for (auto &w : n->W) dev_free(w);
-  dev_free(n->partials); dev_free(n->scal); dev_free(n->extra);
+  dev_free(n->partials); dev_free(n->scal); dev_free(n->extra); dev_free(n->scale);
   dev_free(n->export_item); dev_free(n->import_item); dev_free(n->sendbuf); dev_free(n->recvbuf);
   if (n->h_send) (void)hipHostFree(n->h_send);
   if (n->h_recv) (void)hipHostFree(n->h_recv);
@@ -235,6 +236,51 @@ __global__ void k_nn_check_zero_diag(int32_t N, int nd, const double *__restrict
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)N * nd) return;
   if (fabs(D[(size_t)nd * nd * (i / nd) + (size_t)(nd + 1) * (i % nd)]) == 0.0) *flag = 1;
+}
+
+// SCALING=YES (hecmw_solver_scaling_fw_nn / _bk_nn, las/hecmw_solver_scaling_nn.f90:20-100, :102-180): symmetric diagonal scaling
+__global__ void k_nn_scale_vec(int32_t N, int nd, const double *__restrict__ D, double *__restrict__ scale) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)N * nd) return;
+  scale[i] = 1.0 / sqrt(fabs(D[(size_t)nd * nd * (i / nd) + (size_t)(nd + 1) * (i % nd)]));
+}
+__global__ void k_nn_scale_diag(int32_t NP, int nd, double *__restrict__ D, const double *__restrict__ scale, int back) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)NP * nd * nd) return;
+  const int64_t i = t / (nd * nd);
+  const int r = (int)(t % (nd * nd)) / nd, q = (int)(t % nd);
+  const double si = scale[(size_t)nd * i + r], sj = scale[(size_t)nd * i + q];
+  D[t] = back ? D[t] / (si * sj) : (D[t] * si) * sj;   // evaluation order of the reference (:62-70, :157-165)
+}
+template <int ND>
+__global__ void k_nn_scale_bell(int32_t nslices, const int64_t *__restrict__ slice_ptr, const int32_t *__restrict__ slot_row,
+                                const int32_t *__restrict__ col, double *__restrict__ val, const double *__restrict__ scale,
+                                int back) {
+  const int lane = threadIdx.x & 63;
+  const int32_t s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= nslices) return;
+  const int32_t row = slot_row[(size_t)s * 64 + lane];
+  if (row < 0) return;
+  const int64_t base = slice_ptr[s];
+  const int w = (int)(slice_ptr[s + 1] - base);
+  for (int k = 0; k < w; k++) {
+    const int32_t cidx = col[(base + k) * 64 + lane];
+    double *v = val + (size_t)(base + k) * (ND * ND) * 64 + lane;
+#pragma unroll
+    for (int d = 0; d < ND; d++)
+#pragma unroll
+      for (int e = 0; e < ND; e++) {
+        const double si = scale[(size_t)ND * row + d], sj = scale[(size_t)ND * cidx + e];
+        double &x = v[(size_t)(d * ND + e) * 64];
+        x = back ? x / (si * sj) : (x * si) * sj;
+      }
+  }
+}
+__global__ void k_nn_scale_rhs(int64_t n, double *__restrict__ B, double *__restrict__ X, const double *__restrict__ scale, int back) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (back) { X[i] = X[i] * scale[i]; B[i] = B[i] / scale[i]; }
+    else B[i] = B[i] * scale[i];
+  }
 }
 
 #define NN_DISPATCH(nd, ...)                                                                                    \
@@ -613,6 +659,38 @@ static int nn_bicgstab(fx_context *c, int MAXIT, double TOL, int iterpremax, NnR
   return 0;
 }
 
+static int nn_scale_bell(fx_context *c, NnBell &b, int back) {
+  NnDev *n = nn_of(c);
+  if (b.nslices <= 0) return 0;
+  NN_DISPATCH(n->ndof, hipLaunchKernelGGL((k_nn_scale_bell<ND>), dim3((b.nslices + 3) / 4), dim3(256), 0, c->stream, b.nslices,
+                                          b.slice_ptr, b.slot_row, b.col, b.val, n->scale, back))
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+// forward: scale vector (+ its halo), matrix, right-hand side; back: x, right-hand side and matrix restored
+static int nn_scaling(fx_context *c, int back) {
+  NnDev *n = nn_of(c);
+  const int nd = n->ndof;
+  const size_t len = (size_t)nd * std::max(n->NP, 1);
+  if (!n->scale && dev_alloc(&n->scale, len)) return FX_ERROR_RUNTIME;
+  if (n->N <= 0) return 0;
+  if (!back) {
+    HIP_TRY(hipMemsetAsync(n->scale, 0, len * 8, c->stream));
+    hipLaunchKernelGGL(k_nn_scale_vec, dim3(((int64_t)n->N * nd + 255) / 256), dim3(256), 0, c->stream, n->N, nd, n->D, n->scale);
+    if (nn_halo(c, n->scale)) return FX_ERROR_RUNTIME;
+  } else {
+    hipLaunchKernelGGL(k_nn_scale_rhs, dim3(nn_vgrid((int64_t)nd * n->N)), dim3(256), 0, c->stream, (int64_t)nd * n->N, n->B, n->X,
+                       n->scale, 1);
+  }
+  hipLaunchKernelGGL(k_nn_scale_diag, dim3(((int64_t)n->NP * nd * nd + 255) / 256), dim3(256), 0, c->stream, n->NP, nd, n->D, n->scale, back);
+  if (nn_scale_bell(c, n->M, back)) return FX_ERROR_RUNTIME;
+  if (!back)
+    hipLaunchKernelGGL(k_nn_scale_rhs, dim3(nn_vgrid((int64_t)nd * n->N)), dim3(256), 0, c->stream, (int64_t)nd * n->N, n->B, n->X,
+                       n->scale, 0);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // GMRES(m) and GPBiCG of fx_krylov2_host.h on the generic-block system
 struct OpsNN {
   fx_context *c;
@@ -648,7 +726,7 @@ static int nn_solve(fx_context *c, const fx_matrix_view *m, const fx_comm_view *
   if (m->NDOF < 1 || m->NDOF > 6) { g_fx_error = "NDOF must be 1..6"; return FX_ERROR_UNSUPPORTED; }
   const int maxit = Iarray[0], precond = Iarray[2], method2 = Iarray[7], iterpremax = Iarray[4];
   int method = Iarray[1];
-  if (Iarray[6] != 0) { g_fx_error = "NDOF != 3: SCALING is not on the GPU path"; return FX_ERROR_UNSUPPORTED; }
+  const bool scaling = Iarray[6] != 0;  // SCALING=YES
   const double t0 = now_s();
   NnDev *n0 = nn_of(c);
   const bool values_changed = Iarray[97] >= 1 || Iarray[96] >= 1 || !n0->have_matrix ||
@@ -698,6 +776,13 @@ static int nn_solve(fx_context *c, const fx_matrix_view *m, const fx_comm_view *
     res = NnResult();
     int e;
     n->iterpremax = iterpremax;
+    if (scaling) {  // scale, then build the preconditioner of the scaled matrix (hecmw_solver_CG.f90:104-112)
+      if (nn_scaling(c, 0)) return FX_ERROR_RUNTIME;
+      if (iterpremax > 0) {
+        if (int pe = nn_precond_setup(c, precond, sigma, Iarray[33])) return pe;
+        if (n->precond_kind == 1 && (nn_scale_bell(c, n->L, 0) || nn_scale_bell(c, n->U, 0))) return FX_ERROR_RUNTIME;  // built from the caller's values
+      }
+    }
     if (method == 1) e = nn_cg(c, maxit, Rarray[0], iterpremax, &res);
     else if (method == 2) e = nn_bicgstab(c, maxit, Rarray[0], iterpremax, &res);
     else if (method == 3 || method == 4) {
@@ -706,6 +791,10 @@ static int nn_solve(fx_context *c, const fx_matrix_view *m, const fx_comm_view *
       res.iter = hk.iter; res.resid = hk.resid; res.error = hk.error; res.hist = hk.hist;
     } else { g_fx_error = "METHOD must be 1 (CG), 2 (BiCGSTAB), 3 (GMRES) or 4 (GPBiCG)"; return FX_ERROR_INCONS_PC; }
     if (e) return e;
+    if (scaling) {  // x and b back, matrix restored (hecmw_solver_CG.f90:277); the preconditioner belonged to the scaled matrix
+      if (nn_scaling(c, 1)) return FX_ERROR_RUNTIME;
+      n->precond_valid = false;
+    }
     if (res.error == FX_ERROR_DIVERGE_PC || res.error == FX_ERROR_DIVERGE_MAT) {  // Iterative.f90:145-156
       Iarray[81] = 1;
       if (method == 1 && method2 > 1) { method = method2; continue; }

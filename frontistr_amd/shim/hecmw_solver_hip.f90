@@ -92,9 +92,9 @@ contains
     on_gpu = hecMAT%Iarray(99) == 1 .and. hecMESH%mpc%n_mpc == 0 .and. hecMAT%cmat%n_val == 0
     if (hecMAT%NDOF == 3) then
       on_gpu = on_gpu .and. (precond == 1 .or. precond == 2 .or. precond == 3 .or. precond == 10)
-    else   ! generic block sizes: METHOD 1-4 with SSOR / DIAG, no SCALING (include/fistr_hip.h)
+    else   ! generic block sizes: METHOD 1-4 with SSOR / DIAG (include/fistr_hip.h)
       on_gpu = on_gpu .and. hecMAT%NDOF >= 1 .and. hecMAT%NDOF <= 6 .and. (precond >= 1 .and. precond <= 3) .and. &
-               (hecMAT%Iarray(2) >= 1 .and. hecMAT%Iarray(2) <= 4) .and. hecMAT%Iarray(7) == 0
+               (hecMAT%Iarray(2) >= 1 .and. hecMAT%Iarray(2) <= 4)
     endif
     if (.not. on_gpu) then
       call get_environment_variable('HECMW_GPU_UNSUPPORTED', envu, elen, estat)

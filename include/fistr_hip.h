@@ -96,7 +96,7 @@ int fx_device_synchronize(fx_context *ctx);
  * SCALING Iarray(7) /= 0: symmetric diagonal scaling around every attempt (las/hecmw_solver_scaling_33.f90);
  * SIGMA_DIAG Rarray(2) < 0: the reference's automatic retry for the ILU family; METHOD2 Iarray(8) take-over.
  * NDOF = 3 is the tuned path.  NDOF = 1, 2, 4, 5, 6 (hecmw_matvec_nn las_nn.f90:135, precond/nn + 11/22/44/66) take the
- * generic-block path: METHOD 1-4; PRECOND 1, 2, 3; no SCALING; anything else E-1001 / FX_ERROR_UNSUPPORTED. */
+ * generic-block path: METHOD 1-4; PRECOND 1, 2, 3; SCALING; anything else E-1001 / FX_ERROR_UNSUPPORTED. */
 int fx_solve(fx_context *ctx, const fx_matrix_view *mat, const fx_comm_view *comm, int32_t *Iarray,
              double *Rarray, fx_solve_info *info, double *hist, int32_t hist_len);
 

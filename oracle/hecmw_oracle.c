@@ -738,34 +738,34 @@ int orc_solve_bicgstab(const orc_matrix *A, const orc_comm *c, orc_precond *P, i
 /* hecmw_solver_scaling_fw_33 / _bk_33, las/hecmw_solver_scaling_33.f90:20-117, :119-208 (SCALING=YES, Iarray(7)):
  * symmetric diagonal scaling D^-1/2 A D^-1/2, b <- D^-1/2 b before the Krylov loop (and before the preconditioner
  * set-up), x <- D^-1/2 x, b and the matrix divided back afterwards. */
-static void scaling_33(int back, int32_t N, int32_t NP, const int32_t *indexL, const int32_t *itemL,
+/* nd = 3: hecmw_solver_scaling_33.f90; any other block size: las/hecmw_solver_scaling_nn.f90:20-100, :102-180 (the same loops) */
+static void scaling_33(int nd, int back, int32_t N, int32_t NP, const int32_t *indexL, const int32_t *itemL,
                        const int32_t *indexU, const int32_t *itemU, double *D, double *AL, double *AU, double *B,
                        double *X, double *scale, const orc_comm *c) {
+  const int nd2 = nd * nd;
   if (!back) {
     for (int32_t i = 0; i < N; i++)
-      for (int k = 0; k < 3; k++) scale[3 * i + k] = 1.0 / sqrt(fabs(D[9 * i + 4 * k]));
+      for (int k = 0; k < nd; k++) scale[nd * i + k] = 1.0 / sqrt(fabs(D[(size_t)nd2 * i + (nd + 1) * k]));
     if (c && c->halo) c->halo(scale, c->ctx);
   } else {
-    for (int32_t i = 0; i < 3 * N; i++) { X[i] = X[i] * scale[i]; B[i] = B[i] / scale[i]; }
+    for (int32_t i = 0; i < nd * N; i++) { X[i] = X[i] * scale[i]; B[i] = B[i] / scale[i]; }
   }
   /* forward: A(ij) * scale(i) * scale(j) evaluated left to right (:62-70); back: A(ij) / (scale(i)*scale(j)) (:157-165) */
 #define SCALE_BLOCK(blk, si, sj)                                                        \
-  for (int r = 0; r < 3; r++)                                                           \
-    for (int q = 0; q < 3; q++) {                                                       \
-      double *v = (blk) + 3 * r + q;                                                    \
+  for (int r = 0; r < nd; r++)                                                          \
+    for (int q = 0; q < nd; q++) {                                                      \
+      double *v = (blk) + nd * r + q;                                                   \
       *v = back ? *v / (scale[(si) + r] * scale[(sj) + q]) : *v * scale[(si) + r] * scale[(sj) + q]; \
     }
   for (int32_t i = 0; i < NP; i++) {
-    SCALE_BLOCK(D + 9 * i, 3 * i, 3 * i)
-    for (int32_t k = indexL[i]; k < indexL[i + 1]; k++) { const int32_t j = itemL[k] - 1; SCALE_BLOCK(AL + 9 * k, 3 * i, 3 * j) }
-    for (int32_t k = indexU[i]; k < indexU[i + 1]; k++) { const int32_t j = itemU[k] - 1; SCALE_BLOCK(AU + 9 * k, 3 * i, 3 * j) }
+    SCALE_BLOCK(D + (size_t)nd2 * i, nd * i, nd * i)
+    for (int32_t k = indexL[i]; k < indexL[i + 1]; k++) { const int32_t j = itemL[k] - 1; SCALE_BLOCK(AL + (size_t)nd2 * k, nd * i, nd * j) }
+    for (int32_t k = indexU[i]; k < indexU[i + 1]; k++) { const int32_t j = itemU[k] - 1; SCALE_BLOCK(AU + (size_t)nd2 * k, nd * i, nd * j) }
   }
 #undef SCALE_BLOCK
   if (!back)
-    for (int32_t i = 0; i < 3 * N; i++) B[i] = B[i] * scale[i];
+    for (int32_t i = 0; i < nd * N; i++) B[i] = B[i] * scale[i];
 }
-
-
 
 /* hecmw_solve_iterative, hecmw_solver_Iterative.f90:13-210 (serial + comm hooks).
  * Error codes: hecmw_solve_error.f90:9-15. */
@@ -818,24 +818,23 @@ int orc_solve_iterative(const orc_matrix *A, const orc_comm *c, const double *B,
   /* SCALING=YES (Iarray(7)): every method scales first thing and un-scales last thing (CG.f90:104/:277 and the same
    * lines of the other three); the caller's arrays are left alone here, the solve runs on scaled copies */
   const int scaling = F1(Iarray, 7) != 0;
-  if (scaling && nd != 3) return 1001; /* hecmw_solver_scaling_nn is not restated */
   orc_matrix As = *A;
   double *sD = NULL, *sAL = NULL, *sAU = NULL, *sB = NULL, *scale = NULL;
   const orc_matrix *Aorig = A;
   const double *Borig = B;
   if (scaling) {
-    const size_t nl = (size_t)9 * A->indexL[NP], nu = (size_t)9 * A->indexU[NP];
-    sD = (double *)malloc((size_t)9 * NP * sizeof(double)); memcpy(sD, A->D, (size_t)9 * NP * sizeof(double));
+    const size_t nl = (size_t)nd * nd * A->indexL[NP], nu = (size_t)nd * nd * A->indexU[NP];
+    sD = (double *)malloc((size_t)nd * nd * NP * sizeof(double)); memcpy(sD, A->D, (size_t)nd * nd * NP * sizeof(double));
     sAL = (double *)malloc((nl + 1) * sizeof(double)); memcpy(sAL, A->AL, nl * sizeof(double));
     sAU = (double *)malloc((nu + 1) * sizeof(double)); memcpy(sAU, A->AU, nu * sizeof(double));
-    sB = (double *)malloc((size_t)3 * NP * sizeof(double)); memcpy(sB, B, (size_t)3 * NP * sizeof(double));
-    scale = (double *)calloc((size_t)3 * NP, sizeof(double));
+    sB = (double *)malloc((size_t)nd * NP * sizeof(double)); memcpy(sB, B, (size_t)nd * NP * sizeof(double));
+    scale = (double *)calloc((size_t)nd * NP, sizeof(double));
     As.D = sD; As.AL = sAL; As.AU = sAU;
     A = &As; B = sB;
   }
   for (;;) {
     F1(Iarray, 81) = 0; F1(Iarray, 82) = 0;
-    if (scaling) scaling_33(0, N, NP, A->indexL, A->itemL, A->indexU, A->itemU, sD, sAL, sAU, sB, X, scale, c);
+    if (scaling) scaling_33(nd, 0, N, NP, A->indexL, A->itemL, A->indexU, A->itemU, sD, sAL, sAU, sB, X, scale, c);
     orc_precond *P = NULL;
     if (iterPREmax > 0) {
       if (g_persist) { /* the module-level `save` state of the reference's preconditioners: rebuilt only when the flags ask */
@@ -860,7 +859,7 @@ int orc_solve_iterative(const orc_matrix *A, const orc_comm *c, const double *B,
       error = orc_solve_gpbicg(A, c, P, iterPREmax, B, X, ITER, RESID, &iter_run, &resid_run, hist);
     else { if (!g_persist) orc_precond_free(P); return 1001; }
     if (!g_persist) orc_precond_free(P);
-    if (scaling) scaling_33(1, N, NP, A->indexL, A->itemL, A->indexU, A->itemU, sD, sAL, sAU, sB, X, scale, c);
+    if (scaling) scaling_33(nd, 1, N, NP, A->indexL, A->itemL, A->indexU, A->itemU, sD, sAL, sAU, sB, X, scale, c);
     if (error == ERR_DIVERGE_PC || error == ERR_DIVERGE_MAT) { /* :145-156 */
       F1(Iarray, 82) = 1;
       if ((PRECOND >= 10 && PRECOND < 20) && auto_sigma_diag == 1 && SIGMA_DIAG < 2.0) {

@@ -45,3 +45,18 @@ def test_matvec_nn_matches_dense(oracle):
         x = np.random.default_rng(nd).standard_normal(nd * A.NP)
         y = oracle.matvec(A, x)
         assert np.abs(y - dense(A) @ x).max() <= 1e-12 * np.abs(y).max()
+
+
+@pytest.mark.parametrize("nd", [1, 2, 4, 5, 6])
+def test_nn_scaling_oracle_vs_live_reference(oracle, nd):
+    """SCALING=YES (hecmw_solver_scaling_nn and its 44 / 66 copies) through the generic restatement: bit-identical to the reference."""
+    from oracle import refrun
+    if not refrun.have_ref("ref_solve"):
+        pytest.skip("oracle/_ref not built")
+    A = nn_system(nd)
+    for meth, pc, thr in ((1, 3, 1), (1, 1, 4), (2, 1, 4), (3, 3, 1)):
+        I, R = refrun.default_params(method=meth, precond=pc)
+        I[6] = 1
+        r = refrun.run_solve(A, I, R, threads=thr)
+        o = oracle.solve_iterative(A, I, R, nthreads=thr)
+        assert o["iter"] == r["iter"] and np.array_equal(o["X"], r["X"]), (meth, pc, thr)
