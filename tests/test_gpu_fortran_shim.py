@@ -94,3 +94,21 @@ def test_shim_recycle_policy_sequence():
     assert r["returncode"] == 0 and "reference CPU solver used" not in r["stdout"]
     assert np.array_equal(r["Iarray"][95:98], g[tag + "Iarray"][95:98])
     assert np.abs(r["X"] - g[tag + "X"]).max() <= 1e-7 * np.abs(g[tag + "X"]).max()
+
+
+@pytest.mark.parametrize("nd,meth,pc,scal", [(2, 3, 3, 0), (4, 4, 1, 0), (1, 1, 1, 1), (6, 2, 3, 1)])
+def test_shim_generic_blocks_other_methods_and_scaling(nd, meth, pc, scal):
+    """GMRES / GPBiCG and SCALING=YES for hecMAT%NDOF /= 3 through the Fortran call, against the CPU oracle (bit-identical to the
+    reference on these systems, tests/test_oracle_nn.py)."""
+    from nn_cases import nn_system
+    from oracle import pyoracle, refrun
+    if not refrun.have_ref("shim_solve"):
+        pytest.skip("oracle/_ref/shim_solve not built")
+    A = nn_system(nd)
+    I, R = refrun.default_params(method=meth, precond=pc)
+    I[6] = scal
+    o = pyoracle.solve_iterative(A, I, R, nthreads=4)
+    r = refrun.run_solve(A, I, R, exe_name="shim_solve")
+    assert r["returncode"] == 0 and "reference CPU solver used" not in r["stdout"] and "libfistr_hip-E" not in r["stdout"], r["stdout"][-1500:]
+    assert "%dx%d BLOCK (libfistr_hip) METHOD %d" % (nd, nd, meth) in r["stdout"]
+    assert r["Iarray"][80] == 1 and np.abs(r["X"] - o["X"]).max() <= 1e-7 * np.abs(o["X"]).max()
