@@ -298,29 +298,42 @@ __global__ void k_nn_scale_rhs(int64_t n, double *__restrict__ B, double *__rest
 // ---------------------------------------------------------------------------------------------------------------
 // rows[slot] = row id or -1; for each row a list of (column, pointer to its nd2 values).  Slices of 64 slots.
 struct NnRowEntry { int32_t col; const double *src; };
-static int nn_bell_build(fx_context *c, NnBell &b, int nd, const std::vector<int32_t> &rows,
-                         const std::vector<std::vector<NnRowEntry>> &entries /* per slot */) {
+// fill(slot, out): the (column, source block) list of that slot's row, in the order the kernel is to visit it.  Called
+// twice per slot (widths, then values) from the host threads with a per-call scratch vector -- no per-row allocation.
+template <class Fill>
+static int nn_bell_build(fx_context *c, NnBell &b, int nd, const std::vector<int32_t> &rows, Fill fill) {
   nn_bell_free(b);
   const int nd2 = nd * nd;
   b.nslots = (int32_t)rows.size();
   b.nslices = b.nslots / 64;
   std::vector<int64_t> sp((size_t)b.nslices + 1, 0);
-  for (int32_t s = 0; s < b.nslices; s++) {
-    size_t w = 0;
-    for (int l = 0; l < 64; l++) w = std::max(w, entries[(size_t)s * 64 + l].size());
-    sp[s + 1] = sp[s] + (int64_t)w;
-  }
+  parallel_for(b.nslices, [&](int64_t s0, int64_t s1) {
+    std::vector<NnRowEntry> tmp;
+    for (int64_t s = s0; s < s1; s++) {
+      size_t w = 0;
+      for (int l = 0; l < 64; l++) {
+        tmp.clear();
+        if (rows[(size_t)s * 64 + l] >= 0) fill((int64_t)s * 64 + l, tmp);
+        w = std::max(w, tmp.size());
+      }
+      sp[s + 1] = (int64_t)w;
+    }
+  });
+  for (int32_t s = 0; s < b.nslices; s++) sp[s + 1] += sp[s];
   b.nblocks_padded = sp[b.nslices];
   std::vector<int32_t> col((size_t)std::max<int64_t>(b.nblocks_padded, 1) * 64, 0);
   std::vector<double> val((size_t)std::max<int64_t>(b.nblocks_padded, 1) * nd2 * 64, 0.0);
-  nn_each(b.nslices, [&](int64_t s) {
-    for (int l = 0; l < 64; l++) {
-      const auto &e = entries[(size_t)s * 64 + l];
-      for (size_t k = 0; k < e.size(); k++) {
-        col[(size_t)(sp[s] + k) * 64 + l] = e[k].col;
-        for (int q = 0; q < nd2; q++) val[((size_t)(sp[s] + k) * nd2 + q) * 64 + l] = e[k].src[q];
+  parallel_for(b.nslices, [&](int64_t s0, int64_t s1) {
+    std::vector<NnRowEntry> tmp;
+    for (int64_t s = s0; s < s1; s++)
+      for (int l = 0; l < 64; l++) {
+        tmp.clear();
+        if (rows[(size_t)s * 64 + l] >= 0) fill((int64_t)s * 64 + l, tmp);
+        for (size_t k = 0; k < tmp.size(); k++) {
+          col[(size_t)(sp[s] + k) * 64 + l] = tmp[k].col;
+          for (int q = 0; q < nd2; q++) val[((size_t)(sp[s] + k) * nd2 + q) * 64 + l] = tmp[k].src[q];
+        }
       }
-    }
   });
   if (dev_alloc(&b.slice_ptr, sp.size()) || dev_alloc(&b.slot_row, std::max<size_t>(rows.size(), 1)) ||
       dev_alloc(&b.col, col.size()) || dev_alloc(&b.val, val.size()))
@@ -382,16 +395,13 @@ static int nn_upload(fx_context *c, const fx_matrix_view *m, const fx_comm_view 
     // SpMV rows 1..N in the caller's order: D, then the lower blocks, then the upper blocks (las_nn.f90:274-307)
     const int32_t nslots = (m->N + 63) / 64 * 64;
     std::vector<int32_t> rows((size_t)nslots, -1);
-    std::vector<std::vector<NnRowEntry>> ent((size_t)nslots);
-    nn_each(m->N, [&](int64_t i) {
-      rows[i] = (int32_t)i;
-      auto &e = ent[i];
-      e.reserve(1 + (m->indexL[i + 1] - m->indexL[i]) + (m->indexU[i + 1] - m->indexU[i]));
+    for (int32_t i = 0; i < m->N; i++) rows[i] = i;
+    auto fillM = [&](int64_t i, std::vector<NnRowEntry> &e) {
       e.push_back({(int32_t)i, m->D + (size_t)nd2 * i});
       for (int32_t j = m->indexL[i]; j < m->indexL[i + 1]; j++) e.push_back({m->itemL[j] - 1, m->AL + (size_t)nd2 * j});
       for (int32_t j = m->indexU[i]; j < m->indexU[i + 1]; j++) e.push_back({m->itemU[j] - 1, m->AU + (size_t)nd2 * j});
-    });
-    if (nn_bell_build(c, n->M, nd, rows, ent)) return FX_ERROR_RUNTIME;
+    };
+    if (nn_bell_build(c, n->M, nd, rows, fillM)) return FX_ERROR_RUNTIME;
     n->have_matrix = true;
     if (shape) n->precond_valid = false;  // new values alone: the flags / recycle policy of the solve decide (as the 3x3 path)
   }
@@ -502,24 +512,28 @@ static int nn_ssor_setup(fx_context *c, int ncolor_in) {
     while (rows.size() % 64) { rows.push_back(-1); slot_new.push_back(-1); }
     n->color_slice.push_back((int32_t)(rows.size() / 64));
   }
-  std::vector<std::vector<NnRowEntry>> entL(rows.size()), entU(rows.size());
-  nn_each((int64_t)rows.size(), [&](int64_t s) {
+  auto fillLU = [&](int64_t s, std::vector<NnRowEntry> &out, bool lower) {
     const int32_t iold = rows[s], inew = slot_new[s];
-    if (iold < 0) return;
-    std::vector<std::pair<int32_t, NnRowEntry>> lo, up;  // keyed by the NEW index of the column
+    std::pair<int32_t, NnRowEntry> buf[128];  // keyed by the NEW index of the column
+    std::vector<std::pair<int32_t, NnRowEntry>> big;
+    size_t cnt = 0;
     auto add = [&](int32_t kold, const double *src) {
       if (kold >= N) return;  // halo column: localized preconditioner
       const int32_t knew = iperm[kold];
-      (knew < inew ? lo : up).push_back({knew, {kold, src}});
+      if ((knew < inew) != lower) return;
+      if (cnt < 128) buf[cnt++] = {knew, {kold, src}};
+      else { if (big.empty()) big.assign(buf, buf + cnt); big.push_back({knew, {kold, src}}); cnt++; }
     };
     for (int32_t j = n->h_indexL[iold]; j < n->h_indexL[iold + 1]; j++) add(n->h_itemL[j] - 1, n->h_AL.data() + (size_t)nd2 * j);
     for (int32_t j = n->h_indexU[iold]; j < n->h_indexU[iold + 1]; j++) add(n->h_itemU[j] - 1, n->h_AU.data() + (size_t)nd2 * j);
-    std::sort(lo.begin(), lo.end(), [](const auto &a, const auto &b) { return a.first < b.first; });  // forward: ascending (:300)
-    std::sort(up.begin(), up.end(), [](const auto &a, const auto &b) { return a.first > b.first; });  // backward: descending (:352)
-    for (auto &p : lo) entL[s].push_back(p.second);
-    for (auto &p : up) entU[s].push_back(p.second);
-  });
-  if (nn_bell_build(c, n->L, nd, rows, entL) || nn_bell_build(c, n->U, nd, rows, entU)) return FX_ERROR_RUNTIME;
+    std::pair<int32_t, NnRowEntry> *p = big.empty() ? buf : big.data();
+    if (lower) std::sort(p, p + cnt, [](const auto &a, const auto &b) { return a.first < b.first; });  // forward: ascending (:300)
+    else std::sort(p, p + cnt, [](const auto &a, const auto &b) { return a.first > b.first; });       // backward: descending (:352)
+    for (size_t k = 0; k < cnt; k++) out.push_back(p[k].second);
+  };
+  if (nn_bell_build(c, n->L, nd, rows, [&](int64_t s, std::vector<NnRowEntry> &o) { fillLU(s, o, true); }) ||
+      nn_bell_build(c, n->U, nd, rows, [&](int64_t s, std::vector<NnRowEntry> &o) { fillLU(s, o, false); }))
+    return FX_ERROR_RUNTIME;
   return 0;
 }
 
