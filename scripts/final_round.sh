@@ -12,6 +12,8 @@ timeout -k 10 300 python bench.py --elems 69 --precond 3 > $OUT/bench_1m_cg_diag
 timeout -k 10 300 python bench.py --method 2 --precond 10 --steps 40 --warmup 5 --no-cpu-baseline > $OUT/bench_10m_bicgstab_ilu0.json 2> $OUT/bench_ilu.err; echo "benchilu rc=$?" | tee -a $OUT/summary.txt
 timeout -k 10 300 python scripts/bench_nonlinear.py 149 1 1 3 2>/dev/null | tail -1 > $OUT/nonlinear_newton_10m.json; echo "nl rc=$?" | tee -a $OUT/summary.txt
 timeout -k 10 200 python scripts/bench_assembly.py 149 > $OUT/assembly.json 2>/dev/null
+timeout -k 10 300 python scripts/bench_nn.py 1 150 > $OUT/nn_ndof1.json 2>/dev/null
+timeout -k 10 300 python scripts/bench_nn.py 6 70 > $OUT/nn_ndof6.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline > $OUT/prof_run.json 2> $OUT/prof.err
 f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/kernel_stats_cg_ssor_10m.csv
