@@ -45,9 +45,9 @@ struct NnDev {
   std::vector<int32_t> neighbor, export_index, import_index;
   int32_t *export_item = nullptr, *import_item = nullptr;
   double *sendbuf = nullptr, *recvbuf = nullptr, *h_send = nullptr, *h_recv = nullptr;
-  // host copies for the SSOR set-up
+  // host copies of the profile for the SSOR set-up
   std::vector<int32_t> h_indexL, h_itemL, h_indexU, h_itemU;
-  std::vector<double> h_AL, h_AU;
+  const double *cur_AL = nullptr, *cur_AU = nullptr;  // the caller's off-diagonal blocks, valid during the current fx_solve only
 };
 
 template <typename F>
@@ -389,8 +389,6 @@ static int nn_upload(fx_context *c, const fx_matrix_view *m, const fx_comm_view 
     n->h_indexU.assign(m->indexU, m->indexU + m->NP + 1);
     n->h_itemL.assign(m->itemL, m->itemL + m->NPL);
     n->h_itemU.assign(m->itemU, m->itemU + m->NPU);
-    n->h_AL.assign(m->AL, m->AL + (size_t)nd2 * m->NPL);
-    n->h_AU.assign(m->AU, m->AU + (size_t)nd2 * m->NPU);
     HIP_TRY(hipMemcpy(n->D, m->D, (size_t)nd2 * m->NP * 8, hipMemcpyHostToDevice));
     // SpMV rows 1..N in the caller's order: D, then the lower blocks, then the upper blocks (las_nn.f90:274-307)
     const int32_t nslots = (m->N + 63) / 64 * 64;
@@ -524,8 +522,8 @@ static int nn_ssor_setup(fx_context *c, int ncolor_in) {
       if (cnt < 128) buf[cnt++] = {knew, {kold, src}};
       else { if (big.empty()) big.assign(buf, buf + cnt); big.push_back({knew, {kold, src}}); cnt++; }
     };
-    for (int32_t j = n->h_indexL[iold]; j < n->h_indexL[iold + 1]; j++) add(n->h_itemL[j] - 1, n->h_AL.data() + (size_t)nd2 * j);
-    for (int32_t j = n->h_indexU[iold]; j < n->h_indexU[iold + 1]; j++) add(n->h_itemU[j] - 1, n->h_AU.data() + (size_t)nd2 * j);
+    for (int32_t j = n->h_indexL[iold]; j < n->h_indexL[iold + 1]; j++) add(n->h_itemL[j] - 1, n->cur_AL + (size_t)nd2 * j);
+    for (int32_t j = n->h_indexU[iold]; j < n->h_indexU[iold + 1]; j++) add(n->h_itemU[j] - 1, n->cur_AU + (size_t)nd2 * j);
     std::pair<int32_t, NnRowEntry> *p = big.empty() ? buf : big.data();
     if (lower) std::sort(p, p + cnt, [](const auto &a, const auto &b) { return a.first < b.first; });  // forward: ascending (:300)
     else std::sort(p, p + cnt, [](const auto &a, const auto &b) { return a.first > b.first; });       // backward: descending (:352)
@@ -748,6 +746,7 @@ static int nn_solve(fx_context *c, const fx_matrix_view *m, const fx_comm_view *
   if (nn_upload(c, m, cm, values_changed)) return FX_ERROR_RUNTIME;
   if (values_changed) { c->host_D = m->D; c->host_AL = m->AL; c->host_AU = m->AU; }
   NnDev *n = nn_of(c);
+  n->cur_AL = m->AL; n->cur_AU = m->AU;  // the sweep layouts of a preconditioner (re)built in this call are gathered from these
   const int nd = n->ndof;
   int ret = 0;
   double rhs2 = 0.0;
