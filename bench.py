@@ -8,26 +8,34 @@ timed region: the matrix is assembled ON the device (fx_assemble_c3d8) from the 
 mesh, the multicolour SSOR is set up, r0/||b|| are computed; then W untimed + exactly K timed
 iterations run between barrier + synchronize pairs.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the global cube is split into
-px*py*pz node-based overlapping subdomains of 150^3 internal nodes each (weak scaling, the
-reference's own decomposition model); SpMV halo exchange and the dot-product all-reduces go
-through RCCL inside the library.
+N > 1: one process per GPU.  Either the driver starts the ranks (torch.distributed.run: RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) or `python bench.py --gpus N` starts them
+itself: the parent -- which never imports torch and never touches a GPU -- spawns N rank
+processes with that environment, relays rank 0's JSON line and fails if any rank fails.
+The global cube is split into px*py*pz node-based overlapping subdomains of 150^3 internal nodes
+each (weak scaling, the reference's own decomposition model); the SpMV halo exchange and the
+dot-product all-reduces go through RCCL inside the library (fx_comm_init); torch.distributed
+(gloo) is only the control plane: rendezvous, the ncclUniqueId broadcast, barriers, the max over
+ranks of the timed region.  `n_gpus` is what the RCCL communicator reports (ncclCommCount).
 
 The JSON line also carries
-  roofline     : the dominant kernel (BELL-64 SpMV) timed live with HIP events on the solver
-                 stream; achieved = algorithmic bytes (72*nb + 4*(nb-N) + 8*(N+1) +
-                 48*N) / time, peak 8 TB/s (MI355X_MICROARCH.md)
-  cpu_baseline : the REAL reference (oracle/_ref/ref_solve_omp, HEC-MW compiled from
-                 /root/reference with flang -fopenmp) timed on this box's host cores on a
-                 bounded sample of the same workload (rank 0, N=1 only).
+  roofline     : the dominant kernel (BELL-64 SpMV, in the variant the timed loop launches: with
+                 the fused p.q partial for CG) timed live with HIP events on the solver stream;
+                 achieved = algorithmic bytes (72*nb + 4*(nb-N) + 8*(N+1) + 48*N) /
+                 time, peak 8 TB/s (MI355X_MICROARCH.md)
+  cpu_baseline : the REAL reference (oracle/_ref/ref_solve_omp_o3, HEC-MW compiled from
+                 /root/reference with flang -O3 -fopenmp) timed on this box's host cores (all
+                 cores of the affinity mask) on a bounded sample of the same workload (rank 0,
+                 N=1 only); --cpu-full times it on the full workload instead (minutes).
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -44,11 +52,82 @@ def spmv_algorithmic_bytes(N, nb):
     return 72 * nb + 4 * (nb - N) + 2 * 4 * (N + 1) + 24 * N + 24 * N
 
 
-def cpu_baseline(hip, n_sample, iters, cores, method=1, precond=1):
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--elems", dest="n", type=int, default=149, help="elements per edge per GPU (149 -> 150^3 nodes = 10.125M DOF)")
+    ap.add_argument("--precond", type=int, default=1, help="1 SSOR (config 3), 3 block-Jacobi (config 2), 10 ILU(0)")
+    ap.add_argument("--method", type=int, default=1, help="1 CG, 2 BiCGSTAB")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-n", type=int, default=69)
+    ap.add_argument("--cpu-sample-iters", type=int, default=40)
+    ap.add_argument("--cpu-full", action="store_true",
+                    help="time the reference on the FULL workload (same deck, --cpu-sample-iters iterations) instead of the sample")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` without a launcher.  The parent stays free of torch /
+# HIP; the children are fresh processes (no exec of a process that has touched the GPU).
+# ---------------------------------------------------------------------------------------------
+def launch_ranks(a):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this pool
+        env.setdefault("OMP_NUM_THREADS", "4")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    failed = None
+    out0 = b""
+    deadline = time.time() + float(os.environ.get("FX_BENCH_LAUNCH_TIMEOUT", "3000"))
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [i for i, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = (bad[0], codes[bad[0]])
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() > deadline:
+            failed = (-1, "timeout")
+            break
+        time.sleep(0.2)
+    if failed is not None:
+        for p in procs:           # the exact processes started above, nothing else
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    out0 = procs[0].stdout.read() if procs[0].stdout else b""
+    lines = [ln for ln in out0.decode(errors="replace").splitlines() if ln.strip().startswith("{")]
+    if failed is not None:
+        sys.stderr.write("bench.py: rank %s failed (%s); no result\n" % failed)
+        return 1
+    if not lines:
+        sys.stderr.write("bench.py: rank 0 printed no JSON line\n")
+        return 1
+    print(lines[-1], flush=True)
+    return 0
+
+
+def cpu_baseline(hip, np, n_sample, iters, cores, method=1, precond=1):
     """Reference CG + multicolour SSOR on a (n_sample+1)^3-node cube, `iters` iterations."""
     from frontistr_amd.mesh import CubeMesh
     from oracle import refrun
-    if not refrun.have_ref("ref_solve_omp"):
+    exe = "ref_solve_omp_o3" if refrun.have_ref("ref_solve_omp_o3") else "ref_solve_omp"
+    if not refrun.have_ref(exe):
         return None
     mesh = CubeMesh(n_sample)
     hm = hip.hecmwST_local_mesh(n_node=mesh.n_node)
@@ -62,25 +141,23 @@ def cpu_baseline(hip, n_sample, iters, cores, method=1, precond=1):
     A = refrun.BSR(m.N, m.NP, m.indexL, m.itemL, m.indexU, m.itemU, m.D, m.AL, m.AU, m.B)
     I, R = refrun.default_params(method=method, precond=precond, maxit=iters, tol=1e-30, iterlog=0, timelog=1)
     wd = "/dev/shm" if os.path.isdir("/dev/shm") else None
-    r = refrun.run_solve(A, I, R, threads=cores, workdir=wd, timeout=900)
+    r = refrun.run_solve(A, I, R, threads=cores, workdir=wd, timeout=2400, exe_name=exe)
     if "t_per_iter" not in r or r["t_per_iter"] <= 0:
         return None
     return dict(per_iter=r["t_per_iter"], solver=r.get("t_solver"), setup=r.get("t_setup"),
-                matvec=r.get("t_matvec"), precond=r.get("t_precond"), ndof=3 * mesh.n_node)
+                matvec=r.get("t_matvec"), precond=r.get("t_precond"), ndof=3 * mesh.n_node, exe=exe)
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--elems", dest="n", type=int, default=149, help="elements per edge per GPU (149 -> 150^3 nodes = 10.125M DOF)")
-    ap.add_argument("--precond", type=int, default=1, help="1 SSOR (config 3), 3 block-Jacobi (config 2), 10 ILU(0)")
-    ap.add_argument("--method", type=int, default=1, help="1 CG, 2 BiCGSTAB")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-n", type=int, default=69)
-    ap.add_argument("--cpu-sample-iters", type=int, default=40)
-    a = ap.parse_args()
+    a = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and a.gpus > 1:
+        sys.exit(launch_ranks(a))
+    world = int(env_world or "1")
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; they must agree" % (a.gpus, world))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
     # Native libraries write to the process' stdout (RCCL prints a version banner when a communicator is created, the
     # reference binaries of the cpu_baseline leg log their solver summary): keep fd 1 for the ONE JSON line only.
@@ -88,31 +165,30 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    import numpy as np
     import torch
     import torch.distributed as dist
     from frontistr_amd import hecmw as hip
     from frontistr_amd.mesh import CubeMesh
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libfistr_hip has no CPU path")
     # FX_BENCH_TRANSPORT=gloo: rehearsal mode for boxes with fewer GPUs than ranks (ranks share devices,
     # halos / reductions go through the library's host-callback transport).  Default: RCCL over xGMI.
     transport = os.environ.get("FX_BENCH_TRANSPORT", "rccl")
-    dev = local_rank % torch.cuda.device_count()
+    ndev = torch.cuda.device_count()
+    if world > 1 and transport != "gloo" and ndev < world:
+        raise SystemExit("bench.py: %d ranks over RCCL need %d GPUs, this box has %d "
+                         "(FX_BENCH_TRANSPORT=gloo rehearses the decomposition with ranks sharing devices)" % (world, world, ndev))
+    dev = local_rank % ndev
     torch.cuda.set_device(dev)
     if world > 1:
-        if transport == "gloo":
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        dist.init_process_group("gloo")     # control plane only; the data path is RCCL inside libfistr_hip
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
 
     t_setup0 = time.time()
     ctx = hip.SolverContext(device=dev)
@@ -133,10 +209,13 @@ def main():
             from frontistr_amd.comm import attach_host_callbacks
             attach_host_callbacks(ctx, hm, hip.lib())
         else:
-            uid = torch.tensor(list(hip.comm_unique_id()) if rank == 0 else [0] * 128, dtype=torch.uint8, device="cuda")
+            uid = torch.tensor(list(hip.comm_unique_id()) if rank == 0 else [0] * 128, dtype=torch.uint8)
             dist.broadcast(uid, 0)
-            ctx.comm_init(bytes(uid.cpu().tolist()), rank, world)
+            ctx.comm_init(bytes(uid.tolist()), rank, world)
         coord, conn, load, bc = sub.coord, sub.conn, sub.load(), sub.dirichlet()
+    comm_ranks, comm_dev = ctx.comm_size()
+    if comm_ranks != world:
+        raise SystemExit("bench.py: the transport reports %d ranks, the launcher started %d" % (comm_ranks, world))
     hm.elem_node_item = conn.ravel()
     m = hip.hecmw_mat_con(hm, hip.hecmwST_matrix())
     t_con = time.time() - t_setup0
@@ -161,13 +240,18 @@ def main():
     dt = time.perf_counter() - t0
     assert status == 0 and it == a.warmup + a.steps + 1, (status, it)
     assert np.isfinite(resid)
+    devices_used = 1
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if transport == "gloo" else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        t = torch.tensor([dt, float(dev)], dtype=torch.float64)
+        g = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(g, t)
+        dt = max(float(x[0]) for x in g)
+        devices_used = len(set(int(x[1]) for x in g))
 
-    # roofline of the dominant kernel, timed live with HIP events on the solver stream
-    ms_spmv = ctx.matvec_resident_ms(20)
+    # roofline of the dominant kernel, timed live with HIP events on the solver stream: the variant the timed loop
+    # launches (CG: SpMV with the fused p.q partial; BiCGSTAB: the plain product)
+    spmv_variant = 1 if a.method == 1 else 0
+    ms_spmv = ctx.spmv_resident_ms(spmv_variant, 20)
     ms_prec = ctx.precond_apply_ms(10)
     stream_gbs = ctx.stream_ceiling_gbs(5)       # on-box read-streaming ceiling
     alg = spmv_algorithmic_bytes(N, nb)
@@ -180,9 +264,11 @@ def main():
     bell_pad = st["M_pairs"] * 64.0 / max(nb, 1) - 1.0   # M_pairs counts block positions
     traffic, traffic_src = None, None
     try:  # PMC-measured HBM bytes per launch exist only for profiled workloads (committed under profiles/)
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["k_spmv"].get(str(N))
-        if tj and world == 1:
-            traffic, traffic_src = tj["traffic_bytes"], tj["source"]
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+            tj = json.load(open(path))["k_spmv"].get(str(N))
+            if tj and world == 1:
+                traffic, traffic_src = tj["traffic_bytes"], tj["source"]
+                break
     except Exception:
         pass
 
@@ -193,7 +279,7 @@ def main():
         "value": world * a.steps / dt,
         "unit": "CG iterations/s" if world == 1 else "CG iterations/s x subdomains (%.3fM-DOF subdomain-iterations/s, summed over GPUs)" % (3 * N / 1e6),
         "global_iterations_per_s": a.steps / dt,
-        "n_gpus": world,
+        "n_gpus": comm_ranks,
         "steps": a.steps,
         "warmup": a.warmup,
         "ms_per_step": 1e3 * dt / a.steps,
@@ -207,43 +293,50 @@ def main():
                         % (a.n + 1, 3 * N / 1e6, 3 * N * world / 1e6, {1: "CG", 2: "BiCGSTAB"}[a.method],
                            {1: "SSOR(1) multicolour", 3: "block-Jacobi", 10: "ILU(0) level-scheduled"}[a.precond]),
             "decomposition": "x".join(str(d) for d in decomposition(world)),
-            "transport": "none" if world == 1 else transport,
+            "transport": "none" if world == 1 else ("rccl (ncclCommCount=%d)" % comm_ranks if transport != "gloo" else "gloo host callbacks (rehearsal)"),
+            "devices_used": devices_used,
             "ncolor": st["ncolor"],
             "block_rows": N, "blocks": nb,
         },
         "roofline": {
-            "bound": "hbm", "kernel": "k_spmv (BELL-64 3x3-block SpMV)",
+            "bound": "hbm",
+            "kernel": "k_spmv<0,%d> (BELL-64 3x3-block SpMV%s)" % (spmv_variant, ", fused p.q partial: the launch of the timed CG loop" if spmv_variant else ""),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "measured_stream_ceiling": stream_gbs, "frac_of_measured_ceiling": achieved / stream_gbs,
             "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes": alg, "ms_per_launch": ms_spmv,
             "bell_padding_frac": bell_pad,
             "precond_apply": {"ms": ms_prec, "algorithmic_bytes": prec_bytes,
-                              "achieved_GBs": prec_bytes / (ms_prec * 1e-3) / 1e9},
+                              "achieved_GBs": prec_bytes / (ms_prec * 1e-3) / 1e9,
+                              "frac": prec_bytes / (ms_prec * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "iteration_GBs": (alg + prec_bytes + 480 * N) / (dt / a.steps) / 1e9,
         },
         "setup_s": {"mat_con": t_con, "assemble_ms": ms_asm, "precond_setup": t_pre},
         "resid_after_steps": resid,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cores = max(1, min(len(os.sched_getaffinity(0)), 16))
+        cores = max(1, len(os.sched_getaffinity(0)))     # every core this process may run on
+        n_cpu = a.n if a.cpu_full else a.cpu_sample_n
         try:
-            cb = cpu_baseline(hip, a.cpu_sample_n, a.cpu_sample_iters, cores, a.method, a.precond)
+            cb = cpu_baseline(hip, np, n_cpu, a.cpu_sample_iters, cores, a.method, a.precond)
         except Exception as e:  # the baseline is reporting only; never fail the bench on it
             cb = None
             out["cpu_baseline_error"] = repr(e)
         if cb:
             scale = cb["ndof"] / (3.0 * N)      # memory-bound sweeps: time per iteration ~ DOF
+            extrap = abs(scale - 1.0) > 1e-12
             out["cpu_baseline"] = {
                 "value": (1.0 / cb["per_iter"]) * scale, "unit": "CG iterations/s", "cores": cores,
-                "kind": "reference",
-                "sample": "HEC-MW reference (flang -fopenmp, OMP_NUM_THREADS=%d), same METHOD/PRECOND as the GPU run, on a %d^3-node cube "
-                          "(%.2fM DOF), %d iterations: %.4f s/iter measured = %.2f it/s; value = that rate scaled by DOF "
-                          "ratio %.4f to the %.2fM-DOF workload"
-                          % (cores, a.cpu_sample_n + 1, cb["ndof"] / 1e6, a.cpu_sample_iters, cb["per_iter"],
-                             1.0 / cb["per_iter"], scale, 3 * N / 1e6),
+                "kind": "reference", "extrapolated": extrap,
+                "sample": "HEC-MW reference (%s: flang %s -fopenmp, OMP_NUM_THREADS=%d = all cores of the affinity mask), same METHOD/PRECOND "
+                          "as the GPU run, on a %d^3-node cube (%.2fM DOF), %d iterations: %.4f s/iter measured = %.2f it/s%s"
+                          % (cb["exe"], "-O3" if cb["exe"].endswith("_o3") else "-O2", cores, n_cpu + 1, cb["ndof"] / 1e6,
+                             a.cpu_sample_iters, cb["per_iter"], 1.0 / cb["per_iter"],
+                             "; value = that rate scaled by DOF ratio %.4f to the %.2fM-DOF workload" % (scale, 3 * N / 1e6)
+                             if extrap else " (the full workload: measured, not extrapolated)"),
                 "measured_it_per_s_at_sample": 1.0 / cb["per_iter"],
                 "sample_matvec_s": cb.get("matvec"), "sample_precond_s": cb.get("precond"),
+                "sample_setup_s": cb.get("setup"),
             }
     if rank == 0:
         sys.stdout.flush()
@@ -252,6 +345,7 @@ def main():
         os.dup2(2, 1)                      # whatever teardown prints goes to stderr again
     ctx.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

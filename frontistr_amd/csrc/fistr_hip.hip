@@ -54,6 +54,8 @@ struct RcclApi {
   ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*CommCuDevice)(const ncclComm_t, int *) = nullptr;
 };
 static RcclApi g_rccl;
 
@@ -77,6 +79,8 @@ static int rccl_load() {
   RCCL_SYM(Recv, "ncclRecv")
   RCCL_SYM(AllReduce, "ncclAllReduce")
   RCCL_SYM(GetErrorString, "ncclGetErrorString")
+  RCCL_SYM(CommCount, "ncclCommCount")
+  RCCL_SYM(CommCuDevice, "ncclCommCuDevice")
 #undef RCCL_SYM
   return 0;
 }
@@ -499,6 +503,9 @@ static int ensure_work(fx_context *c) {
 static int setup_halo(fx_context *c, const fx_comm_view *cm) {
   HaloDev &h = c->halo;
   dev_free(h.export_item); dev_free(h.import_item); dev_free(h.sendbuf); dev_free(h.recvbuf);
+  // the pinned staging pair of the host-callback transport is sized by n_export / n_import: it goes with the tables
+  if (c->h_send) { (void)hipHostFree(c->h_send); c->h_send = nullptr; }
+  if (c->h_recv) { (void)hipHostFree(c->h_recv); c->h_recv = nullptr; }
   h = HaloDev();
   c->nn_internal = c->A.N;
   if (!cm) return 0;
@@ -614,6 +621,19 @@ extern "C" int fx_comm_set_host_callbacks(fx_context *c, int rank, int nranks, f
                                           void *user) {
   c->cb_halo = halo; c->cb_allreduce = allreduce; c->cb_user = user;
   c->rank = rank; c->nranks = nranks;
+  return 0;
+}
+
+// What the transport itself reports: ranks in the RCCL communicator (ncclCommCount) and the device it is bound to; with
+// the host-callback transport the rank count given to fx_comm_set_host_callbacks; 1 / the context's device otherwise.
+extern "C" int fx_comm_size(fx_context *c, int32_t *nranks, int32_t *device) {
+  int n = c->nranks, d = c->device;
+  if (c->nccl) {
+    NCCL_TRY(g_rccl.CommCount((ncclComm_t)c->nccl, &n));
+    NCCL_TRY(g_rccl.CommCuDevice((ncclComm_t)c->nccl, &d));
+  }
+  if (nranks) *nranks = n;
+  if (device) *device = d;
   return 0;
 }
 
@@ -1581,6 +1601,9 @@ extern "C" int fx_matvec(fx_context *c, const fx_matrix_view *m, const fx_comm_v
     mv.B = nullptr; mv.X = nullptr;
     int e = fx_upload(c, &mv, cm, what);
     if (e) return e;
+    // the resident values are now this caller's: a later fx_solve of another hecMAT of the same shape (flags 0) must
+    // see that the identity of the arrays changed and upload its own
+    if (what & FX_UP_VALUES) { c->host_D = m->D; c->host_AL = m->AL; c->host_AU = m->AU; }
   }
   HIP_TRY(hipSetDevice(c->device));
   if (ensure_solver(c)) return FX_ERROR_RUNTIME;
@@ -1609,7 +1632,29 @@ extern "C" int fx_nn_matvec_resident(fx_context *c, int nrepeat, float *ms_per_c
   return 0;
 }
 
-// y = A x on resident work vectors, timed with HIP events on the solver stream.
+// y = A x on resident work vectors, timed with HIP events on the solver stream.  variant: 0 plain (BiCGSTAB's products),
+// 1 with the fused partial of x.y (the launch of every CG iteration, hecmw_solver_CG.f90:204-211), 2 r = b - A x with the
+// partial of r.r (the residual recomputation).  The halo exchange of a multi-rank system is part of every call.
+extern "C" int fx_spmv_resident(fx_context *c, int variant, int nrepeat, float *ms_per_call) {
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->have_values) { g_fx_error = "fx_spmv_resident: no matrix resident"; return FX_ERROR_RUNTIME; }
+  if (variant < 0 || variant > 2) { g_fx_error = "fx_spmv_resident: variant must be 0, 1 or 2"; return FX_ERROR_RUNTIME; }
+  if (ensure_solver(c)) return FX_ERROR_RUNTIME;
+  if (to_slots(c, c->A.B, c->Bs)) return FX_ERROR_RUNTIME;
+  const int mode = variant == 2 ? 1 : 0, dot = variant;
+  if (spmv(c, mode, dot, c->Bs, c->Bs, c->W[7], nullptr, 0)) return FX_ERROR_RUNTIME;  // untimed first touch
+  HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  for (int i = 0; i < nrepeat; i++)
+    if (spmv(c, mode, dot, c->Bs, c->Bs, c->W[7], nullptr, 0)) return FX_ERROR_RUNTIME;
+  HIP_TRY(hipEventRecord(c->ev1, c->stream));
+  HIP_TRY(hipEventSynchronize(c->ev1));
+  HIP_TRY(hipGetLastError());
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  if (ms_per_call) *ms_per_call = ms / std::max(nrepeat, 1);
+  return 0;
+}
+
 extern "C" int fx_matvec_resident(fx_context *c, int nrepeat, float *ms_per_call) {
   HIP_TRY(hipSetDevice(c->device));
   if (!c->have_values) { g_fx_error = "fx_matvec_resident: no matrix resident"; return FX_ERROR_RUNTIME; }

@@ -846,7 +846,10 @@ static int nn_matvec(fx_context *c, const fx_matrix_view *m, const fx_comm_view 
       g_fx_error = "fx_matvec: mat->D is NULL but no matrix values are resident";
       return FX_ERROR_RUNTIME;
     }
-  } else if (nn_upload(c, &mv, cm, true)) return FX_ERROR_RUNTIME;  // no change flag on this entry: values uploaded every call
+  } else {
+    if (nn_upload(c, &mv, cm, true)) return FX_ERROR_RUNTIME;  // no change flag on this entry: values uploaded every call
+    c->host_D = m->D; c->host_AL = m->AL; c->host_AU = m->AU;   // whose values are resident now (see fx_solve)
+  }
   NnDev *n = nn_of(c);
   const size_t len = (size_t)n->ndof * n->NP * 8;
   HIP_TRY(hipMemcpyAsync(n->W[6], x, len, hipMemcpyHostToDevice, c->stream));

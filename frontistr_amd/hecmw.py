@@ -228,6 +228,12 @@ class SolverContext:
         _chk(lib().fx_matvec_resident(self.h, nrepeat, C.byref(ms)))
         return ms.value
 
+    def spmv_resident_ms(self, variant=1, nrepeat=10):
+        """variant 0 plain, 1 with the fused x.y partial (the CG loop's launch), 2 residual + r.r partial."""
+        ms = C.c_float(0)
+        _chk(lib().fx_spmv_resident(self.h, int(variant), nrepeat, C.byref(ms)))
+        return ms.value
+
     def precond_apply_ms(self, nrepeat=5):
         ms = C.c_float(0)
         _chk(lib().fx_precond_apply_resident(self.h, nrepeat, C.byref(ms)))
@@ -299,6 +305,12 @@ class SolverContext:
     def comm_init(self, unique_id, rank, nranks):
         buf = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
         _chk(lib().fx_comm_init(self.h, buf, rank, nranks))
+
+    def comm_size(self):
+        """(ranks, device) as the transport itself reports them (ncclCommCount / ncclCommCuDevice)."""
+        n, d = C.c_int32(0), C.c_int32(0)
+        _chk(lib().fx_comm_size(self.h, C.byref(n), C.byref(d)))
+        return n.value, d.value
 
     def synchronize(self):
         _chk(lib().fx_device_synchronize(self.h))

@@ -129,6 +129,10 @@ int fx_download_x(fx_context *ctx, double *X, int32_t n);          /* 3*NP doubl
 int fx_download_matrix(fx_context *ctx, double *D, double *AL, double *AU, double *B);
 /* Resident single operations (tests, roofline timing). */
 int fx_matvec_resident(fx_context *ctx, int nrepeat, float *ms_per_call); /* y = A x on work vectors */
+/* The same with the launch variant chosen: 0 plain (hecmw_solver_BiCGSTAB.f90:184, :210), 1 fused partial of x.y (the
+ * product of every CG iteration, hecmw_solver_CG.f90:204-211), 2 r = b - A x with the partial of r.r (hecmw_matresid,
+ * las/hecmw_solver_las.f90:105-122).  HIP events on the solver stream; one untimed call first. */
+int fx_spmv_resident(fx_context *ctx, int variant, int nrepeat, float *ms_per_call);
 /* The same for the resident NDOF != 3 system of the last fx_solve / fx_matvec (hecmw_matvec_nn, las_nn.f90:135-310).
  * stats: NDOF, N, padded blocks of the layout, blocks of the matrix (N + NPL + NPU). */
 int fx_nn_matvec_resident(fx_context *ctx, int nrepeat, float *ms_per_call, int64_t stats[4]);
@@ -245,6 +249,9 @@ int fx_comm_init(fx_context *ctx, const unsigned char id[128], int rank, int nra
  * export_item order, recv must be filled with 3*n_import doubles in import_item order
  * (hecmw_solve_send_recv_33, hecmw_solver_SR_33.F90:42-124).  allreduce: in-place SUM over
  * ranks of n doubles (hecmw_allreduce_R, hecmw_comm_f.F90:346-379). */
+/* Ranks the transport itself reports (ncclCommCount of the RCCL communicator, or the count given with the host
+ * callbacks; 1 without either) and the device the communicator / context is bound to. */
+int fx_comm_size(fx_context *ctx, int32_t *nranks, int32_t *device);
 typedef void (*fx_halo_fn)(const double *send, double *recv, void *user);
 typedef void (*fx_allreduce_fn)(double *v, int n, void *user);
 int fx_comm_set_host_callbacks(fx_context *ctx, int rank, int nranks, fx_halo_fn halo, fx_allreduce_fn allreduce,

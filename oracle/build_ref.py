@@ -13,6 +13,7 @@ Executables produced
   oracle/_ref/ref_solve       serial build      (natural-order SSOR, 1 thread)
   oracle/_ref/ref_solve_omp   -fopenmp build    (RCM + multicolour SSOR when
                                                  OMP_NUM_THREADS >= 2)
+  oracle/_ref/ref_solve_omp_o3  the same at -O3: the cpu_baseline binary of bench.py
   oracle/_ref/ref_fem         element stiffness / profile / assembly / BC of
                               the reference (STF_C3D8IC, STF_C3D8Bbar, STF_C3,
                               hecmw_mat_con, hecmw_mat_ass_elem, hecmw_mat_ass_bc)
@@ -119,16 +120,16 @@ def scan_driver(path):
     return us - INTRINSIC
 
 
-def build_variant(name, drivers, omp, jobs, provides, uses, overrides=None, defines=(), extra_link=(), exe_name=None):
+def build_variant(name, drivers, omp, jobs, provides, uses, overrides=None, defines=(), extra_link=(), exe_name=None, opt="-O2"):
     objdir = os.path.join(OUT, "obj_" + name)
     moddir = os.path.join(OUT, "mod_" + name)
     os.makedirs(objdir, exist_ok=True)
     os.makedirs(moddir, exist_ok=True)
-    fflags = ["-O2", "-cpp", "-DHECMW_SERIAL", "-module-dir", moddir, "-I", moddir,
+    fflags = [opt, "-cpp", "-DHECMW_SERIAL", "-module-dir", moddir, "-I", moddir,
               "-I", os.path.join(REF, "fistr1/src/common"),
               "-I", os.path.join(REF, "fistr1/src/lib"),
               "-I", os.path.join(REF, "hecmw1/src/common")]
-    cflags = ["-O2", "-DHECMW_SERIAL", "-fcommon", "-w",
+    cflags = [opt, "-DHECMW_SERIAL", "-fcommon", "-w",
               "-I", os.path.join(REF, "hecmw1/src/common"),
               "-I", os.path.join(REF, "hecmw1/src/hecmw"),
               "-I", os.path.join(REF, "hecmw1/src/visualizer")]
@@ -269,6 +270,9 @@ def main():
     if a.only in (None, "solve"):
         build_variant("serial", [solve], False, a.jobs, provides, uses)
         build_variant("omp", [solve], True, a.jobs, provides, uses)
+        # the CPU-baseline binary of bench.py: same sources, -O3 as SURVEY section 0 built the reference.  Kept apart from
+        # ref_solve_omp so that the golden fixtures keep the build they were generated with.
+        build_variant("omp3", [solve], True, a.jobs, provides, uses, exe_name="ref_solve_omp_o3", opt="-O3")
     if a.only in (None, "fem") and os.path.exists(fem):
         build_variant("fem", [fem], False, a.jobs, provides, uses)
     # Nonlinear (elastoplastic) element path + load-step loop; OpenMP build so that PRECOND=1 is the

@@ -249,3 +249,42 @@ def test_hip_distributed_nonlinear_equals_serial_oracle(oracle, tmp_path):
         assert int(r["it"]) == olog.shape[0] == 8
         assert np.abs(r["X"].reshape(-1, 3) - us[r["gid"]]).max() < 1e-8 * np.abs(us).max()      # internal and halo nodes
         np.testing.assert_allclose(r["hist"], olog[:, 3], rtol=1e-6)                               # |residual| per Newton iteration
+
+
+@pytest.mark.parametrize("ngpu", [2, 4])
+def test_bench_self_launch(ngpu):
+    """`python bench.py --gpus N` with no launcher: the parent (no torch, no HIP) starts N rank processes itself; here they
+    share the one GPU through the gloo rehearsal transport.  n_gpus must be the rank count the transport reports."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["FX_BENCH_TRANSPORT"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ngpu), "--steps", "6", "--warmup", "2",
+                        "--elems", "23"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == ngpu and out["steps"] == 6 and out["scaling"] == "weak"
+    assert out["config"]["decomposition"] == {2: "2x1x1", 4: "2x2x1"}[ngpu]
+    assert out["value"] > 0 and np.isfinite(out["resid_after_steps"])
+    assert "cpu_baseline" not in out          # rank 0 at N = 1 only
+
+
+def test_bench_refuses_more_rccl_ranks_than_devices():
+    """Without the rehearsal transport, N ranks over RCCL on a box with fewer GPUs is an error, not a 1-GPU number."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    from conftest import ROOT
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("more than one GPU here")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "FX_BENCH_TRANSPORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--elems", "8"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode != 0 and "need 2 GPUs" in p.stderr
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
