@@ -175,7 +175,8 @@ static int context_init(fx_context *c) {
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
-  if (dev_alloc(&c->st, 1) || dev_alloc(&c->red_out, 16)) return FX_ERROR_RUNTIME;
+  if (dev_alloc(&c->st, 1) || dev_alloc(&c->red_out, 16) || dev_alloc(&c->df_err, 4)) return FX_ERROR_RUNTIME;
+  HIP_TRY(hipMemset(c->df_err, 0, 16));
   HIP_TRY(hipHostMalloc((void **)&c->st_host, sizeof(KrylovState) * 4, hipHostMallocDefault));
   return 0;
 }
@@ -195,6 +196,7 @@ extern "C" int fx_create(int device, fx_context **out) {
   HIP_TRY(hipSetDevice(device));
   fx_context *c = new fx_context();
   c->device = device;
+  HIP_TRY(hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device));
   if (context_init(c)) {  // release whatever was created before the failing call
     fx_destroy(c);
     return FX_ERROR_RUNTIME;
@@ -208,6 +210,11 @@ extern "C" int fx_create(int device, fx_context **out) {
   if (const char *e = getenv("FX_SPMV_SPATIAL")) c->spmv_spatial = atoi(e) != 0;
   if (const char *e = getenv("FX_GRAPH")) c->graph_mode = atoi(e);
   if (const char *e = getenv("FX_SPLIT_MAX_SLICES")) c->split_max_slices = atoi(e);
+  if (const char *e = getenv("FX_DATAFLOW")) c->df_mode = atoi(e);
+  if (const char *e = getenv("FX_DF_GRID")) c->df_grid = atoi(e);
+  if (const char *e = getenv("FX_DF_POLL")) c->df_poll = atoi(e);
+  if (const char *e = getenv("FX_DF_SLEEP")) c->df_sleep = std::max(0, atoi(e));
+  if (const char *e = getenv("FX_DF_WPS")) c->df_wps = (atoi(e) == 2 || atoi(e) == 4) ? atoi(e) : 8;
   if (const char *e = getenv("FX_SPLIT_WPS")) c->split_wps = (atoi(e) == 2 || atoi(e) == 4 || atoi(e) == 8) ? atoi(e) : 0;
   *out = c;
   return 0;
@@ -244,7 +251,7 @@ static void free_matrix(fx_context *c) {
 static void free_precond(fx_context *c) {
   dev_free(c->diag.alu);
   bell_free(c->ssor.L); bell_free(c->ssor.U);
-  dev_free(c->ssor.alu); dev_free(c->ssor.slot_node); dev_free(c->ssor.zs);
+  dev_free(c->ssor.alu); dev_free(c->ssor.slot_node); dev_free(c->ssor.zs); dev_free(c->ssor.zb);
   dev_free(c->ssor.lu_D); dev_free(c->ssor.lu_AL); dev_free(c->ssor.lu_AU);
   c->ssor = SsorDev();
   c->precond_valid = false;
@@ -264,7 +271,7 @@ extern "C" void fx_destroy(fx_context *c) {
   free_matrix(c);
   dev_free(c->halo.export_item); dev_free(c->halo.import_item);
   dev_free(c->halo.sendbuf); dev_free(c->halo.recvbuf);
-  dev_free(c->st); dev_free(c->red_out); dev_free(c->hist); dev_free(c->extra);
+  dev_free(c->st); dev_free(c->red_out); dev_free(c->hist); dev_free(c->extra); dev_free(c->df_err);
   if (c->st_host) (void)hipHostFree(c->st_host);
   if (c->h_send) (void)hipHostFree(c->h_send);
   if (c->h_recv) (void)hipHostFree(c->h_recv);
@@ -1061,6 +1068,36 @@ static int precond_apply_once(fx_context *c, const double *r, double *z, bool wa
     const bool full = (c->ord.kind == 1);  // Krylov vectors already colour-major: sweep in place on z
     const int32_t *sn = full ? (const int32_t *)nullptr : S.slot_node;
     double *zsweep = full ? z : S.zs, *znat = full ? (double *)nullptr : z;
+    if ((c->precond_kind == 10 && c->df_mode >= 1) || (c->precond_kind == 1 && c->df_mode >= 2)) {
+      // one persistent launch: forward values in S.zs, backward values in z itself (colour-major Krylov vectors) or in
+      // S.zb (+ z in the caller's numbering); both start as the sentinel pattern (0xFF bytes)
+      const int32_t nsl = S.L.nslices;
+      const size_t vbytes = (size_t)3 * S.nslots * 8;
+      if (!full && !S.zb && dev_alloc(&S.zb, (size_t)3 * S.nslots)) return FX_ERROR_RUNTIME;
+      double *zbk = full ? z : S.zb;
+      if (want_dot && nsl > c->max_partials) want_dot = false;
+      hipLaunchKernelGGL(k_df_fill, dim3(grid_for((int64_t)(vbytes / 16), 256, 2048)), dim3(256), 0, c->stream, (int64_t)(vbytes / 16),
+                         (fx_u4 *)S.zs, (fx_u4 *)zbk);  // 3 * 64 * 8 bytes per slice: a multiple of 16
+      int grid = c->df_grid > 0 ? c->df_grid : std::max(1, c->n_cu / 2);  // <= one workgroup per CU: always co-resident
+      grid = std::max(1, std::min(grid, (int)nsl));
+      double *part = want_dot ? c->partials : (double *)nullptr;
+#define DF_LAUNCH2(W, P)                                                                                                    \
+  hipLaunchKernelGGL((k_tri_dataflow<W, P>), dim3(grid), dim3(64 * W), 0, c->stream, nsl, S.L.pair_ptr, S.L.val2, S.L.col2, \
+                     S.U.pair_ptr, S.U.val2, S.U.col2, sn, S.alu, r, S.zs, zbk, znat, part, gate_status(c), c->df_err, c->df_sleep)
+#define DF_LAUNCH(W)                    \
+  do {                                  \
+    if (c->df_poll == 0) DF_LAUNCH2(W, 0); \
+    else DF_LAUNCH2(W, 1);              \
+  } while (0)
+      if (c->df_wps == 2) DF_LAUNCH(2);
+      else if (c->df_wps == 8) DF_LAUNCH(8);
+      else DF_LAUNCH(4);
+#undef DF_LAUNCH
+#undef DF_LAUNCH2
+      HIP_TRY(hipGetLastError());
+      *nparts = want_dot ? nsl : 0;
+      return 0;
+    }
     // Workgroup size per colour: 64-thread groups (one slice each) spread a colour evenly over the 256 CUs
     // (a 150^3 colour has 5276 slices = 5.2 four-slice groups per CU: a 6-vs-5 imbalance); FX_SSOR_BS overrides.
     const int bs = c->ssor_bs;
@@ -1173,9 +1210,16 @@ static int krylov_init_state(fx_context *c, int maxit, double tol) {
 }
 
 static int poll_state(fx_context *c, KrylovState *out) {
+  int32_t *herr = (int32_t *)(c->st_host + 3);  // pinned
   HIP_TRY(hipMemcpyAsync(c->st_host, c->st, sizeof(KrylovState), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(herr, c->df_err, 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   *out = *c->st_host;
+  if (*herr != 0) {
+    (void)hipMemset(c->df_err, 0, 4);
+    g_fx_error = "dataflow sweep: a bounded wait ran out (workgroups not co-resident, or a producer failed); FX_DATAFLOW=0 selects the launch-per-level sweeps";
+    return FX_ERROR_RUNTIME;
+  }
   return 0;
 }
 

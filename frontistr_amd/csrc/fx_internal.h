@@ -86,6 +86,7 @@ struct SsorDev {
   int32_t nslots = 0;                // colour-major slots (each colour padded to a 64 multiple)
   int32_t *slot_node = nullptr;      // device: slot -> 0-based node, -1 = padding
   double *zs = nullptr;              // private sweep vector, 3*nslots, colour-major
+  double *zb = nullptr;              // dataflow sweeps: the backward sweep's vector (zs holds the forward one), 3*nslots
   double *lu_D = nullptr, *lu_AL = nullptr, *lu_AU = nullptr;  // ILU(0): factor values in the reference CSR layout
   std::vector<int32_t> slot_start;   // ILU(0): first slot of each level (ncolor+1)
   int32_t max_row_blocks = 0;        // ILU(0): largest number of off-diagonal blocks in a row (<= 32: lane-per-block factorisation)
@@ -168,6 +169,7 @@ struct NlDev {
 
 struct fx_context {
   int device = 0;
+  int n_cu = 256;  // compute units of the device
   hipStream_t stream = nullptr;
   DevCSR A;
   Ordering ord;
@@ -202,6 +204,19 @@ struct fx_context {
   // with 8 waves per slice, 10.7 ms with the diagonal factor prefetched (BiCGSTAB + ILU(0) 24 -> 43 it/s).  Auto: 8 for ILU(0) levels, 4 for SSOR colours.
   int split_max_slices = 2048;
   int split_wps = 0;
+  // Dataflow triangular sweeps (k_tri_dataflow): one persistent launch per apply, rows synchronised through
+  // sentinel-tagged data instead of one launch per colour / level.  FX_DATAFLOW=0 off, 1 (default) ILU(0) levels,
+  // 2 also the multicolour SSOR (measured slower than the colour launches: 1.59-1.71 against 1.50 ms per apply -- the big
+  // colours are bandwidth-bound and a few hundred workgroups with one slice each in flight do not saturate HBM).
+  // FX_DF_GRID workgroups (default: one per two CUs), FX_DF_WPS waves per slice (2, 4, 8), FX_DF_POLL 0 = every poll
+  // re-reads all entries, 1 = only the unpublished ones, FX_DF_SLEEP s_sleep(1)s between polls.
+  // Measured at 10.1M DOF, ILU(0), 1,044 levels (same process, scripts/experiments/ab_dataflow3.py): launch per level
+  // 10.7 ms per apply; dataflow 4.80-4.87 ms with 128 workgroups x 8 waves (96: 5.3, 160: 4.89, 192: 4.92, 256: 5.0-5.1,
+  // 512: 8.0; 4 waves per slice 5.2; re-reading all entries per poll 5.6; two polls in flight 5.9; 0.4-1.5 us of sleep
+  // between polls 4.9-5.3): 2,088 dependent hand-offs of ~2.3 us each -- the polls of the waiting workgroups compete
+  // with the frontier's hand-offs, so fewer pollers and fewer re-read entries are faster.
+  int df_mode = 1, df_grid = 0, df_wps = 8, df_poll = 1, df_sleep = 2;
+  int32_t *df_err = nullptr;  // device: raised by a sweep whose bounded spin ran out
   // software-pipelined row loop (2-deep: values + gathers of pair i+1 and ids of pair i+2 in flight while pair i
   // is multiplied; 116 VGPRs, 4 waves/SIMD).  Measured on MI355X at 10.1M DOF with the final layout (odd-tail BELL,
   // non-temporal stream loads): SpMV 1.14-1.17 -> 1.105-1.11 ms; colour sweeps 1.685 -> 1.61 ms per apply.

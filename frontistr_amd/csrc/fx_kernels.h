@@ -360,13 +360,23 @@ __global__ __launch_bounds__(BS) void k_ssor_color(int32_t slice0, int32_t slice
 // level at 10M DOF).  WPS waves share one slice: wave w takes the block pairs w, w+WPS, ... (7 pairs for a hex-mesh
 // lower part => at most two per wave at WPS=4), issues every load of its pairs before the first use, and the partial
 // sums meet in LDS in a fixed order.  Same layout, same coalescing, 1/WPS of the dependent depth.
+// The contraction is written out (which product is fused into which sum) so that every kernel that shares these helpers
+// rounds identically: k_ssor_color_split and k_tri_dataflow are bit-identical by construction, not by the compiler's mood.
+__device__ __forceinline__ double bell_dot3(double a0, double a1, double a2, double x0, double x1, double x2) {
+  return fma(a2, x2, fma(a1, x1, a0 * x0));
+}
 __device__ __forceinline__ void bell_pair_fma(const double2 (&a)[9], const double (&xv)[6], double &s0, double &s1, double &s2) {
-  s0 += a[0].x * xv[0] + a[1].x * xv[1] + a[2].x * xv[2];
-  s1 += a[3].x * xv[0] + a[4].x * xv[1] + a[5].x * xv[2];
-  s2 += a[6].x * xv[0] + a[7].x * xv[1] + a[8].x * xv[2];
-  s0 += a[0].y * xv[3] + a[1].y * xv[4] + a[2].y * xv[5];
-  s1 += a[3].y * xv[3] + a[4].y * xv[4] + a[5].y * xv[5];
-  s2 += a[6].y * xv[3] + a[7].y * xv[4] + a[8].y * xv[5];
+  s0 += bell_dot3(a[0].x, a[1].x, a[2].x, xv[0], xv[1], xv[2]);
+  s1 += bell_dot3(a[3].x, a[4].x, a[5].x, xv[0], xv[1], xv[2]);
+  s2 += bell_dot3(a[6].x, a[7].x, a[8].x, xv[0], xv[1], xv[2]);
+  s0 += bell_dot3(a[0].y, a[1].y, a[2].y, xv[3], xv[4], xv[5]);
+  s1 += bell_dot3(a[3].y, a[4].y, a[5].y, xv[3], xv[4], xv[5]);
+  s2 += bell_dot3(a[6].y, a[7].y, a[8].y, xv[3], xv[4], xv[5]);
+}
+__device__ __forceinline__ void bell_single_fma(const double (&a)[9], const double (&xv)[3], double &s0, double &s1, double &s2) {
+  s0 += bell_dot3(a[0], a[1], a[2], xv[0], xv[1], xv[2]);
+  s1 += bell_dot3(a[3], a[4], a[5], xv[0], xv[1], xv[2]);
+  s2 += bell_dot3(a[6], a[7], a[8], xv[0], xv[1], xv[2]);
 }
 
 template <bool FWD, int WPS>
@@ -428,8 +438,16 @@ __global__ __launch_bounds__(64 * WPS) void k_ssor_color_split(int32_t slice0, i
     const double xva[6] = {xa[0], xa[1], xa[2], xb[0], xb[1], xb[2]};
     bell_pair_fma(a, xva, s0, s1, s2);
   }
-  if (((h1 - h0) & 1) && w == (np % WPS))
-    bell_tail_block(val2 + (size_t)(h0 + 2 * np) * 576 + lane, col2 + (size_t)(h0 + 2 * np) * 64 + lane, zs, s0, s1, s2);
+  if (((h1 - h0) & 1) && w == (np % WPS)) {  // an odd last block of the slice is stored alone
+    const double *vt = val2 + (size_t)(h0 + 2 * np) * 576 + lane;
+    const int cc = ld_stream(col2 + (size_t)(h0 + 2 * np) * 64 + lane);
+    double a[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) a[e] = ld_stream(vt + e * 64);
+    const double *xa = zs + (size_t)3 * cc;
+    const double x[3] = {xa[0], xa[1], xa[2]};
+    bell_single_fma(a, x, s0, s1, s2);
+  }
   part[w][0][lane] = s0; part[w][1][lane] = s1; part[w][2][lane] = s2;
   __syncthreads();
   double d[1] = {0.0};
@@ -456,6 +474,218 @@ __global__ __launch_bounds__(64 * WPS) void k_ssor_color_split(int32_t slice0, i
     }
   }
   if (!FWD && partials) block_sum_store<1, 64 * WPS>(d, partials, 0, blockIdx.x);
+}
+
+// ------------------------------------------------------------------------
+// Dataflow triangular sweeps: ONE persistent launch per preconditioner apply instead of one launch per colour / per
+// ILU(0) dependency level (1,044 levels x 2 half sweeps at 10M DOF; each level is ~50 slices, i.e. a few microseconds
+// of dependent latency and almost no bandwidth).  There is no grid barrier either: the DATA is the flag.  Both sweep
+// vectors are filled with a sentinel bit pattern before the launch; a row publishes its three entries with 8-byte
+// agent-scope (write-through, sc1) stores -- one naturally aligned store each, so never torn -- and a consumer re-reads
+// the entries it gathers with agent-scope loads until none is the sentinel (MI355X_MICROARCH.md, inter-workgroup
+// visibility: the self-tagged 8-byte granule hand-off, 0.8-1.5 us per hop; a kernel boundary costs 1.5-1.9 us plus the
+// dependent index -> block -> gather chain after it).  The matrix stream of a slice (blocks, column ids, diagonal factor,
+// right-hand side) does not depend on the sweep and is in flight before the slice starts to poll, so only the gather of
+// z, the 3x3 substitution and the store sit on the critical path.
+//   forward  (ascending slices):  zf_i = D~_i^-1 (r_i - sum_{j in L(i)} L_ij zf_j)
+//   backward (descending slices): zb_i = zf_i - D~_i^-1 sum_{j in U(i)} U_ij zb_j ;  z[node_i] = zb_i (+ partial of r.z)
+// Same operands in the same order as k_ssor_color_split with the same WPS: results are bit-identical to it.
+// Progress: workgroup w owns slices w, w + G, ...; it walks them upwards in the forward sweep and downwards in the
+// backward sweep, and a slice only waits for slices earlier in its sweep's order, so the first unfinished slice of a
+// sweep can always run -- provided all G workgroups are resident (G <= CUs here).
+// Every spin is bounded by wall-clock time; a timeout raises *err (the host turns it into a runtime failure).
+// ------------------------------------------------------------------------
+#define FX_DF_SENTINEL (-1LL)          // 0xFFFFFFFFFFFFFFFF: a NaN pattern no arithmetic instruction produces
+#define FX_DF_TIMEOUT_TICKS 200000000ull  // 2 s of the 100 MHz constant clock
+
+__device__ __forceinline__ double df_load(const double *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void df_store(double *p, double v) {
+  if (__double_as_longlong(v) == FX_DF_SENTINEL) v = __longlong_as_double(0x7FF8000000000000LL);  // keep the tag unique
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Tag fill of the sweep vectors before a launch, with the same agent-scope write-through stores the hand-off itself uses
+// (a plain memset's lines can survive, stale, in another XCD's L2: per-XCD L2s are only kept coherent for sc1 traffic).
+typedef unsigned int fx_u4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_df_fill(int64_t n16, fx_u4 *__restrict__ a, fx_u4 *__restrict__ b) {
+  const fx_u4 tag = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(a + i), "v"(tag) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(b + i), "v"(tag) : "memory");
+  }
+}
+
+// Gather the two vector entries (3 doubles each) of one block pair, waiting until their producers have published them.
+// A padding block points at the lane's own slot (value 0): no producer, contributes 0.
+// POLL selects how a wave waits (A/B-measured in one process, scripts/experiments/ab_dataflow3.sh):
+//   0  every pass re-reads all 3 * NB entries;  1  later passes re-read only the entries still unpublished.
+template <int NB, int POLL>
+__device__ __forceinline__ void df_gather(const double *__restrict__ zs, const int (&col)[NB], int self, double (&x)[3 * NB],
+                                          int32_t *__restrict__ err, bool &dead, int nsleep) {
+  bool miss[3 * NB];
+  bool any = false;
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    const double *xa = zs + (size_t)3 * col[b];
+    const bool need = col[b] != self;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      x[3 * b + k] = df_load(xa + k);
+      miss[3 * b + k] = need && __double_as_longlong(x[3 * b + k]) == FX_DF_SENTINEL;
+      any |= miss[3 * b + k];
+    }
+    if (!need) { x[3 * b] = 0.0; x[3 * b + 1] = 0.0; x[3 * b + 2] = 0.0; }
+  }
+  if (!__any(any) || dead) return;  // a wave that has given up takes what is there: the launch drains without waiting
+  unsigned long long t0 = 0;
+  for (unsigned spins = 1;; spins++) {
+    for (int q = 0; q < nsleep; q++) __builtin_amdgcn_s_sleep(1);  // 64 clocks each
+    any = false;
+#pragma unroll
+    for (int e = 0; e < 3 * NB; e++) {
+      const bool need = col[e / 3] != self;
+      if (POLL == 0 ? need : miss[e]) {
+        x[e] = df_load(zs + (size_t)3 * col[e / 3] + (e % 3));
+        miss[e] = __double_as_longlong(x[e]) == FX_DF_SENTINEL;
+        any |= miss[e];
+      }
+    }
+    if (!__any(any)) return;
+    if ((spins & 255u) == 0u) {  // bounded spin: give up after FX_DF_TIMEOUT_TICKS, or as soon as somebody else has
+      const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+      if (t0 == 0) t0 = now;
+      const int e = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (e != 0 || now - t0 > FX_DF_TIMEOUT_TICKS) {
+        if (e == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dead = true;
+        return;
+      }
+    }
+  }
+}
+
+template <bool FWD, int WPS, int POLL>
+__device__ __forceinline__ void df_slice(int slice, const int32_t *__restrict__ pair_ptr, const double *__restrict__ val2,
+                                         const int *__restrict__ col2, const int32_t *__restrict__ slot_node,
+                                         const double *__restrict__ alu, const double *__restrict__ r,
+                                         double *__restrict__ zf, double *__restrict__ zb, double *__restrict__ z,
+                                         double *__restrict__ partials, int32_t *__restrict__ err, double (*part)[3][64],
+                                         bool &dead, int nsleep) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int h0 = pair_ptr[slice], h1 = pair_ptr[slice + 1];
+  const int np = (h1 - h0) >> 1;
+  const int slot = slice * 64 + lane;
+  const double *zsrc = FWD ? zf : zb;  // the vector whose entries this sweep produces and gathers
+  // the finishing wave's own operands: independent of the sweep, in flight before the first poll
+  int node = -1;
+  double u[9], ri0 = 0.0, ri1 = 0.0, ri2 = 0.0, zo0 = 0.0, zo1 = 0.0, zo2 = 0.0;
+  if (w == 0) {
+    node = slot_node ? slot_node[slot] : slot;
+    const size_t base = (size_t)slice * 576 + lane;
+#pragma unroll
+    for (int e = 0; e < 9; e++) u[e] = alu[base + (size_t)e * 64];
+    if (node >= 0) {
+      if (FWD || partials) { ri0 = r[(size_t)3 * node]; ri1 = r[(size_t)3 * node + 1]; ri2 = r[(size_t)3 * node + 2]; }
+      if (!FWD) {  // this row's forward value: written by this very thread earlier in the launch (a workgroup keeps its slices)
+        zo0 = df_load(zf + (size_t)3 * slot); zo1 = df_load(zf + (size_t)3 * slot + 1); zo2 = df_load(zf + (size_t)3 * slot + 2);
+      }
+    }
+  }
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  const double2 *vbase = (const double2 *)(val2 + (size_t)h0 * 576) + lane;
+  const int2 *cbase = (const int2 *)(col2 + (size_t)h0 * 64) + lane;
+  int i = w;
+  for (; i + WPS < np; i += 2 * WPS) {  // two of this wave's pairs in flight together
+    const double2 *va = vbase + (size_t)i * 576, *vb = vbase + (size_t)(i + WPS) * 576;
+    const int2 ca = ld_stream(cbase + (size_t)i * 64), cb = ld_stream(cbase + (size_t)(i + WPS) * 64);
+    double2 a[9], b[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) a[e] = ld_stream(va + e * 64);
+#pragma unroll
+    for (int e = 0; e < 9; e++) b[e] = ld_stream(vb + e * 64);
+    const int cols[4] = {ca.x, ca.y, cb.x, cb.y};
+    double x[12];
+    df_gather<4, POLL>(zsrc, cols, slot, x, err, dead, nsleep);
+    const double xva[6] = {x[0], x[1], x[2], x[3], x[4], x[5]};
+    const double xvb[6] = {x[6], x[7], x[8], x[9], x[10], x[11]};
+    bell_pair_fma(a, xva, s0, s1, s2);
+    bell_pair_fma(b, xvb, s0, s1, s2);
+  }
+  if (i < np) {
+    const double2 *va = vbase + (size_t)i * 576;
+    const int2 ca = ld_stream(cbase + (size_t)i * 64);
+    double2 a[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) a[e] = ld_stream(va + e * 64);
+    const int cols[2] = {ca.x, ca.y};
+    double x[6];
+    df_gather<2, POLL>(zsrc, cols, slot, x, err, dead, nsleep);
+    bell_pair_fma(a, x, s0, s1, s2);
+  }
+  if (((h1 - h0) & 1) && w == (np % WPS)) {  // an odd last block of the slice is stored alone
+    const double *vt = val2 + (size_t)(h0 + 2 * np) * 576 + lane;
+    const int cols[1] = {ld_stream(col2 + (size_t)(h0 + 2 * np) * 64 + lane)};
+    double a[9], x[3];
+#pragma unroll
+    for (int e = 0; e < 9; e++) a[e] = ld_stream(vt + e * 64);
+    df_gather<1, POLL>(zsrc, cols, slot, x, err, dead, nsleep);
+    bell_single_fma(a, x, s0, s1, s2);
+  }
+  part[w][0][lane] = s0; part[w][1][lane] = s1; part[w][2][lane] = s2;
+  __syncthreads();
+  if (w == 0) {
+    s0 = part[0][0][lane]; s1 = part[0][1][lane]; s2 = part[0][2][lane];
+#pragma unroll
+    for (int k = 1; k < WPS; k++) { s0 += part[k][0][lane]; s1 += part[k][1][lane]; s2 += part[k][2][lane]; }
+    double d = 0.0;
+    if (node >= 0) {
+      if (FWD) {
+        double x1 = ri0 - s0, x2 = ri1 - s1, x3 = ri2 - s2;
+        lusolve33_dev(u, x1, x2, x3);
+        double *zi = zf + (size_t)3 * slot;
+        df_store(zi, x1); df_store(zi + 1, x2); df_store(zi + 2, x3);
+      } else {
+        lusolve33_dev(u, s0, s1, s2);
+        const double x1 = zo0 - s0, x2 = zo1 - s1, x3 = zo2 - s2;
+        double *zi = zb + (size_t)3 * slot;
+        df_store(zi, x1); df_store(zi + 1, x2); df_store(zi + 2, x3);
+        if (z) {
+          double *zn = z + (size_t)3 * node;
+          zn[0] = x1; zn[1] = x2; zn[2] = x3;
+        }
+        if (partials) d = ri0 * x1 + ri1 * x2 + ri2 * x3;
+      }
+    }
+    if (!FWD && partials) {
+      d = wave_sum(d);
+      if (lane == 0) partials[slice] = d;
+    }
+  }
+}
+
+template <int WPS, int POLL>
+__global__ __launch_bounds__(64 * WPS) void k_tri_dataflow(int32_t nslices, const int32_t *__restrict__ Lptr,
+                                                           const double *__restrict__ Lval, const int *__restrict__ Lcol,
+                                                           const int32_t *__restrict__ Uptr, const double *__restrict__ Uval,
+                                                           const int *__restrict__ Ucol,
+                                                           const int32_t *__restrict__ slot_node,
+                                                           const double *__restrict__ alu, const double *__restrict__ r,
+                                                           double *__restrict__ zf, double *__restrict__ zb,
+                                                           double *__restrict__ z, double *__restrict__ partials,
+                                                           const int32_t *__restrict__ gate, int32_t *__restrict__ err,
+                                                           int nsleep) {
+  if (gate && *gate != 0) return;
+  __shared__ double part[2][WPS][3][64];  // double-buffered: one workgroup barrier per slice
+  int buf = 0;
+  bool dead = false;  // per wave: its bounded wait ran out (or another wave's did); it then stops waiting, never stops running
+  for (int slice = blockIdx.x; slice < nslices; slice += gridDim.x, buf ^= 1)
+    df_slice<true, WPS, POLL>(slice, Lptr, Lval, Lcol, slot_node, alu, r, zf, zb, z, partials, err, part[buf], dead, nsleep);
+  // backward: the SAME slices, last first (a row's forward value is then its own thread's earlier store)
+  const int mine = nslices > (int)blockIdx.x ? (nslices - 1 - (int)blockIdx.x) / (int)gridDim.x : -1;
+  for (int slice = (int)blockIdx.x + mine * (int)gridDim.x; mine >= 0 && slice >= 0; slice -= gridDim.x, buf ^= 1)
+    df_slice<false, WPS, POLL>(slice, Uptr, Uval, Ucol, slot_node, alu, r, zf, zb, z, partials, err, part[buf], dead, nsleep);
 }
 
 // ------------------------------------------------------------------------

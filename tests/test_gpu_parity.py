@@ -656,3 +656,42 @@ def test_two_matrices_of_one_shape_alternate_without_flags(hip, oracle):
         o = oracle.solve_iterative(A, I, R)
         assert np.abs(m.X - o["X"]).max() <= 1e-7 * np.abs(o["X"]).max()
     ctx.close()
+
+
+@pytest.mark.parametrize("deck", DECKS)
+@pytest.mark.parametrize("pc", [10, 1])
+def test_dataflow_sweeps_equal_launch_per_level_sweeps_bitwise(hip, deck, pc, monkeypatch):
+    """k_tri_dataflow (one persistent launch per apply, rows synchronised through sentinel-tagged data) feeds every row the
+    operands of the launch-per-colour / per-level wave-split kernel in the same order (W waves share a row's block pairs,
+    their partial sums are added in wave order): with the same W, z = M^-1 r must be bit-identical, for ILU(0) levels and
+    for the multicolour SSOR, also with fewer workgroups than slices; different W differ by rounding only."""
+    A = golden_matrix(load_golden(deck))
+    r = np.cos(0.11 * np.arange(3 * A.NP) + 0.3)
+    keys = ("FX_DATAFLOW", "FX_DF_WPS", "FX_DF_GRID", "FX_SPLIT_WPS", "FX_SPLIT_MAX_SLICES")
+
+    def apply(env):
+        for k in keys:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = to_hecmat(hip, A)
+        m.Iarray[2] = pc
+        ctx = hip.SolverContext()
+        ctx.upload(m)
+        ctx.precond_setup(m)
+        z = ctx.precond_apply(r)
+        ctx.precond_apply(np.sin(1.7 * r) + 0.5)     # other data in between: every apply re-initialises the tags
+        z2 = ctx.precond_apply(r)
+        ctx.close()
+        assert np.array_equal(z, z2)
+        return z[:3 * A.N]
+
+    ref = {}
+    for wps, grid in ((2, "3"), (4, "0"), (8, "1"), (8, "0")):
+        lev = apply(dict(FX_DATAFLOW="0", FX_SPLIT_WPS=str(wps), FX_SPLIT_MAX_SLICES=str(1 << 30)))
+        df = apply(dict(FX_DATAFLOW="2", FX_DF_WPS=str(wps), FX_DF_GRID=grid))
+        assert np.all(np.isfinite(lev))
+        assert np.array_equal(df, lev), wps
+        ref[wps] = lev
+    assert np.array_equal(apply(dict(FX_DATAFLOW="2", FX_DF_WPS="8", FX_DF_POLL="0")), ref[8])
+    assert relerr(ref[2], ref[4]) < 1e-13 and relerr(ref[8], ref[4]) < 1e-13
