@@ -25,7 +25,7 @@ The JSON line also carries
                  time, peak 8 TB/s (MI355X_MICROARCH.md)
   cpu_baseline : the REAL reference (oracle/_ref/ref_solve_omp_o3, HEC-MW compiled from
                  /root/reference with flang -O3 -fopenmp) timed on this box's host cores (all
-                 cores of the affinity mask) on a bounded sample of the same workload (rank 0,
+                 cores of the affinity mask, capped by the cgroup CPU quota) on a bounded sample of the same workload (rank 0,
                  N=1 only); --cpu-full times it on the full workload instead (minutes).
 """
 import argparse
@@ -120,6 +120,22 @@ def launch_ranks(a):
         return 1
     print(lines[-1], flush=True)
     return 0
+
+
+def host_cores():
+    """Cores this process may actually use: the affinity mask capped by the cgroup CPU quota (on the GPU boxes of this
+    pool: 256 cores in the mask, cpu.max = 16 CPUs; 256 OpenMP threads on a 16-CPU quota ran the reference 12x slower)."""
+    n = len(os.sched_getaffinity(0))
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: (t.strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()))):
+        try:
+            quota, period = parse(open(path).read())
+            if quota not in ("max", "-1"):
+                n = min(n, max(1, -(-int(quota) // int(period))))
+            break
+        except (OSError, ValueError):
+            continue
+    return max(1, n)
 
 
 def cpu_baseline(hip, np, n_sample, iters, cores, method=1, precond=1):
@@ -315,7 +331,7 @@ def main():
         "resid_after_steps": resid,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cores = max(1, len(os.sched_getaffinity(0)))     # every core this process may run on
+        cores = host_cores()     # every core this process may run on (affinity mask capped by the cgroup quota)
         n_cpu = a.n if a.cpu_full else a.cpu_sample_n
         try:
             cb = cpu_baseline(hip, np, n_cpu, a.cpu_sample_iters, cores, a.method, a.precond)
@@ -328,7 +344,7 @@ def main():
             out["cpu_baseline"] = {
                 "value": (1.0 / cb["per_iter"]) * scale, "unit": "CG iterations/s", "cores": cores,
                 "kind": "reference", "extrapolated": extrap,
-                "sample": "HEC-MW reference (%s: flang %s -fopenmp, OMP_NUM_THREADS=%d = all cores of the affinity mask), same METHOD/PRECOND "
+                "sample": "HEC-MW reference (%s: flang %s -fopenmp, OMP_NUM_THREADS=%d = every core of the affinity mask / cgroup quota), same METHOD/PRECOND "
                           "as the GPU run, on a %d^3-node cube (%.2fM DOF), %d iterations: %.4f s/iter measured = %.2f it/s%s"
                           % (cb["exe"], "-O3" if cb["exe"].endswith("_o3") else "-O2", cores, n_cpu + 1, cb["ndof"] / 1e6,
                              a.cpu_sample_iters, cb["per_iter"], 1.0 / cb["per_iter"],

@@ -239,6 +239,8 @@ struct fx_context {
   double *hist = nullptr;      // device residual history
   int32_t hist_cap = 0;
   int k_method = 1, k_maxit = 0, k_it = 1;  // host mirror of the running Krylov loop
+  int k_method_last = 1;       // METHOD of the last fx_solve_resident attempt
+  double host_dbg[16] = {0};   // scalars of the host-driven recurrences (fx_debug_state)
   // Launch-bound sizes (<= graph_max_rows block rows, single rank): one CG / BiCGSTAB iteration is captured once per
   // solve into two hipGraphs (ordinary iteration; the one that recomputes r = b - A x) and replayed -- every kernel
   // argument is constant over a solve, what changes lives in the device-resident KrylovState.

@@ -55,6 +55,9 @@ struct HostKrylov {
   int iter = 0, status = 1, error = 0;
   double resid = 0.0;
   std::vector<double> hist;
+  // scalars of the last iteration in fx_debug_state's order (rho rho1 beta c1 alpha omega c2 cg0 cg1 dnrm2 bnrm2 ...):
+  // GPBiCG: rho = r~.r, c2 = r~.A p (ALPHA's denominator), omega = QSI, cg0 = COEF1, cg1 = ETA
+  double dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 static int hk_dot(fx_context *c, const double *x, const double *y, double *out) {
@@ -264,6 +267,10 @@ static int gpbicg_solve_t(const Ops &o, int MAXIT, double TOL, HostKrylov *out) 
     BETA = ALPHA * COEF1 / (QSI * RHO);
     VLAUNCH(k_gp_w1, BETA, TT, PT, W1);
     RESID = sqrt(DNRM2 / BNRM2);
+    {
+      const double d[16] = {RHO, RHO1, BETA, 0.0, ALPHA, QSI, RHO1, COEF1, ETA, DNRM2, BNRM2, RESID, TOL, (double)iter, 0.0, 0.0};
+      memcpy(out->dbg, d, sizeof d);
+    }
     RHO = COEF1;
     out->hist.push_back(RESID);
     if (!std::isfinite(RESID)) { error = FX_ERROR_NOCONV_MAXIT; break; }  // breakdown: same guard as the BiCGSTAB path

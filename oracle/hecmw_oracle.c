@@ -832,6 +832,13 @@ int orc_solve_iterative(const orc_matrix *A, const orc_comm *c, const double *B,
     As.D = sD; As.AL = sAL; As.AU = sAU;
     A = &As; B = sB;
   }
+  /* The retries of :145-156 ("Increasing SIGMA_DIAG", METHOD2) call the Krylov routine again, whose hecmw_precond_setup finds
+   * Iarray(97) = Iarray(98) = 0 (cleared by the first set-up) and returns early (hecmw_precond_BILU_33.f90:49-57, the
+   * hecmw_precond_clear at the end of every method is commented out, hecmw_solver_CG.f90:285): the preconditioner of the first
+   * attempt -- built with the first SIGMA_DIAG -- serves every retry.  Checked against the real reference
+   * (tests/golden/retry.npz).  With SCALING the first attempt's set-up sees the scaled matrix; later attempts scale the same
+   * matrix the same way. */
+  orc_precond *P_call = NULL;
   for (;;) {
     F1(Iarray, 81) = 0; F1(Iarray, 82) = 0;
     if (scaling) scaling_33(nd, 0, N, NP, A->indexL, A->itemL, A->indexU, A->itemU, sD, sAL, sAU, sB, X, scale, c);
@@ -844,7 +851,8 @@ int orc_solve_iterative(const orc_matrix *A, const orc_comm *c, const double *B,
         }
         P = g_P;
       } else {
-        P = orc_precond_setup(A, PRECOND, SIGMA_DIAG, NCOLOR_IN, nthreads);
+        if (!P_call) P_call = orc_precond_setup(A, PRECOND, SIGMA_DIAG, NCOLOR_IN, nthreads);
+        P = P_call;
       }
       if (!P) return 1001;
       F1(Iarray, 98) = 0; F1(Iarray, 97) = 0;
@@ -857,8 +865,7 @@ int orc_solve_iterative(const orc_matrix *A, const orc_comm *c, const double *B,
       error = orc_solve_gmres(A, c, P, iterPREmax, B, X, ITER, RESID, F1(Iarray, 6), &iter_run, &resid_run, hist, NULL);
     else if (METHOD == 4)
       error = orc_solve_gpbicg(A, c, P, iterPREmax, B, X, ITER, RESID, &iter_run, &resid_run, hist);
-    else { if (!g_persist) orc_precond_free(P); return 1001; }
-    if (!g_persist) orc_precond_free(P);
+    else { orc_precond_free(P_call); return 1001; }
     if (scaling) scaling_33(nd, 1, N, NP, A->indexL, A->itemL, A->indexU, A->itemU, sD, sAL, sAU, sB, X, scale, c);
     if (error == ERR_DIVERGE_PC || error == ERR_DIVERGE_MAT) { /* :145-156 */
       F1(Iarray, 82) = 1;
@@ -873,6 +880,7 @@ int orc_solve_iterative(const orc_matrix *A, const orc_comm *c, const double *B,
     }
     break;
   }
+  orc_precond_free(P_call);
   if (error != 0) ret = error;
   /* hecmw_rel_resid_L2, hecmw_solver_las.f90:129-158 */
   {

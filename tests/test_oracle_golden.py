@@ -215,3 +215,24 @@ def test_preconditioner_recycle_policy_matches_reference(oracle, name, meth, pc,
     assert np.array_equal(Iout[95:98], g[tag + "Iarray"][95:98])
     fresh = oracle.solve_sequence(A, I, R, 1, nthreads=thr)[0]
     assert fresh[0] == iters[0]
+
+
+def test_divergence_retries_match_the_real_reference(oracle):
+    """hecmw_solver_Iterative.f90:145-156 against tests/golden/retry.npz (real reference runs, make_retry_golden.py): the
+    'Increasing SIGMA_DIAG' retries and the METHOD2 take-over restart from the X the failed attempt left behind with the
+    factors of the FIRST attempt (the reference's set-up returns early on a retry).  ITER, flags and X bit-exact."""
+    from oracle.refrun import default_params
+    g = load_golden("retry")
+    for k in range(int(g["n_cases"])):
+        tag = "c%d_" % k
+        blk, scale, sigma, m2 = g[tag + "case"]
+        A = golden_matrix(load_golden("cube4"))
+        A.D = A.D.copy()
+        A.D[9 * int(blk):9 * int(blk) + 9] *= scale
+        I, R = default_params(method=1, precond=10, maxit=500)
+        R[1] = sigma
+        I[7] = int(m2)
+        o = oracle.solve_iterative(A, I, R)
+        assert o["iter"] == int(g[tag + "iter"]), (k, o["iter"], int(g[tag + "iter"]))
+        assert np.array_equal(o["Iarray"][80:82], g[tag + "Iarray"][80:82]), k
+        assert np.array_equal(o["X"], g[tag + "X"]), k
