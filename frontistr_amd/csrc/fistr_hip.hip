@@ -145,6 +145,45 @@ static void dev_free(T *&p) {
   p = nullptr;
 }
 
+// ---- PhaseClock (TIMELOG) ----
+static int clock_collect(fx_context *c) {  // the stream must be idle (called right after a synchronize)
+  PhaseClock &k = c->clock;
+  for (int i = 0; i < k.used; i++) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, k.ev[2 * i], k.ev[2 * i + 1]) == hipSuccess) k.acc[k.kind[i]] += 1e-3 * ms;
+  }
+  k.used = 0;
+  return 0;
+}
+static int clock_begin(fx_context *c, int kind) {
+  PhaseClock &k = c->clock;
+  if (!k.on) return -1;
+  if (k.used >= 512) {  // pool exhausted between two polls: drain it
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    clock_collect(c);
+  }
+  if ((int)k.ev.size() < 2 * (k.used + 1)) {
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    k.ev.push_back(a); k.ev.push_back(b);
+    k.kind.push_back(kind);
+  }
+  const int id = k.used++;
+  k.kind[id] = kind;
+  HIP_TRY(hipEventRecord(k.ev[2 * id], c->stream));
+  return id;
+}
+static void clock_end(fx_context *c, int id) {
+  if (id >= 0) (void)hipEventRecord(c->clock.ev[2 * id + 1], c->stream);
+}
+struct ClockScope {  // records the pair around a scope
+  fx_context *c;
+  int id;
+  ClockScope(fx_context *ctx, int kind) : c(ctx), id(clock_begin(ctx, kind)) {}
+  ~ClockScope() { clock_end(c, id); }
+};
+
 // Temporary device buffers of one entry point: released on every return path.
 struct DevScratch {
   std::vector<void *> ptrs;
@@ -276,6 +315,7 @@ extern "C" void fx_destroy(fx_context *c) {
   if (c->h_send) (void)hipHostFree(c->h_send);
   if (c->h_recv) (void)hipHostFree(c->h_recv);
   if (c->nccl && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)c->nccl);
+  for (hipEvent_t e : c->clock.ev) (void)hipEventDestroy(e);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -653,6 +693,7 @@ static inline bool multi_rank(const fx_context *c) {
 
 // SUM over ranks of n (<= 8) doubles living at device address v, on the solver stream.
 static int allreduce_dev(fx_context *c, double *v, int n) {
+  ClockScope cs(c, 2);
   if (c->nccl) {
     NCCL_TRY(g_rccl.AllReduce(v, v, n, ncclDouble, ncclSum, (ncclComm_t)c->nccl, c->stream));
     return 0;
@@ -674,6 +715,7 @@ static int halo_update(fx_context *c, double *x) {
   // grouped ncclSend/ncclRecv on a single GPU)
   if (h.n_neighbor <= 0 || (c->nranks <= 1 && !c->nccl && !c->cb_halo)) return 0;
   if (!c->nccl && !c->cb_halo) { g_fx_error = "halo exchange requested but no communicator (fx_comm_init) was set"; return FX_ERROR_RUNTIME; }
+  ClockScope cs(c, 2);
   if (h.n_export > 0)
     hipLaunchKernelGGL(k_halo_pack, dim3((h.n_export + 255) / 256), dim3(256), 0, c->stream, h.n_export, h.export_item, x,
                        h.sendbuf);
@@ -720,6 +762,7 @@ static inline const int32_t *gate_verify(fx_context *c) { return &c->st->need_ve
 static int spmv(fx_context *c, int mode, int dot, double *x, const double *b, double *y, const int32_t *gate,
                 int32_t gate_val) {
   if (halo_update(c, x)) return FX_ERROR_RUNTIME;
+  ClockScope cs(c, 0);
   const Bell &M = c->M;
   const int bs = c->spmv_bs;
   const dim3 g((M.nslices + bs / 64 - 1) / (bs / 64)), blk(bs);
@@ -1167,6 +1210,7 @@ static int spmv(fx_context *c, int mode, int dot, double *x, const double *b, do
 //   Z = 0; ZP = R; repeat { ZP <- M^-1 ZP; Z += ZP; ZP = R - A Z }.
 // The common iterPREmax = 1 case is the single fused sweep.
 static int precond_apply(fx_context *c, const double *r, double *z, bool want_dot, int *nparts) {
+  ClockScope cs(c, 1);
   if (c->iterpremax <= 1 || c->precond_kind == 0) return precond_apply_once(c, r, z, want_dot, nparts);
   *nparts = 0;  // r.z is taken by a separate dot afterwards
   int np;
@@ -1217,6 +1261,7 @@ static int poll_state(fx_context *c, KrylovState *out) {
   HIP_TRY(hipMemcpyAsync(herr, c->df_err, 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   *out = *c->st_host;
+  if (c->clock.on) clock_collect(c);
   if (*herr != 0) {
     (void)hipMemset(c->df_err, 0, 4);
     g_fx_error = "dataflow sweep: a bounded wait ran out (workgroups not co-resident, or a producer failed); FX_DATAFLOW=0 selects the launch-per-level sweeps";
@@ -1239,7 +1284,7 @@ static int krylov_begin(fx_context *c, int method, int maxit, double tol) {
   // auto: only the sweep-heavy preconditioners (40+ launches per iteration); measured at 98k DOF: CG + SSOR 293 -> 270 us,
   // BiCGSTAB + SSOR 562 -> 517 us per iteration, but CG + block-Jacobi (8 launches) 42.8 -> 45.1 us
   const bool sweepy = (c->precond_kind == 1 || c->precond_kind == 10);
-  c->k_graph = !multi_rank(c) && c->nranks <= 1 && c->halo.n_neighbor <= 0 &&
+  c->k_graph = !c->clock.on && !multi_rank(c) && c->nranks <= 1 && c->halo.n_neighbor <= 0 &&
                (c->graph_mode == 2 || (c->graph_mode == 1 && sweepy && c->ord.nslots <= c->graph_max_rows));
   if (krylov_init_state(c, maxit, tol)) return FX_ERROR_RUNTIME;
   HIP_TRY(hipMemsetAsync(c->W[2], 0, (size_t)c->wlen * 8, c->stream));  // P
@@ -1397,6 +1442,7 @@ extern "C" int fx_krylov_begin(fx_context *c, const int32_t *Iarray, const doubl
   if (!c->have_values || !c->precond_valid) { g_fx_error = "fx_krylov_begin: matrix / preconditioner not resident"; return FX_ERROR_RUNTIME; }
   if (Iarray[1] != 1 && Iarray[1] != 2) { g_fx_error = "METHOD must be 1 (CG) or 2 (BiCGSTAB)"; return FX_ERROR_INCONS_PC; }
   c->iterpremax = Iarray[4];
+  c->clock.on = false;  // the staged API is what bench.py times: no event pairs inside
   const int e = krylov_begin(c, Iarray[1], Iarray[0], Rarray[0]);
   if (e) return e;
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1467,6 +1513,9 @@ extern "C" int fx_solve_resident(fx_context *c, int32_t *Iarray, double *Rarray,
   int method = Iarray[1];
   const double tol = Rarray[0];
   c->iterpremax = iterpremax;
+  c->clock.on = Iarray[21] >= 1;  // TIMELOG
+  c->clock.used = 0;
+  c->clock.acc[0] = c->clock.acc[1] = c->clock.acc[2] = 0.0;
   int ret = 0, np;
   double t0 = now_s();
   // hecmw_solve_check_zerorhs (:242-278): warning 2002, X = 0, the solve continues
@@ -1599,6 +1648,12 @@ extern "C" int fx_solve_resident(fx_context *c, int32_t *Iarray, double *Rarray,
     info->resid = s.resid;
     info->rel_resid = resid2;
     info->time_setup = t_setup; info->time_sol = t_sol;
+    if (c->clock.on) {
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      clock_collect(c);
+      info->time_matvec = c->clock.acc[0]; info->time_precond = c->clock.acc[1]; info->time_comm = c->clock.acc[2];
+    }
+    c->clock.on = false;
     const int nh = std::max(0, std::min((int)hist_len, (int)s.n_hist));
     info->n_hist = hist ? nh : 0;
   }

@@ -167,6 +167,19 @@ struct NlDev {
   int latch = 0;  // MatlMatrix's saved `flag` (calMatMatrix.f90:39): set by the first elastoplastic stress update
 };
 
+// TIMELOG (hecmw_solver_Iterative.f90:192-208): device time of the three phases the reference reports -- solver/matvec
+// (hecmw_matvec_get_timer, comm excluded as las_33.f90:345-349 does), solver/precond (hecmw_precond_get_timer), solver/comm --
+// from HIP event pairs on the solver stream, collected whenever the host polls the Krylov state.  Off unless Iarray(22) >= 1.
+struct PhaseClock {
+  bool on = false;
+  std::vector<hipEvent_t> ev;   // pairs: start, stop
+  std::vector<int> kind;        // per pair: 0 matvec, 1 precond, 2 comm
+  int used = 0;                 // pairs recorded since the last collect
+  int open_kind[4] = {-1, -1, -1, -1};
+  int depth = 0;
+  double acc[3] = {0.0, 0.0, 0.0};  // seconds
+};
+
 struct fx_context {
   int device = 0;
   int n_cu = 256;  // compute units of the device
@@ -265,5 +278,6 @@ struct fx_context {
   const void *host_D = nullptr, *host_AL = nullptr, *host_AU = nullptr;  // the caller's arrays of the last value upload (fx_solve)
   // timing
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  PhaseClock clock;
 };
 

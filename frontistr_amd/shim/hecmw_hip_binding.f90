@@ -1,0 +1,260 @@
+!> Reference-side binding of libfistr_hip, common part: the C-ABI declarations of include/fistr_hip.h, the one device
+!> context of this MPI rank (the state the reference keeps in module `save` variables), the views of
+!> hecmwST_matrix / hecmwST_local_mesh (hecmw1/src/common/hecmw_util_f.F90:433-468, :298-310) and the TRANSPORT of a
+!> domain-decomposed run (`mpirun -np N fistr1`):
+!>
+!>   HECMW_GPU_TRANSPORT=rccl (default)  rank 0 makes the ncclUniqueId (fx_comm_unique_id), hecmw_bcast_C distributes it
+!>                                       over hecMESH%MPI_COMM, every rank calls fx_comm_init: halo exchange and dot-product
+!>                                       reductions then stay on the device (RCCL over xGMI, no host round trip);
+!>   HECMW_GPU_TRANSPORT=mpi             fx_comm_set_host_callbacks wired to the reference's own hecmw_update_m_R
+!>                                       (hecmw_comm_f.F90:816-841 -> hecmw_solve_send_recv_mm) and hecmw_allreduce_R
+!>                                       (:346-379): any MPI the reference was built with, no RCCL needed.
+!>
+!> Used by frontistr_amd/shim/hecmw_solver_hip.f90 (module hecmw_solver: hecmw_solve) and
+!> frontistr_amd/shim/hecmw_matvec_hip.f90 (hecmw_matvec).  INTEGRATION.md shows where a maintainer adds the three files.
+module hecmw_hip_binding
+  use iso_c_binding
+  use hecmw_util
+  implicit none
+  private
+  public :: fx_matrix_view, fx_comm_view, fx_solve_info
+  public :: fx_solve, fx_matvec, fx_last_error
+  public :: fxb_context, fxb_views, fxb_ensure_transport, fxb_error_text
+
+  type, bind(C) :: fx_matrix_view
+    integer(c_int32_t) :: N, NP, NPL, NPU, NDOF
+    type(c_ptr) :: indexL, itemL, indexU, itemU
+    type(c_ptr) :: D, AL, AU, B, X
+  end type fx_matrix_view
+
+  type, bind(C) :: fx_comm_view
+    integer(c_int32_t) :: my_rank, PETOT, nn_internal, n_node, n_neighbor_pe
+    type(c_ptr) :: neighbor_pe, import_index, import_item, export_index, export_item
+  end type fx_comm_view
+
+  type, bind(C) :: fx_solve_info
+    integer(c_int32_t) :: iterations, method, precond, ncolor, n_hist
+    real(c_double) :: resid, rel_resid, time_setup, time_sol, time_comm, time_matvec, time_precond
+  end type fx_solve_info
+
+  interface
+    integer(c_int) function fx_create(device, ctx) bind(C, name='fx_create')
+      import :: c_int, c_ptr
+      integer(c_int), value :: device
+      type(c_ptr) :: ctx
+    end function fx_create
+    integer(c_int) function fx_solve(ctx, mat, comm, Iarray, Rarray, info, hist, hist_len) bind(C, name='fx_solve')
+      import :: c_int, c_ptr, c_int32_t, c_double, fx_matrix_view, fx_comm_view, fx_solve_info
+      type(c_ptr), value :: ctx
+      type(fx_matrix_view) :: mat
+      type(fx_comm_view) :: comm
+      integer(c_int32_t) :: Iarray(100)
+      real(c_double) :: Rarray(100)
+      type(fx_solve_info) :: info
+      real(c_double) :: hist(*)
+      integer(c_int32_t), value :: hist_len
+    end function fx_solve
+    integer(c_int) function fx_matvec(ctx, mat, comm, x, y, commtime) bind(C, name='fx_matvec')
+      import :: c_int, c_ptr, c_double, fx_matrix_view, fx_comm_view
+      type(c_ptr), value :: ctx
+      type(fx_matrix_view) :: mat
+      type(fx_comm_view) :: comm
+      real(c_double) :: x(*), y(*)
+      real(c_double) :: commtime
+    end function fx_matvec
+    function fx_last_error() bind(C, name='fx_last_error') result(p)
+      import :: c_ptr
+      type(c_ptr) :: p
+    end function fx_last_error
+    integer(c_int) function fx_comm_unique_id(id) bind(C, name='fx_comm_unique_id')
+      import :: c_int, c_char
+      character(kind=c_char) :: id(128)
+    end function fx_comm_unique_id
+    integer(c_int) function fx_comm_init(ctx, id, rank, nranks) bind(C, name='fx_comm_init')
+      import :: c_int, c_ptr, c_char
+      type(c_ptr), value :: ctx
+      character(kind=c_char) :: id(128)
+      integer(c_int), value :: rank, nranks
+    end function fx_comm_init
+    integer(c_int) function fx_comm_set_host_callbacks(ctx, rank, nranks, halo, allreduce, user) &
+        bind(C, name='fx_comm_set_host_callbacks')
+      import :: c_int, c_ptr, c_funptr
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: rank, nranks
+      type(c_funptr), value :: halo, allreduce
+      type(c_ptr), value :: user
+    end function fx_comm_set_host_callbacks
+    function fxb_strlen(s) bind(C, name='strlen') result(n)
+      import :: c_ptr, c_size_t
+      type(c_ptr), value :: s
+      integer(c_size_t) :: n
+    end function fxb_strlen
+  end interface
+
+  type(c_ptr), save :: the_ctx = c_null_ptr
+  integer, save :: transport = 0              ! 0 none yet, 1 RCCL, 2 host callbacks through the reference's MPI layer
+  ! what the callbacks need: the mesh whose tables they serve and the block size of the vector in flight
+  type(hecmwST_local_mesh), pointer, save :: cb_mesh => null()
+  integer(kind=kint), save :: cb_ndof = 3
+
+contains
+
+  !> The device context of this rank, created on first use (device = local rank: fx_create(-1)).
+  function fxb_context(hecMESH) result(ctx)
+    type(hecmwST_local_mesh), intent(in) :: hecMESH
+    type(c_ptr) :: ctx
+    integer(c_int) :: ierr
+    if (.not. c_associated(the_ctx)) then
+      ierr = fx_create(-1_c_int, the_ctx)
+      if (ierr /= 0) then
+        write(*,'(a,a)') '#### libfistr_hip: cannot create a device context: ', trim(fxb_error_text())
+        call hecmw_abort(hecmw_comm_get_comm())
+      endif
+    endif
+    ctx = the_ctx
+  end function fxb_context
+
+  function fxb_error_text() result(msg)
+    character(len=512) :: msg
+    character(kind=c_char), pointer :: p(:)
+    type(c_ptr) :: cp
+    integer :: i, n
+    msg = ' '
+    cp = fx_last_error()
+    if (.not. c_associated(cp)) return
+    n = min(int(fxb_strlen(cp)), len(msg))
+    call c_f_pointer(cp, p, [n])
+    do i = 1, n
+      msg(i:i) = p(i)
+    enddo
+  end function fxb_error_text
+
+  !> Borrowed views: c_loc of the members, nothing is copied (the caller owns every array, m_fstr.f90:807-857).
+  subroutine fxb_views(hecMESH, hecMAT, mv, cv)
+    type(hecmwST_local_mesh), intent(in), target :: hecMESH
+    type(hecmwST_matrix), intent(in), target :: hecMAT
+    type(fx_matrix_view), intent(out) :: mv
+    type(fx_comm_view), intent(out) :: cv
+    mv%N = hecMAT%N; mv%NP = hecMAT%NP; mv%NPL = hecMAT%NPL; mv%NPU = hecMAT%NPU; mv%NDOF = hecMAT%NDOF
+    mv%indexL = c_loc(hecMAT%indexL(0)); mv%indexU = c_loc(hecMAT%indexU(0))
+    mv%itemL = c_null_ptr; mv%itemU = c_null_ptr; mv%AL = c_null_ptr; mv%AU = c_null_ptr
+    if (hecMAT%NPL > 0) then
+      mv%itemL = c_loc(hecMAT%itemL(1)); mv%AL = c_loc(hecMAT%AL(1))
+    endif
+    if (hecMAT%NPU > 0) then
+      mv%itemU = c_loc(hecMAT%itemU(1)); mv%AU = c_loc(hecMAT%AU(1))
+    endif
+    mv%D = c_loc(hecMAT%D(1)); mv%B = c_loc(hecMAT%B(1)); mv%X = c_loc(hecMAT%X(1))
+    cv%my_rank = hecMESH%my_rank; cv%PETOT = hecMESH%PETOT
+    cv%nn_internal = hecMESH%nn_internal; cv%n_node = hecMESH%n_node
+    cv%n_neighbor_pe = hecMESH%n_neighbor_pe
+    cv%neighbor_pe = c_null_ptr; cv%import_index = c_null_ptr; cv%import_item = c_null_ptr
+    cv%export_index = c_null_ptr; cv%export_item = c_null_ptr
+    if (hecMESH%n_neighbor_pe > 0) then
+      cv%neighbor_pe  = c_loc(hecMESH%neighbor_pe(1))
+      cv%import_index = c_loc(hecMESH%import_index(0)); cv%import_item = c_loc(hecMESH%import_item(1))
+      cv%export_index = c_loc(hecMESH%export_index(0)); cv%export_item = c_loc(hecMESH%export_item(1))
+    endif
+  end subroutine fxb_views
+
+  !> Establish the transport on the first call of a decomposed run (PETOT > 1, or a rank with neighbour tables); every
+  !> call refreshes what the callbacks serve.  Collective over hecMESH%MPI_COMM the first time (the id broadcast).
+  subroutine fxb_ensure_transport(hecMESH, ndof)
+    use m_hecmw_comm_f
+    type(hecmwST_local_mesh), intent(in), target :: hecMESH
+    integer(kind=kint), intent(in) :: ndof
+    character(kind=c_char) :: id(128)
+    character(len=1) :: idc(128)
+    character(len=16) :: env
+    integer :: elen, estat, i
+    integer(c_int) :: ierr
+    type(c_ptr) :: ctx
+    cb_mesh => hecMESH
+    cb_ndof = ndof
+    if (hecMESH%PETOT <= 1 .and. hecMESH%n_neighbor_pe <= 0) return
+    if (transport /= 0) return
+    ctx = fxb_context(hecMESH)
+    call get_environment_variable('HECMW_GPU_TRANSPORT', env, elen, estat)
+    if (estat == 0 .and. elen >= 3 .and. env(1:3) == 'mpi') then
+      ierr = fx_comm_set_host_callbacks(ctx, int(hecMESH%my_rank, c_int), int(hecMESH%PETOT, c_int), &
+                                        c_funloc(fxb_halo_cb), c_funloc(fxb_allreduce_cb), c_null_ptr)
+      transport = 2
+      if (hecMESH%my_rank == 0) write(*,'(a)') '### libfistr_hip: halo exchange and reductions through hecmw_update_m_R / hecmw_allreduce_R'
+    else
+      idc = ' '
+      if (hecMESH%my_rank == 0) then
+        ierr = fx_comm_unique_id(id)
+        if (ierr /= 0) then
+          write(*,'(a,a)') '#### libfistr_hip-E: cannot create an RCCL id (HECMW_GPU_TRANSPORT=mpi uses the MPI layer instead): ', &
+            trim(fxb_error_text())
+          call hecmw_abort(hecmw_comm_get_comm())
+        endif
+        do i = 1, 128
+          idc(i) = id(i)
+        enddo
+      endif
+      call hecmw_bcast_C(hecMESH, idc, 1, 128, 0)
+      do i = 1, 128
+        id(i) = idc(i)
+      enddo
+      ierr = fx_comm_init(ctx, id, int(hecMESH%my_rank, c_int), int(hecMESH%PETOT, c_int))
+      transport = 1
+      if (hecMESH%my_rank == 0 .and. ierr == 0) write(*,'(a,i0,a)') '### libfistr_hip: RCCL communicator over ', hecMESH%PETOT, ' rank(s)'
+    endif
+    if (ierr /= 0) then
+      write(*,'(a,a)') '#### libfistr_hip-E: transport set-up failed: ', trim(fxb_error_text())
+      call hecmw_abort(hecmw_comm_get_comm())
+    endif
+  end subroutine fxb_ensure_transport
+
+  !> fx_halo_fn: `send` holds cb_ndof * n_export doubles in export_item order, `recv` receives cb_ndof * n_import doubles in
+  !> import_item order.  The exchange itself is the reference's own hecmw_update_m_R on a nodal vector.
+  subroutine fxb_halo_cb(send, recv, user) bind(C)
+    use m_hecmw_comm_f
+    real(c_double) :: send(*), recv(*)
+    type(c_ptr), value :: user
+    real(kind=kreal), allocatable :: val(:)
+    integer(kind=kint) :: k, d, nd, np, ne, ni, node
+    if (.not. associated(cb_mesh)) return
+    nd = cb_ndof; np = cb_mesh%n_node
+    ne = cb_mesh%export_index(cb_mesh%n_neighbor_pe)
+    ni = cb_mesh%import_index(cb_mesh%n_neighbor_pe)
+    allocate(val(nd * np))
+    val = 0.d0
+    do k = 1, ne
+      node = cb_mesh%export_item(k)
+      do d = 1, nd
+        val(nd * (node - 1) + d) = send(nd * (k - 1) + d)
+      enddo
+    enddo
+    call hecmw_update_m_R(cb_mesh, val, np, nd)
+    do k = 1, ni
+      node = cb_mesh%import_item(k)
+      do d = 1, nd
+        recv(nd * (k - 1) + d) = val(nd * (node - 1) + d)
+      enddo
+    enddo
+    deallocate(val)
+  end subroutine fxb_halo_cb
+
+  !> fx_allreduce_fn: in-place SUM over the ranks (hecmw_allreduce_R, hecmw_comm_f.F90:346-379).
+  subroutine fxb_allreduce_cb(v, n, user) bind(C)
+    use m_hecmw_comm_f
+    real(c_double) :: v(*)
+    integer(c_int), value :: n
+    type(c_ptr), value :: user
+    real(kind=kreal), allocatable :: w(:)
+    integer(kind=kint) :: i
+    if (.not. associated(cb_mesh)) return
+    allocate(w(n))
+    do i = 1, n
+      w(i) = v(i)
+    enddo
+    call hecmw_allreduce_R(cb_mesh, w, int(n, kint), hecmw_sum)
+    do i = 1, n
+      v(i) = w(i)
+    enddo
+    deallocate(w)
+  end subroutine fxb_allreduce_cb
+
+end module hecmw_hip_binding

@@ -13,48 +13,8 @@
 !> GPU path abort unless HECMW_GPU_UNSUPPORTED=reference asks for the reference's CPU solver for them.
 module hecmw_solver
   use iso_c_binding
+  use hecmw_hip_binding
   implicit none
-
-  type, bind(C) :: fx_matrix_view
-    integer(c_int32_t) :: N, NP, NPL, NPU, NDOF
-    type(c_ptr) :: indexL, itemL, indexU, itemU
-    type(c_ptr) :: D, AL, AU, B, X
-  end type fx_matrix_view
-
-  type, bind(C) :: fx_comm_view
-    integer(c_int32_t) :: my_rank, PETOT, nn_internal, n_node, n_neighbor_pe
-    type(c_ptr) :: neighbor_pe, import_index, import_item, export_index, export_item
-  end type fx_comm_view
-
-  type, bind(C) :: fx_solve_info
-    integer(c_int32_t) :: iterations, method, precond, ncolor, n_hist
-    real(c_double) :: resid, rel_resid, time_setup, time_sol, time_comm, time_matvec, time_precond
-  end type fx_solve_info
-
-  interface
-    integer(c_int) function fx_create(device, ctx) bind(C, name='fx_create')
-      import :: c_int, c_ptr
-      integer(c_int), value :: device
-      type(c_ptr) :: ctx
-    end function fx_create
-    integer(c_int) function fx_solve(ctx, mat, comm, Iarray, Rarray, info, hist, hist_len) bind(C, name='fx_solve')
-      import :: c_int, c_ptr, c_int32_t, c_double, fx_matrix_view, fx_comm_view, fx_solve_info
-      type(c_ptr), value :: ctx
-      type(fx_matrix_view) :: mat
-      type(fx_comm_view) :: comm
-      integer(c_int32_t) :: Iarray(100)
-      real(c_double) :: Rarray(100)
-      type(fx_solve_info) :: info
-      real(c_double) :: hist(*)
-      integer(c_int32_t), value :: hist_len
-    end function fx_solve
-    function fx_last_error() bind(C, name='fx_last_error') result(p)
-      import :: c_ptr
-      type(c_ptr) :: p
-    end function fx_last_error
-  end interface
-
-  type(c_ptr), save, private :: fx_ctx = c_null_ptr
 
 contains
 
@@ -70,12 +30,15 @@ contains
     type(fx_matrix_view) :: mv
     type(fx_comm_view)   :: cv
     type(fx_solve_info)  :: info
+    type(c_ptr) :: ctx
     real(kind=kreal), allocatable, target :: hist(:)
-    integer(kind=kint) :: ierr, i, nhist, precond
+    integer(kind=kint) :: ierr, i, nhist, precond, iterlog, timelog, iterpremax
     character(len=8) :: env
     character(len=16) :: envu
+    character(len=16) :: msg_method, msg_precond
     logical :: on_gpu
     integer :: elen, estat
+    real(kind=kreal) :: TR
 
     ! Explicit opt-out: HECMW_GPU=0 keeps the reference's own CPU solver for every call, and says so.
     ! Configurations outside the GPU hot path -- other block sizes, direct solvers, MPC / contact matrices,
@@ -110,55 +73,78 @@ contains
       call hecmw_abort(hecmw_comm_get_comm())
     endif
 
-    if (.not. c_associated(fx_ctx)) then
-      ierr = fx_create(-1_c_int, fx_ctx)        ! device = LOCAL_RANK
-      if (ierr /= 0) then
-        write(*,*) '#### libfistr_hip: cannot create a device context'
-        call hecmw_abort(hecmw_comm_get_comm())
-      endif
-    endif
+    ctx = fxb_context(hecMESH)                          ! device = LOCAL_RANK, created on the first call
+    call fxb_ensure_transport(hecMESH, hecMAT%NDOF)     ! decomposed runs: RCCL communicator or the reference's MPI layer
+    call fxb_views(hecMESH, hecMAT, mv, cv)
 
-    mv%N = hecMAT%N; mv%NP = hecMAT%NP; mv%NPL = hecMAT%NPL; mv%NPU = hecMAT%NPU; mv%NDOF = hecMAT%NDOF
-    mv%indexL = c_loc(hecMAT%indexL(0)); mv%itemL = c_loc(hecMAT%itemL(1))
-    mv%indexU = c_loc(hecMAT%indexU(0)); mv%itemU = c_loc(hecMAT%itemU(1))
-    mv%D = c_loc(hecMAT%D(1)); mv%AL = c_loc(hecMAT%AL(1)); mv%AU = c_loc(hecMAT%AU(1))
-    mv%B = c_loc(hecMAT%B(1)); mv%X = c_loc(hecMAT%X(1))
-
-    cv%my_rank = hecMESH%my_rank; cv%PETOT = hecMESH%PETOT
-    cv%nn_internal = hecMESH%nn_internal; cv%n_node = hecMESH%n_node
-    cv%n_neighbor_pe = hecMESH%n_neighbor_pe
-    cv%neighbor_pe = c_null_ptr; cv%import_index = c_null_ptr; cv%import_item = c_null_ptr
-    cv%export_index = c_null_ptr; cv%export_item = c_null_ptr
-    if (hecMESH%n_neighbor_pe > 0) then
-      cv%neighbor_pe  = c_loc(hecMESH%neighbor_pe(1))
-      cv%import_index = c_loc(hecMESH%import_index(0)); cv%import_item = c_loc(hecMESH%import_item(1))
-      cv%export_index = c_loc(hecMESH%export_index(0)); cv%export_item = c_loc(hecMESH%export_item(1))
+    ! the reference's stdout channel, line for line: banner before the solve (hecmw_solve_iterative_printmsg,
+    ! hecmw_solver_Iterative.f90:380-421), ITERLOG lines (hecmw_solver_CG.f90:245), '### Relative residual' (:168),
+    ! the TIMELOG summary (:192-208)
+    iterlog = hecmw_mat_get_iterlog(hecMAT)
+    timelog = hecmw_mat_get_timelog(hecMAT)
+    iterpremax = hecmw_mat_get_iterpremax(hecMAT)
+    select case (hecmw_mat_get_method(hecMAT))
+      case (1); msg_method = 'CG'
+      case (2); msg_method = 'BiCGSTAB'
+      case (3); msg_method = 'GMRES'
+      case (4); msg_method = 'GPBiCG'
+      case default; msg_method = 'Unlabeled'
+    end select
+    select case (precond)
+      case (1, 2); msg_precond = 'SSOR'
+      case (3); msg_precond = 'DIAG'
+      case (10, 11, 12); write(msg_precond, '(a,i0,a)') 'ILU(', precond - 10, ')'
+      case default; msg_precond = 'Unlabeled'
+    end select
+    if (hecMESH%my_rank == 0 .and. (iterlog == 1 .or. timelog >= 1)) then
+      write (*,'(a,i0,a,i0,a,a,a,a,a,i0)') '### ', hecMAT%NDOF, 'x', hecMAT%NDOF, ' BLOCK ', &
+        &   trim(msg_method), ', ', trim(msg_precond), ', ', iterpremax
     endif
 
     nhist = max(hecmw_mat_get_iter(hecMAT), 1) + 1   ! GMRES logs MAXIT+1 lines when it runs out
     allocate(hist(nhist))
-    ierr = fx_solve(fx_ctx, mv, cv, hecMAT%Iarray, hecMAT%Rarray, info, hist, int(nhist, c_int32_t))
+    ierr = fx_solve(ctx, mv, cv, hecMAT%Iarray, hecMAT%Rarray, info, hist, int(nhist, c_int32_t))
 
-    ! the reference's stdout channel (hecmw_solver_Iterative.f90:418-419, hecmw_solver_CG.f90:245, :168)
-    if (hecMESH%my_rank == 0 .and. (hecMAT%Iarray(21) == 1 .or. hecMAT%Iarray(22) >= 1)) then
-      write(*,'(a,i0,a,i0,a,i0,a,i0,a,i0)') '### ', hecMAT%NDOF, 'x', hecMAT%NDOF, ' BLOCK (libfistr_hip) METHOD ', &
-        info%method, ', PRECOND ', info%precond, ', ', hecMAT%Iarray(5)
+    if (info%method /= hecmw_mat_get_method(hecMAT) .and. ierr >= 0) then   ! METHOD2 took over: the reference prints a second banner
+      select case (info%method)
+        case (2); msg_method = 'BiCGSTAB'
+        case (3); msg_method = 'GMRES'
+        case (4); msg_method = 'GPBiCG'
+      end select
+      if (hecMESH%my_rank == 0 .and. (iterlog == 1 .or. timelog >= 1)) then
+        write (*,'(a,i0,a,i0,a,a,a,a,a,i0)') '### ', hecMAT%NDOF, 'x', hecMAT%NDOF, ' BLOCK ', &
+          &   trim(msg_method), ', ', trim(msg_precond), ', ', iterpremax
+      endif
     endif
-    if (hecMESH%my_rank == 0 .and. hecMAT%Iarray(21) == 1) then
+    if (hecMESH%my_rank == 0 .and. iterlog == 1) then
       do i = 1, info%n_hist
         write(*,'(i7, 1pe16.6)') i, hist(i)
       enddo
     endif
-    if (hecMESH%my_rank == 0 .and. (hecMAT%Iarray(21) == 1 .or. hecMAT%Iarray(22) >= 1)) then
-      write(*,"(a,1pe12.5)") '### Relative residual =', info%rel_resid
-    endif
     deallocate(hist)
 
     if (ierr < 0) then
-      write(*,*) '#### libfistr_hip runtime failure'
+      write(*,'(a,a)') '#### libfistr_hip runtime failure: ', trim(fxb_error_text())
       call hecmw_abort(hecmw_comm_get_comm())
     else if (ierr /= 0) then
       call hecmw_solve_error(hecMESH, ierr)     ! E-codes abort, W-codes warn (hecmw_solve_error.f90)
+    endif
+
+    if (hecMESH%my_rank == 0 .and. (iterlog == 1 .or. timelog >= 1)) then
+      write(*,"(a,1pe12.5)") '### Relative residual =', info%rel_resid
+    endif
+    if (hecMESH%my_rank == 0 .and. timelog >= 1) then
+      TR = (info%time_sol - info%time_comm) / (info%time_sol + 1.d-24) * 100.d0
+      write (*,'(/a)')          '### summary of linear solver'
+      write (*,'(i10,a, 1pe16.6)')      info%iterations, ' iterations  ', info%resid
+      write (*,'(a, 1pe16.6 )') '    set-up time      : ', info%time_setup
+      write (*,'(a, 1pe16.6 )') '    solver time      : ', info%time_sol
+      write (*,'(a, 1pe16.6 )') '    solver/comm time : ', info%time_comm
+      write (*,'(a, 1pe16.6 )') '    solver/matvec    : ', info%time_matvec
+      write (*,'(a, 1pe16.6 )') '    solver/precond   : ', info%time_precond
+      if (info%iterations > 0) &
+        write (*,'(a, 1pe16.6 )') '    solver/1 iter    : ', info%time_sol / info%iterations
+      write (*,'(a, 1pe16.6/)') '    work ratio (%)   : ', TR
     endif
   end subroutine hecmw_solve
 

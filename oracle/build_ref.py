@@ -291,12 +291,35 @@ def main():
     # Integration check of the drop-in boundary: the SAME driver, but `hecmw_solve` now comes from
     # frontistr_amd/shim/hecmw_solver_hip.f90 (module hecmw_solver) -> libfistr_hip.so.  The reference's
     # derived types and every other module are the reference's own objects.
-    shim = os.path.join(os.path.dirname(HERE), "frontistr_amd", "shim", "hecmw_solver_hip.f90")
+    shimdir = os.path.join(os.path.dirname(HERE), "frontistr_amd", "shim")
+    shim = os.path.join(shimdir, "hecmw_solver_hip.f90")
     hiplib = os.path.join(os.path.dirname(HERE), "frontistr_amd", "libfistr_hip.so")
     if a.only in (None, "shim") and os.path.exists(shim) and os.path.exists(hiplib):
-        build_variant("shim", [solve], False, a.jobs, provides, uses, overrides={"hecmw_solver": shim},
-                      defines=("USE_SHIM",), exe_name="shim_solve",
-                      extra_link=(hiplib, "-Wl,-rpath," + os.path.dirname(hiplib), "-Wl,-rpath,/opt/rocm/lib"))
+        # hecmw_matvec: the four-line patch of INTEGRATION.md section 2 applied to a SCRATCH copy of the reference's
+        # hecmw_solver_las.f90 (build intermediate under oracle/_ref/, removed after the compile; never committed)
+        gen = os.path.join(OUT, "gen_shim")
+        os.makedirs(gen, exist_ok=True)
+        las = os.path.join(gen, "hecmw_solver_las.f90")
+        with open(os.path.join(REF, "hecmw1/src/solver/las/hecmw_solver_las.f90")) as fh:
+            src = fh.read()
+        use_anchor = "  use hecmw_solver_las_nn\n"
+        body_anchor = "    select case(hecMAT%NDOF)\n      case (3)\n        call hecmw_matvec_33(hecMESH, hecMAT, X, Y, time_Ax, COMMtime)"
+        assert src.count(use_anchor) >= 1 and src.count(body_anchor) == 1, "hecmw_solver_las.f90 changed: update the patch"
+        src = src.replace(use_anchor, use_anchor + "  use hecmw_matvec_hip\n", 1)
+        src = src.replace(body_anchor, "    if (hecmw_matvec_hip_enabled(hecMAT)) then\n"
+                                       "      call hecmw_matvec_on_gpu(hecMESH, hecMAT, X, Y, COMMtime); return\n"
+                                       "    endif\n" + body_anchor, 1)
+        with open(las, "w") as fh:
+            fh.write(src)
+        try:
+            build_variant("shim", [solve], False, a.jobs, provides, uses,
+                          overrides={"hecmw_solver": shim, "hecmw_hip_binding": os.path.join(shimdir, "hecmw_hip_binding.f90"),
+                                     "hecmw_matvec_hip": os.path.join(shimdir, "hecmw_matvec_hip.f90"), "hecmw_solver_las": las},
+                          defines=("USE_SHIM",), exe_name="shim_solve",
+                          extra_link=(hiplib, "-Wl,-rpath," + os.path.dirname(hiplib), "-Wl,-rpath,/opt/rocm/lib"))
+        finally:
+            os.remove(las)
+            os.rmdir(gen)
     return 0
 
 

@@ -13,6 +13,8 @@
 !>   int32  Iarray(100);  real64 Rarray(100)
 !>   int32  indexL(0:NP) indexU(0:NP) itemL(NPL) itemU(NPU)
 !>   real64 D(9NP) AL(9NPL) AU(9NPU) B(3NP) X(3NP)
+!>   optional (a subdomain with halo tables, hecmw_util_f.F90:298-310):
+!>   int32  n_neighbor_pe PETOT my_rank; neighbor_pe(n) import_index(0:n) export_index(0:n) import_item(*) export_item(*)
 !> out.bin: int32 Iarray(100); real64 Rarray(100); real64 X(3NP) (mode 2/3: Y/Z)
 !>          real64 t_total
 program ref_solve
@@ -29,7 +31,7 @@ program ref_solve
   type(hecmwST_local_mesh) :: hecMESH
   type(hecmwST_matrix)     :: hecMAT
   character(len=1024) :: fin, fout
-  integer(kind=4) :: magic, mode, N, NP, NPL, NPU, nrepeat, u, irep, nd
+  integer(kind=4) :: magic, mode, N, NP, NPL, NPU, nrepeat, u, irep, nd, nnb, petot, myrank, ios
   integer(kind=4) :: Iarr(100)
   real(kind=8)    :: Rarr(100), t0, t1, tcomm
   real(kind=8), allocatable :: Y(:), WK(:), X0(:)
@@ -64,16 +66,30 @@ program ref_solve
   read(u) hecMAT%AU
   read(u) hecMAT%B
   read(u) hecMAT%X
-  close(u)
 
   hecMESH%zero = 0; hecMESH%MPI_COMM = 0; hecMESH%PETOT = 1; hecMESH%PEsmpTOT = 1
   hecMESH%my_rank = 0; hecMESH%n_subdomain = 1; hecMESH%n_neighbor_pe = 0
   hecMESH%n_node = NP; hecMESH%nn_internal = N; hecMESH%n_dof = nd
   hecMESH%nn_middle = NP
   hecMESH%mpc%n_mpc = 0
-  allocate(hecMESH%neighbor_pe(0), hecMESH%import_index(0:0), hecMESH%export_index(0:0))
-  allocate(hecMESH%import_item(0), hecMESH%export_item(0))
-  hecMESH%import_index(0) = 0; hecMESH%export_index(0) = 0
+  nnb = 0
+  read(u, iostat=ios) nnb, petot, myrank
+  if (ios /= 0) nnb = 0
+  if (nnb > 0) then
+    hecMESH%n_neighbor_pe = nnb; hecMESH%PETOT = petot; hecMESH%my_rank = myrank
+    allocate(hecMESH%neighbor_pe(nnb), hecMESH%import_index(0:nnb), hecMESH%export_index(0:nnb))
+    read(u) hecMESH%neighbor_pe
+    read(u) hecMESH%import_index
+    read(u) hecMESH%export_index
+    allocate(hecMESH%import_item(hecMESH%import_index(nnb)), hecMESH%export_item(hecMESH%export_index(nnb)))
+    read(u) hecMESH%import_item
+    read(u) hecMESH%export_item
+  else
+    allocate(hecMESH%neighbor_pe(0), hecMESH%import_index(0:0), hecMESH%export_index(0:0))
+    allocate(hecMESH%import_item(0), hecMESH%export_item(0))
+    hecMESH%import_index(0) = 0; hecMESH%export_index(0) = 0
+  endif
+  close(u)
 
   allocate(Y(nd*NP), WK(nd*NP), X0(nd*NP))
   X0 = hecMAT%X
@@ -112,7 +128,7 @@ program ref_solve
     do irep = 1, max(nrepeat, 1)
       call hecmw_matvec(hecMESH, hecMAT, hecMAT%X, Y, tcomm)
     enddo
-    Y(nd*N+1:) = 0.d0
+    Y(nd*N+1:) = hecMAT%X(nd*N+1:)     ! the halo part of X after the update, in the unused tail of Y
   case (3)
     tcomm = 0.d0
     call hecmw_precond_setup(hecMAT, hecMESH, 1)

@@ -81,7 +81,7 @@ def default_params(method=1, precond=3, maxit=10000, tol=1e-8, iterlog=1, timelo
     return I, R
 
 
-def write_system(path, mode, m, I, R, nrepeat=1):
+def write_system(path, mode, m, I, R, nrepeat=1, comm=None):
     with open(path, "wb") as f:
         ndof = int(getattr(m, "NDOF", 3))
         np.array([MAGIC_SOLVE, mode + (100 * ndof if ndof != 3 else 0), m.N, m.NP, m.NPL, m.NPU, nrepeat], dtype=np.int32).tofile(f)
@@ -91,6 +91,11 @@ def write_system(path, mode, m, I, R, nrepeat=1):
             a.astype(np.int32).tofile(f)
         for a in (m.D, m.AL, m.AU, m.B, m.X):
             a.astype(np.float64).tofile(f)
+        if comm is not None:      # halo tables of a subdomain: dict(PETOT, my_rank, neighbor_pe, import_index, export_index, import_item, export_item)
+            nb = np.asarray(comm["neighbor_pe"], dtype=np.int32)
+            np.array([nb.size, comm.get("PETOT", 1), comm.get("my_rank", 0)], dtype=np.int32).tofile(f)
+            for k in ("neighbor_pe", "import_index", "export_index", "import_item", "export_item"):
+                np.asarray(comm[k], dtype=np.int32).tofile(f)
 
 
 HIST_RE = re.compile(r"^\s*(\d+)\s+([0-9.]+E[+-]\d+)\s*$")
@@ -131,7 +136,7 @@ def parse_stdout(text):
     return info
 
 
-def run_solve(m, I, R, mode=1, threads=1, nrepeat=1, workdir=None, timeout=None, exe_name=None, extra_env=None):
+def run_solve(m, I, R, mode=1, threads=1, nrepeat=1, workdir=None, timeout=None, exe_name=None, extra_env=None, comm=None):
     """Run the reference.  threads==1 -> serial build (natural-order SSOR);
     threads>=2 -> OpenMP build (RCM + multicolour SSOR)."""
     exe = os.path.join(REFDIR, exe_name or ("ref_solve_omp" if threads > 1 else "ref_solve"))
@@ -139,7 +144,7 @@ def run_solve(m, I, R, mode=1, threads=1, nrepeat=1, workdir=None, timeout=None,
         raise FileNotFoundError(exe + " (run python oracle/build_ref.py where /root/reference exists)")
     with tempfile.TemporaryDirectory(dir=workdir) as td:
         fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
-        write_system(fin, mode, m, I, R, nrepeat)
+        write_system(fin, mode, m, I, R, nrepeat, comm)
         env = dict(os.environ)
         env["OMP_NUM_THREADS"] = str(threads)
         if extra_env:
