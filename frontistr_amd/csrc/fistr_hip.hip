@@ -214,6 +214,13 @@ static int context_init(fx_context *c) {
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
+  {  // the exchange must not queue behind the interior rows it overlaps with: highest priority the device offers
+    int lo = 0, hi = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIP_TRY(hipStreamCreateWithPriority(&c->comm_stream, hipStreamNonBlocking, hi));
+  }
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
   if (dev_alloc(&c->st, 1) || dev_alloc(&c->red_out, 16) || dev_alloc(&c->df_err, 4)) return FX_ERROR_RUNTIME;
   HIP_TRY(hipMemset(c->df_err, 0, 16));
   HIP_TRY(hipHostMalloc((void **)&c->st_host, sizeof(KrylovState) * 4, hipHostMallocDefault));
@@ -248,6 +255,7 @@ extern "C" int fx_create(int device, fx_context **out) {
   if (const char *e = getenv("FX_SPMV_BS")) c->spmv_bs = (atoi(e) == 64) ? 64 : 256;
   if (const char *e = getenv("FX_SPMV_SPATIAL")) c->spmv_spatial = atoi(e) != 0;
   if (const char *e = getenv("FX_GRAPH")) c->graph_mode = atoi(e);
+  if (const char *e = getenv("FX_OVERLAP")) c->overlap = atoi(e) != 0;
   if (const char *e = getenv("FX_SPLIT_MAX_SLICES")) c->split_max_slices = atoi(e);
   if (const char *e = getenv("FX_DATAFLOW")) c->df_mode = atoi(e);
   if (const char *e = getenv("FX_DF_GRID")) c->df_grid = atoi(e);
@@ -261,6 +269,7 @@ extern "C" int fx_create(int device, fx_context **out) {
 
 static void bell_free(Bell &b) {
   dev_free(b.pair_ptr); dev_free(b.val2_base); dev_free(b.col2); dev_free(b.slot_row); dev_free(b.src2); dev_free(b.slice_order);
+  dev_free(b.wg_interior); dev_free(b.wg_boundary);
   b.val2 = nullptr;
   b = Bell();
 }
@@ -316,6 +325,9 @@ extern "C" void fx_destroy(fx_context *c) {
   if (c->h_recv) (void)hipHostFree(c->h_recv);
   if (c->nccl && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)c->nccl);
   for (hipEvent_t e : c->clock.ev) (void)hipEventDestroy(e);
+  if (c->comm_stream) { (void)hipStreamSynchronize(c->comm_stream); (void)hipStreamDestroy(c->comm_stream); }
+  if (c->ev_packed) (void)hipEventDestroy(c->ev_packed);
+  if (c->ev_halo) (void)hipEventDestroy(c->ev_halo);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -488,6 +500,32 @@ static int build_full_bell(fx_context *c) {
     std::stable_sort(ordv.begin(), ordv.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
     if (dev_alloc(&c->M.slice_order, (size_t)nsl)) return FX_ERROR_RUNTIME;
     HIP_TRY(hipMemcpy(c->M.slice_order, ordv.data(), (size_t)nsl * 4, hipMemcpyHostToDevice));
+  }
+  if (c->halo.n_neighbor > 0) {  // interior / boundary split of the SpMV's virtual workgroups (4 slices of the walk each)
+    const int32_t nsl = c->M.nslices, N = c->A.N;
+    std::vector<int32_t> walk((size_t)nsl);
+    if (c->M.slice_order) HIP_TRY(hipMemcpy(walk.data(), c->M.slice_order, (size_t)nsl * 4, hipMemcpyDeviceToHost));
+    else for (int32_t i = 0; i < nsl; i++) walk[i] = i;
+    std::vector<uint8_t> bnd((size_t)nsl, 0);
+    parallel_for(nsl, [&](int64_t a, int64_t b) {
+      for (int64_t sl = a; sl < b; sl++)
+        for (int l = 0; l < 64; l++) {
+          const int32_t r = sr[(size_t)sl * 64 + l];
+          if (r >= 0 && iU[r + 1] > iU[r] && jU[iU[r + 1] - 1] > N) { bnd[sl] = 1; break; }  // itemU ascending: halo ids (> N) come last
+        }
+    });
+    const int spb = c->spmv_bs / 64;
+    const int32_t nwg = (nsl + spb - 1) / spb;
+    std::vector<int32_t> wi, wb;
+    for (int32_t w = 0; w < nwg; w++) {
+      bool b = false;
+      for (int k = 0; k < spb && (int64_t)w * spb + k < nsl; k++) b |= bnd[walk[(size_t)w * spb + k]] != 0;
+      (b ? wb : wi).push_back(w);
+    }
+    c->M.n_wg_interior = (int32_t)wi.size(); c->M.n_wg_boundary = (int32_t)wb.size();
+    if (dev_alloc(&c->M.wg_interior, wi.size()) || dev_alloc(&c->M.wg_boundary, wb.size())) return FX_ERROR_RUNTIME;
+    if (!wi.empty()) HIP_TRY(hipMemcpy(c->M.wg_interior, wi.data(), wi.size() * 4, hipMemcpyHostToDevice));
+    if (!wb.empty()) HIP_TRY(hipMemcpy(c->M.wg_boundary, wb.data(), wb.size() * 4, hipMemcpyHostToDevice));
   }
   c->m_symbolic = true;
   c->bell_valid = false;
@@ -707,49 +745,73 @@ static int allreduce_dev(fx_context *c, double *v, int n) {
   return 0;
 }
 
-// hecmw_update_3_R (hecmw_comm_f.F90:669-694): persistent device buffers, one grouped
-// send/recv per neighbour, all on the solver stream (no host synchronisation).
-static int halo_update(fx_context *c, double *x) {
-  HaloDev &h = c->halo;
+// hecmw_update_3_R (hecmw_comm_f.F90:669-694): persistent device buffers, one grouped send/recv per neighbour, no host
+// synchronisation with RCCL.  Two halves so that the SpMV can multiply its interior rows in between:
+//   halo_pack:     pack on the solver stream, comm_stream ordered after it by an event;
+//   halo_exchange: the transfer + unpack on comm_stream (RCCL: enqueued; host callbacks: the host blocks on comm_stream only,
+//                  so whatever was queued on the solver stream before -- the interior rows -- runs meanwhile);
+//   halo_end:      the solver stream waits for the unpack.
+// halo_update = the three back to back.
+static inline bool halo_active(const fx_context *c) {
   // one rank WITH a communicator and a neighbour table exchanges with itself (periodic tables; tests use it to drive the
   // grouped ncclSend/ncclRecv on a single GPU)
-  if (h.n_neighbor <= 0 || (c->nranks <= 1 && !c->nccl && !c->cb_halo)) return 0;
+  return c->halo.n_neighbor > 0 && !(c->nranks <= 1 && !c->nccl && !c->cb_halo);
+}
+
+static int halo_pack(fx_context *c, double *x) {
+  HaloDev &h = c->halo;
+  if (!halo_active(c)) return 0;
   if (!c->nccl && !c->cb_halo) { g_fx_error = "halo exchange requested but no communicator (fx_comm_init) was set"; return FX_ERROR_RUNTIME; }
-  ClockScope cs(c, 2);
   if (h.n_export > 0)
     hipLaunchKernelGGL(k_halo_pack, dim3((h.n_export + 255) / 256), dim3(256), 0, c->stream, h.n_export, h.export_item, x,
                        h.sendbuf);
-  if (!c->nccl) {  // host-staged transport
+  HIP_TRY(hipEventRecord(c->ev_packed, c->stream));
+  HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_packed, 0));
+  return 0;
+}
+
+static int halo_exchange(fx_context *c, double *x) {  // after halo_pack; everything on comm_stream
+  HaloDev &h = c->halo;
+  if (!halo_active(c)) return 0;
+  hipStream_t cs = c->comm_stream;
+  if (!c->nccl) {  // host-staged transport: the host blocks on comm_stream only; what is queued on the solver stream keeps running
     if (!c->h_send) {
       HIP_TRY(hipHostMalloc((void **)&c->h_send, (size_t)3 * std::max(h.n_export, 1) * 8, hipHostMallocDefault));
       HIP_TRY(hipHostMalloc((void **)&c->h_recv, (size_t)3 * std::max(h.n_import, 1) * 8, hipHostMallocDefault));
     }
-    HIP_TRY(hipMemcpyAsync(c->h_send, h.sendbuf, (size_t)3 * h.n_export * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_send, h.sendbuf, (size_t)3 * h.n_export * 8, hipMemcpyDeviceToHost, cs));
+    HIP_TRY(hipStreamSynchronize(cs));
     c->cb_halo(c->h_send, c->h_recv, c->cb_user);
-    HIP_TRY(hipMemcpyAsync(h.recvbuf, c->h_recv, (size_t)3 * h.n_import * 8, hipMemcpyHostToDevice, c->stream));
-    if (h.n_import > 0)
-      hipLaunchKernelGGL(k_halo_unpack, dim3((h.n_import + 255) / 256), dim3(256), 0, c->stream, h.n_import, h.import_item,
-                         h.recvbuf, x);
-    HIP_TRY(hipGetLastError());
-    return 0;
+    HIP_TRY(hipMemcpyAsync(h.recvbuf, c->h_recv, (size_t)3 * h.n_import * 8, hipMemcpyHostToDevice, cs));
+  } else {
+    NCCL_TRY(g_rccl.GroupStart());
+    for (int k = 0; k < h.n_neighbor; k++) {
+      const int32_t ns = h.export_index[k + 1] - h.export_index[k], nr = h.import_index[k + 1] - h.import_index[k];
+      if (ns > 0)
+        NCCL_TRY(g_rccl.Send(h.sendbuf + (size_t)3 * h.export_index[k], (size_t)3 * ns, ncclDouble, h.neighbor[k], (ncclComm_t)c->nccl, cs));
+      if (nr > 0)
+        NCCL_TRY(g_rccl.Recv(h.recvbuf + (size_t)3 * h.import_index[k], (size_t)3 * nr, ncclDouble, h.neighbor[k], (ncclComm_t)c->nccl, cs));
+    }
+    NCCL_TRY(g_rccl.GroupEnd());
   }
-  NCCL_TRY(g_rccl.GroupStart());
-  for (int k = 0; k < h.n_neighbor; k++) {
-    const int32_t ns = h.export_index[k + 1] - h.export_index[k], nr = h.import_index[k + 1] - h.import_index[k];
-    if (ns > 0)
-      NCCL_TRY(g_rccl.Send(h.sendbuf + (size_t)3 * h.export_index[k], (size_t)3 * ns, ncclDouble, h.neighbor[k], (ncclComm_t)c->nccl,
-                        c->stream));
-    if (nr > 0)
-      NCCL_TRY(g_rccl.Recv(h.recvbuf + (size_t)3 * h.import_index[k], (size_t)3 * nr, ncclDouble, h.neighbor[k], (ncclComm_t)c->nccl,
-                        c->stream));
-  }
-  NCCL_TRY(g_rccl.GroupEnd());
   if (h.n_import > 0)
-    hipLaunchKernelGGL(k_halo_unpack, dim3((h.n_import + 255) / 256), dim3(256), 0, c->stream, h.n_import, h.import_item,
-                       h.recvbuf, x);
+    hipLaunchKernelGGL(k_halo_unpack, dim3((h.n_import + 255) / 256), dim3(256), 0, cs, h.n_import, h.import_item, h.recvbuf, x);
   HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(c->ev_halo, cs));
   return 0;
+}
+
+static int halo_end(fx_context *c) {
+  if (!halo_active(c)) return 0;
+  HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
+  return 0;
+}
+
+static int halo_update(fx_context *c, double *x) {
+  if (!halo_active(c)) return 0;
+  ClockScope cs(c, 2);
+  if (halo_pack(c, x) || halo_exchange(c, x)) return FX_ERROR_RUNTIME;
+  return halo_end(c);
 }
 
 // ---------------------------------------------------------------------------
@@ -758,18 +820,20 @@ static int halo_update(fx_context *c, double *x) {
 static inline const int32_t *gate_status(fx_context *c) { return &c->st->status; }
 static inline const int32_t *gate_verify(fx_context *c) { return &c->st->need_verify; }
 
-// y = A x (mode 0) or y = b - A x (mode 1), optional fused dot partial (dot 1: x.y, 2: y.y)
-static int spmv(fx_context *c, int mode, int dot, double *x, const double *b, double *y, const int32_t *gate,
-                int32_t gate_val) {
-  if (halo_update(c, x)) return FX_ERROR_RUNTIME;
-  ClockScope cs(c, 0);
+// y = A x (mode 0) or y = b - A x (mode 1), optional fused dot partial (dot 1: x.y, 2: y.y).
+// Domain-decomposed systems (FX_OVERLAP, default on): the interior virtual workgroups are launched while the halo exchange
+// is in flight on comm_stream, the boundary ones after it -- same workgroup -> slices -> partial-slot mapping as the single
+// launch, so y and the dot partials are bit-identical to it.
+static int spmv_launch(fx_context *c, int mode, int dot, double *x, const double *b, double *y, const int32_t *gate,
+                       int32_t gate_val, const int32_t *wg_list, int nwg) {
   const Bell &M = c->M;
   const int bs = c->spmv_bs;
-  const dim3 g((M.nslices + bs / 64 - 1) / (bs / 64)), blk(bs);
+  const dim3 g(nwg), blk(bs);
   double *part = c->partials;
+  if (nwg <= 0) return 0;
 #define SPMV_LAUNCH3(MODE, DOT, PIPE, B)                                                                              \
   hipLaunchKernelGGL((k_spmv<MODE, DOT, PIPE, B>), g, blk, 0, c->stream, M.nslices, c->ord.nslots, M.pair_ptr, M.val2, \
-                     M.col2, x, b, y, part, gate, gate_val, M.slice_order)
+                     M.col2, x, b, y, part, gate, gate_val, M.slice_order, wg_list)
 #define SPMV_LAUNCH(MODE, DOT)                                     \
   do {                                                             \
     if (c->pipe_spmv) {                                            \
@@ -789,6 +853,27 @@ static int spmv(fx_context *c, int mode, int dot, double *x, const double *b, do
 #undef SPMV_LAUNCH3
   HIP_TRY(hipGetLastError());
   return 0;
+}
+
+static inline int spmv_nparts(fx_context *c);
+static int spmv(fx_context *c, int mode, int dot, double *x, const double *b, double *y, const int32_t *gate,
+                int32_t gate_val) {
+  const Bell &M = c->M;
+  const int nwg = spmv_nparts(c);
+  if (c->overlap && halo_active(c) && M.wg_interior && M.n_wg_interior > 0) {
+    if (halo_pack(c, x)) return FX_ERROR_RUNTIME;
+    {
+      ClockScope cs(c, 0);
+      if (spmv_launch(c, mode, dot, x, b, y, gate, gate_val, M.wg_interior, M.n_wg_interior)) return FX_ERROR_RUNTIME;
+    }
+    if (halo_exchange(c, x)) return FX_ERROR_RUNTIME;  // in flight beside the interior rows
+    { ClockScope cs(c, 2); if (halo_end(c)) return FX_ERROR_RUNTIME; }  // what the solver stream still waits for = exposed comm time
+    ClockScope cs(c, 0);
+    return spmv_launch(c, mode, dot, x, b, y, gate, gate_val, M.wg_boundary, M.n_wg_boundary);
+  }
+  if (halo_update(c, x)) return FX_ERROR_RUNTIME;
+  ClockScope cs(c, 0);
+  return spmv_launch(c, mode, dot, x, b, y, gate, gate_val, nullptr, nwg);
 }
 static inline int spmv_nparts(fx_context *c) { return (c->M.nslices + c->spmv_bs / 64 - 1) / (c->spmv_bs / 64); }
 
@@ -870,6 +955,11 @@ static int ssor_setup_symbolic(fx_context *c, int ncolor_in) {
           rows.assign(perm0.begin() + cidx[col], perm0.begin() + cidx[col + 1]);
           std::sort(rows.begin(), rows.end());
           std::stable_sort(rows.begin(), rows.end(), [&](int32_t a, int32_t b) { return nlow[a] < nlow[b]; });
+          if (c->halo.n_neighbor > 0)  // subdomain: rows with a halo column last, so that they share few slices (interior / boundary split of the SpMV)
+            std::stable_sort(rows.begin(), rows.end(), [&](int32_t a, int32_t b) {
+              const bool ha = iU[a + 1] > iU[a] && jU[iU[a + 1] - 1] > N, hb = iU[b + 1] > iU[b] && jU[iU[b + 1] - 1] > N;
+              return ha < hb;
+            });
         }
       });
     for (auto &t : th) t.join();
@@ -1857,7 +1947,8 @@ extern "C" int fx_stream_ceiling(fx_context *c, int nrepeat, double *gbs) {
 
 // Sizes of the resident structures (for the algorithmic-bytes accounting of bench.py).
 // out[0] N, [1] NP, [2] NPL, [3] NPU, [4] M.npairs, [5] M.nblocks, [6] M.nslices,
-// [7] ssor.ncolor, [8] L.npairs, [9] L.nblocks, [10] U.npairs, [11] U.nblocks, [12] ssor slices
+// [7] ssor.ncolor, [8] L.npairs, [9] L.nblocks, [10] U.npairs, [11] U.nblocks, [12] ssor slices,
+// [13] interior / [14] boundary workgroups of the SpMV (domain-decomposed systems)
 extern "C" int fx_get_stats(fx_context *c, int64_t out[16]) {
   memset(out, 0, 16 * sizeof(int64_t));
   out[0] = c->A.N; out[1] = c->A.NP; out[2] = c->A.NPL; out[3] = c->A.NPU;
@@ -1865,6 +1956,7 @@ extern "C" int fx_get_stats(fx_context *c, int64_t out[16]) {
   out[7] = c->ssor.ncolor;
   out[8] = c->ssor.L.npairs; out[9] = c->ssor.L.nblocks; out[10] = c->ssor.U.npairs; out[11] = c->ssor.U.nblocks;
   out[12] = c->ssor.L.nslices;
+  out[13] = c->M.n_wg_interior; out[14] = c->M.n_wg_boundary;  // SpMV workgroups overlapped with / ordered after the halo exchange
   return 0;
 }
 

@@ -55,6 +55,10 @@ struct Bell {
   int *src2 = nullptr;          // npairs*64: source block codes 3*idx+{0 D,1 AL,2 AU}, -1 padding (kept for numeric refresh)
   int32_t *slot_row = nullptr;  // nslots: 0-based node id of the slot, -1 = padding slot (may be null = identity)
   int32_t *slice_order = nullptr;  // nslices: order in which the SpMV walks the slices (null = ascending)
+  // Domain-decomposed systems: the SpMV's virtual workgroups (4 consecutive entries of the slice walk each) split into those
+  // none of whose rows has a halo column (interior: run while the halo exchange is in flight) and the rest (boundary).
+  int32_t *wg_interior = nullptr, *wg_boundary = nullptr;
+  int32_t n_wg_interior = 0, n_wg_boundary = 0;
   int64_t nblocks = 0;          // real (non padding) blocks
   size_t bytes() const { return (size_t)npairs * 64 * (9 * 8 + 4) + (size_t)(nslices + 1) * 4; }
 };
@@ -272,6 +276,12 @@ struct fx_context {
   void *cb_user = nullptr;
   double *h_send = nullptr, *h_recv = nullptr;  // pinned staging
   HaloDev halo;
+  // Interior / boundary overlap of the SpMV (the design the reference sketched and left commented out,
+  // hecmw_solver_las_33.f90:242-246, :312-343 with hecmw_solver_SR_33.F90:129-273): pack on the solver stream, the
+  // exchange + unpack on comm_stream while the interior rows are multiplied, the boundary rows after it.  FX_OVERLAP=0: serial.
+  bool overlap = true;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_packed = nullptr, ev_halo = nullptr;
   NlDev nl;
   ElemColors asm_colors;  // fx_assemble_c3d8
   void *nn = nullptr;  // NnDev (fx_nn_host.h): systems with NDOF != 3

@@ -207,9 +207,14 @@ __global__ __launch_bounds__(BS) void k_spmv(int32_t nslices, int32_t nrows,
                                                    const double *__restrict__ x, const double *__restrict__ b,
                                                    double *__restrict__ y, double *__restrict__ partials,
                                                    const int32_t *__restrict__ gate, int32_t gate_val,
-                                                   const int32_t *__restrict__ slice_order) {
+                                                   const int32_t *__restrict__ slice_order,
+                                                   const int32_t *__restrict__ wg_list) {
   if (gate && *gate != gate_val) return;
-  const int vb = xcd_block(blockIdx.x, gridDim.x);
+  // wg_list (may be null): the virtual workgroups of THIS launch -- the interior / boundary halves of a domain-decomposed
+  // product (spmv(), fistr_hip.hip).  A virtual workgroup always covers the same four slices and owns the same partial-sum
+  // slot, so the two halves together are bit-identical to the one launch over all workgroups.
+  int vb = xcd_block(blockIdx.x, gridDim.x);
+  if (wg_list) vb = wg_list[vb];
   int slice = vb * (BS / 64) + (threadIdx.x >> 6);
   const bool live = slice < nslices;
   if (live && slice_order) slice = slice_order[slice];

@@ -288,3 +288,26 @@ def test_bench_refuses_more_rccl_ranks_than_devices():
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert p.returncode != 0 and "need 2 GPUs" in p.stderr
     assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.parametrize("world,m,meth,pc", [(2, 16, 1, 1), (4, 12, 1, 1), (2, 8, 2, 3), (4, 6, 2, 10)])
+def test_interior_boundary_spmv_overlap_is_bitwise_the_serial_exchange(tmp_path, monkeypatch, world, m, meth, pc):
+    """The SpMV of a subdomain split into interior workgroups (launched while the halo exchange is in flight on its own
+    stream) and boundary workgroups (after it) -- the design the reference sketched and left commented out,
+    hecmw_solver_las_33.f90:242-246, :312-343 -- against the same library with FX_OVERLAP=0 (pack -> exchange -> unpack ->
+    one launch): every residual-history line, the iteration count and X must be BIT-identical on every rank (same
+    workgroup -> slices -> partial-sum slot mapping in both), and the split must really have happened."""
+    monkeypatch.setenv("FX_OVERLAP", "0")
+    (tmp_path / "serial").mkdir()
+    ser = run_world("hip", world, m, meth, pc, tmp_path / "serial")
+    monkeypatch.setenv("FX_OVERLAP", "1")
+    (tmp_path / "overlap").mkdir()
+    ovl = run_world("hip", world, m, meth, pc, tmp_path / "overlap")
+    for a, b in zip(ser, ovl):
+        assert int(a["it"]) == int(b["it"]) and int(a["code"]) == int(b["code"]) == 0
+        assert np.array_equal(a["hist"], b["hist"])
+        assert np.array_equal(a["X"], b["X"])
+        assert int(b["wg"][1]) > 0                       # boundary workgroups exist on every rank of a decomposed cube
+    if pc == 1:     # colour-major numbering: the rows with halo columns are grouped at the end of each colour, so most
+        assert all(int(b["wg"][0]) > 0 for b in ovl)     # workgroups are interior and ran beside the exchange (with the
+                                                         # natural numbering of DIAG / ILU(0) an x-face touches every slice)
