@@ -7,7 +7,7 @@ against the rank itself (test_rccl_self_neighbour_halo_exchange)."""
 import numpy as np
 import pytest
 
-from test_distributed import check_against_serial, dist_prefix, run_world, serial_cube4, serial_reference
+from test_distributed import check_against_serial, dist8_prefix, dist_prefix, run_world, serial_cube4, serial_reference
 
 pytestmark = pytest.mark.gpu
 
@@ -311,3 +311,49 @@ def test_interior_boundary_spmv_overlap_is_bitwise_the_serial_exchange(tmp_path,
     if pc == 1:     # colour-major numbering: the rows with halo columns are grouped at the end of each colour, so most
         assert all(int(b["wg"][0]) > 0 for b in ovl)     # workgroups are interior and ran beside the exchange (with the
                                                          # natural numbering of DIAG / ILU(0) an x-face touches every slice)
+
+
+@pytest.mark.parametrize("meth,pc", [(1, 3), (1, 1), (2, 10)])
+def test_eight_subdomains_of_the_reference_partitioner(oracle, meth, pc):
+    """configs[3] ('... scaled to 8 subdomains, 8 GPUs, halo exchange') on the one GPU of the test box: the EIGHT HECMW-DIST
+    files hecmw_part1 wrote (tests/golden/dist_cube6x8, 7 neighbours per rank), one libfistr_hip context and one thread per
+    subdomain in this process (the box admits at most 6 GPU processes), device assembly + BC + solve per subdomain, halo
+    exchange and reductions through the host-callback transport.  Block-Jacobi: same iterations and field as the serial
+    oracle; localized SSOR / ILU(0) (halo columns dropped, hecmw_matrix_reorder.f90:50): same converged field."""
+    from frontistr_amd import hecmw as hip
+    from frontistr_amd.hecmw_dist import read_dist
+    from thread_world import ThreadWorld
+    subs = [read_dist("%s.%d" % (dist8_prefix(), r)) for r in range(8)]
+
+    def rank_main(r, world):
+        sub = subs[r]
+        fix = sub.group("FIX")
+        bc = (np.repeat(fix, 3).astype(np.int32), np.tile(np.array([1, 2, 3], dtype=np.int32), fix.size), np.zeros(3 * fix.size))
+        load = np.zeros(3 * sub.n_node)
+        load[3 * (sub.group("TOP") - 1)] = 1.0
+        hm = sub.hecmesh(hip)
+        hm.elem_node_item = sub.conn.ravel()
+        mat = hip.hecmw_mat_con(hm, hip.hecmwST_matrix())
+        ctx = hip.SolverContext(device=0)
+        cbs = world.callbacks(r, sub)
+        assert hip.lib().fx_comm_set_host_callbacks(ctx.h, r, 8, cbs[0], cbs[1], None) == 0
+        ctx.upload(mat, hm, what=hip.FX_UP_PROFILE)
+        ctx.assemble_c3d8(sub.coord, sub.conn, 210000.0, 0.3, elemopt=1, load=load, bc=bc)
+        mat.Iarray[0] = 10000; mat.Iarray[1] = meth; mat.Iarray[2] = pc
+        code = ctx.solve_resident(mat)
+        ctx.download_x(mat)
+        res = dict(X=mat.X.copy(), it=ctx.info.iterations, hist=ctx.history.copy(), code=code, gid=sub.global_id,
+                   nn_internal=sub.nn_internal, conv=int(mat.Iarray[80]))
+        ctx.close()
+        return res
+
+    res = ThreadWorld(8).run(rank_main)
+    ser = serial_cube4(oracle, meth, pc, n=6)
+    assert all(r["code"] == 0 and r["conv"] == 1 for r in res)
+    assert len(set(int(r["it"]) for r in res)) == 1                      # every rank saw the same reductions
+    if pc == 3:
+        check_against_serial(res, ser, meth)
+    else:
+        xs = ser["X"].reshape(-1, 3)
+        for r in res:
+            assert np.abs(r["X"].reshape(-1, 3) - xs[r["gid"]]).max() < 2e-7 * np.abs(xs).max()

@@ -143,3 +143,75 @@ def test_nonlinear_patch_test_fullsize(n):
         t = np.zeros((m.NP, 3)); t[:, d] = 1.0
         assert np.abs(spmv(hip, ctx, m, t.ravel())).max() < 1e-9 * np.abs(Aw).max()
     ctx.close()
+
+
+def test_bicgstab_ilu0_fullsize(monkeypatch):
+    """configs[4]'s solver pairing at BASELINE size (10.125M DOF): BiCGSTAB + ILU(0) through size-independent properties.
+      * the dependency levels of the natural-order ILU(0) on a 150^3-node hex cube: level(i,j,k) = i + 2j + 4k + 1, 1,044 in all;
+      * the reported residual is the true ||b - A x|| / ||b|| of the returned x, and the recurrence is finite throughout;
+      * ILU(0) of a symmetric matrix is a symmetric operator: r . M^-1 s == s . M^-1 r;
+      * the persistent dataflow sweep (default) and the launch-per-level sweep give bit-identical M^-1 r at full size."""
+    from frontistr_amd import hecmw as hip
+    n = 149
+    mesh, m, ctx = build(hip, n)
+    m.Iarray[0] = 40; m.Iarray[1] = 2; m.Iarray[2] = 10
+    m.Rarray[0] = 1e-30
+    code = ctx.solve_resident(m)
+    assert code == hip.HECMW_SOLVER_ERROR_NOCONV_MAXIT and ctx.info.iterations == 41
+    assert ctx.info.ncolor == 7 * n + 1                                   # dependency levels
+    h = ctx.history
+    assert len(h) == 40 and np.all(np.isfinite(h)) and h[-1] < h[0]
+    assert abs(ctx.info.rel_resid - h[-1]) <= 1e-6 * h[-1]
+    st = ctx.stats()
+    assert st["L_blocks"] == st["NPL"] and st["U_blocks"] == st["NPU"]     # every off-diagonal block is in exactly one sweep
+    rng = np.random.default_rng(1)
+    r = rng.standard_normal(3 * m.NP); s = rng.standard_normal(3 * m.NP)
+    Mr, Ms = ctx.precond_apply(r), ctx.precond_apply(s)
+    assert np.all(np.isfinite(Mr))
+    assert abs(np.dot(s, Mr) - np.dot(r, Ms)) <= 1e-9 * (np.abs(s) @ np.abs(Mr))
+    ctx.close()
+    monkeypatch.setenv("FX_DATAFLOW", "0")                                 # the launch-per-level sweeps, 8 waves per slice as the dataflow default
+    mesh2, m2, ctx2 = build(hip, n)
+    m2.Iarray[1] = 2; m2.Iarray[2] = 10
+    ctx2.precond_setup(m2)
+    assert np.array_equal(ctx2.precond_apply(r), Mr)
+    ctx2.close()
+
+
+def test_nonlinear_substep_bicgstab_ilu0_fullsize():
+    """configs[4]'s loop at BASELINE size: one load sub-step of the elastoplastic (multilinear Mises, updated Lagrange) Newton
+    loop on the 10.125M-DOF cube with BiCGSTAB + ILU(0) inside, as a PATCH TEST with a known answer: every surface node is
+    prescribed u = H x, so the converged field is u = H x everywhere, every one of the 26.5M quadrature points carries the same
+    (plastic) stress, and the Newton residual falls from iteration to iteration.  Each Newton iteration re-assembles the
+    tangent on the device, refreshes the ILU(0) factors as Iarray(97) asks and solves to 1e-8."""
+    from frontistr_amd import fstr, hecmw as hip
+    from frontistr_amd.mesh import CubeMesh
+    n = 149
+    mesh = CubeMesh(n)
+    hm = hip.hecmwST_local_mesh(n_node=mesh.n_node)
+    hm.elem_node_item = mesh.conn.ravel()
+    m = hip.hecmw_mat_con(hm, hip.hecmwST_matrix())
+    ctx = hip.SolverContext()
+    ctx.upload(m, what=hip.FX_UP_PROFILE | hip.FX_UP_X)
+    table = [[450, 0], [608, 0.05], [679, 0.1], [732, 0.2], [752, 0.3], [766, 0.4], [780, 0.5]]
+    solid = fstr.fstr_solid(ctx, mesh.coord, mesh.conn,
+                            fstr.tMaterial(206900.0, 0.29, plastic=True, harden=fstr.MULTILINEAR, table=table, nlgeom_flag=2))
+    H = np.array([[0.004, 0.002, 0.0], [0.0, -0.001, 0.001], [0.0005, 0.0, 0.012]])
+    c = mesh.coord
+    surf = np.nonzero(np.any((c == 0) | (c == n), axis=1))[0]
+    us = (c[surf] @ H.T)
+    bc = (np.repeat(surf + 1, 3).astype(np.int32), np.tile(np.array([1, 2, 3], dtype=np.int32), surf.size), us.ravel().copy())
+    m.Iarray[0] = 2000; m.Iarray[1] = 2; m.Iarray[2] = 10
+    m.Rarray[0] = 1e-8
+    ok, log = fstr.fstr_Newton(solid, m, (0.0, 1.0), bc, None, 6, 1e-6, True)
+    # log columns: iter, solver iterations, solver code, |B|, |X|, |QFORCE|, |dunode|
+    assert ok and log.shape[0] >= 1 and np.all(log[:, 2] == 0) and np.all(log[:, 1] > 0)
+    assert np.all(np.isfinite(log))
+    assert log[-1, 3] < 1e-5 * log[-1, 5]      # |B| (out-of-balance force) against |QFORCE|: equilibrium of the affine field
+    st = solid.get_state(("unode", "stress", "istat"))
+    u_exact = (c @ H.T).ravel()
+    assert np.abs(st["unode"] - u_exact).max() < 2e-5 * np.abs(u_exact).max()
+    sig = st["stress"].reshape(-1, 6)
+    assert np.abs(sig - sig[0]).max() < 1e-3 * np.abs(sig[0]).max()
+    assert st["istat"].min() == 1                                          # every point yielded
+    ctx.close()
