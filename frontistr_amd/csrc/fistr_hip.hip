@@ -247,6 +247,11 @@ extern "C" int fx_create(int device, fx_context **out) {
     fx_destroy(c);
     return FX_ERROR_RUNTIME;
   }
+  if (const char *e = getenv("FX_DUMMY_MB")) {  // placement experiments: shifts where the allocations that follow land
+    void *dummy = nullptr;
+    (void)hipMalloc(&dummy, (size_t)atoll(e) << 20);  // kept for the life of the process on purpose
+  }
+  if (const char *e = getenv("FX_TUNE_PLACEMENT")) c->tune_tries = std::max(0, atoi(e));
   if (const char *e = getenv("FX_PIPE_SPMV")) c->pipe_spmv = atoi(e) != 0;
   if (const char *e = getenv("FX_PIPE_SSOR")) c->pipe_ssor = atoi(e) != 0;
   if (const char *e = getenv("FX_SSOR_MODE")) c->ssor_mode = atoi(e);
@@ -534,6 +539,68 @@ static int build_full_bell(fx_context *c) {
 
 static int ensure_work(fx_context *c);
 
+static int spmv_launch(fx_context *c, int mode, int dot, double *x, const double *b, double *y, const int32_t *gate,
+                       int32_t gate_val, const int32_t *wg_list, int nwg);
+static inline int spmv_nparts(fx_context *c);
+
+// Placement search of a BELL value array (see fx_context::tune_tries): candidate allocations are filled (fill) and timed
+// (time_ms: one representative launch sequence, lower is better); the fastest is kept.  Candidates are held until the search
+// ends -- freeing one early would hand the same physical block to the next hipMalloc.  The search stops early once a
+// candidate streams at >= good_gbs (GB/s over `stream_bytes`).
+template <class Fill, class Time>
+static int tune_placement(fx_context *c, Bell &B, const char *what, double stream_bytes, double good_gbs, Fill fill, Time time_ms) {
+  B.placed = true;
+  if (c->tune_tries <= 1 || B.nslices < c->tune_min_slices) return 0;
+  const size_t bytes = (size_t)B.npairs * 576 * 8;
+  std::vector<void *> cand;
+  std::vector<float> t;
+  cand.push_back(B.val2_base);
+  t.push_back(0.f);
+  if (time_ms(&t[0])) return FX_ERROR_RUNTIME;
+  for (int k = 1; k < c->tune_tries; k++) {
+    if (stream_bytes / (1e-3 * *std::min_element(t.begin(), t.end())) / 1e9 >= good_gbs) break;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + (bytes >> 1) + ((size_t)4 << 30)) break;  // keep headroom
+    char *base = nullptr;
+    if (hipMalloc((void **)&base, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+    B.val2_base = base;
+    B.val2 = (double *)base;
+    if (fill()) return FX_ERROR_RUNTIME;
+    cand.push_back(base);
+    t.push_back(0.f);
+    if (time_ms(&t.back())) return FX_ERROR_RUNTIME;
+  }
+  const int best = (int)(std::min_element(t.begin(), t.end()) - t.begin());
+  if (getenv("FX_TIMING") && atoi(getenv("FX_TIMING"))) {
+    fprintf(stderr, "[fx timing] %s value-array placement:", what);
+    for (size_t k = 0; k < t.size(); k++) fprintf(stderr, " %.3f ms%s", t[k], (int)k == best ? "*" : "");
+    fprintf(stderr, "\n");
+  }
+  for (size_t k = 0; k < cand.size(); k++)
+    if ((int)k != best) (void)hipFree(cand[k]);
+  B.val2_base = cand[best];  // every candidate was filled from the same values
+  B.val2 = (double *)cand[best];
+  return 0;
+}
+
+static int tune_value_placement(fx_context *c) {
+  Bell &M = c->M;
+  auto time_spmv = [&](float *ms) -> int {
+    const int nwg = spmv_nparts(c);
+    if (spmv_launch(c, 0, 0, c->Bs, nullptr, c->W[7], nullptr, 0, nullptr, nwg)) return FX_ERROR_RUNTIME;  // untimed
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    for (int i = 0; i < 3; i++)
+      if (spmv_launch(c, 0, 0, c->Bs, nullptr, c->W[7], nullptr, 0, nullptr, nwg)) return FX_ERROR_RUNTIME;
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    *ms /= 3.f;
+    return 0;
+  };
+  const double bytes = (double)M.npairs * 64 * 76 + 48.0 * c->ord.nslots;
+  return tune_placement(c, M, "SpMV", bytes, 6600.0, [&]() { return bell_fill_values(c, M); }, time_spmv);
+}
+
 // Make the ordering, M (symbolic + values) and the work vectors current.
 static int ensure_solver(fx_context *c) {
   if (c->ord.kind < 0 && set_ordering(c, 0, nullptr)) return FX_ERROR_RUNTIME;
@@ -542,6 +609,7 @@ static int ensure_solver(fx_context *c) {
   if (!c->bell_valid && c->have_values) {
     if (bell_fill_values(c, c->M)) return FX_ERROR_RUNTIME;
     c->bell_valid = true;
+    if (!c->M.placed && tune_value_placement(c)) return FX_ERROR_RUNTIME;
   }
   return 0;
 }
@@ -1025,6 +1093,36 @@ static int ssor_setup_symbolic(fx_context *c, int ncolor_in) {
   return 0;
 }
 
+static int precond_apply_once(fx_context *c, const double *r, double *z, bool want_dot, int *nparts);
+
+// Placement search of the sweep layouts' value arrays (L, then U), timed on the whole apply.
+static int tune_sweep_placement(fx_context *c, const double *lu_D, const double *lu_AL, const double *lu_AU) {
+  SsorDev &S = c->ssor;
+  if (S.L.placed && S.U.placed) return 0;
+  if (c->tune_tries <= 1 || S.L.nslices < c->tune_min_slices) { S.L.placed = S.U.placed = true; return 0; }
+  if (ensure_work(c)) return FX_ERROR_RUNTIME;
+  KrylovState st0;
+  memset(&st0, 0, sizeof st0);
+  HIP_TRY(hipMemcpyAsync(c->st, &st0, sizeof st0, hipMemcpyHostToDevice, c->stream));  // status 0: the gated sweeps run
+  auto time_apply = [&](float *ms) -> int {
+    int np;
+    if (precond_apply_once(c, c->Bs, c->W[7], false, &np)) return FX_ERROR_RUNTIME;  // untimed
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    for (int i = 0; i < 2; i++)
+      if (precond_apply_once(c, c->Bs, c->W[7], false, &np)) return FX_ERROR_RUNTIME;
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    *ms /= 2.f;
+    return 0;
+  };
+  const double bytes = 76.0 * 64 * (double)(S.L.npairs + S.U.npairs) + (2 * 72.0 + 120.0) * S.nslots;
+  const double good = c->precond_kind == 10 ? 1e9 : 5450.0;  // level-scheduled ILU(0) is latency-bound: placement does not show
+  if (c->precond_kind == 10) { S.L.placed = S.U.placed = true; return 0; }
+  if (tune_placement(c, S.L, "sweep L", bytes, good, [&]() { return bell_fill_values(c, S.L, lu_D, lu_AL, lu_AU); }, time_apply)) return FX_ERROR_RUNTIME;
+  return tune_placement(c, S.U, "sweep U", bytes, good, [&]() { return bell_fill_values(c, S.U, lu_D, lu_AL, lu_AU); }, time_apply);
+}
+
 static int ssor_setup_numeric(fx_context *c, double sigma_diag) {
   SsorDev &S = c->ssor;
   if (bell_fill_values(c, S.L) || bell_fill_values(c, S.U)) return FX_ERROR_RUNTIME;
@@ -1173,6 +1271,7 @@ extern "C" int fx_precond_setup(fx_context *c, const int32_t *Iarray, const doub
     }
     if (ensure_solver(c)) return FX_ERROR_RUNTIME;
     if (ssor_setup_numeric(c, sigma_diag)) return FX_ERROR_RUNTIME;
+    if (tune_sweep_placement(c, nullptr, nullptr, nullptr)) return FX_ERROR_RUNTIME;
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->precond_valid = true;
@@ -1826,6 +1925,9 @@ extern "C" int fx_nn_matvec_resident(fx_context *c, int nrepeat, float *ms_per_c
 // partial of r.r (the residual recomputation).  The halo exchange of a multi-rank system is part of every call.
 extern "C" int fx_spmv_resident(fx_context *c, int variant, int nrepeat, float *ms_per_call) {
   HIP_TRY(hipSetDevice(c->device));
+  if (getenv("FX_PLACEMENT_DEBUG"))
+    fprintf(stderr, "[fx placement] val2 %p col2 %p pair_ptr %p x(Bs) %p y(W7) %p partials %p slice_order %p\n", (void *)c->M.val2,
+            (void *)c->M.col2, (void *)c->M.pair_ptr, (void *)c->Bs, (void *)c->W[7], (void *)c->partials, (void *)c->M.slice_order);
   if (!c->have_values) { g_fx_error = "fx_spmv_resident: no matrix resident"; return FX_ERROR_RUNTIME; }
   if (variant < 0 || variant > 2) { g_fx_error = "fx_spmv_resident: variant must be 0, 1 or 2"; return FX_ERROR_RUNTIME; }
   if (ensure_solver(c)) return FX_ERROR_RUNTIME;

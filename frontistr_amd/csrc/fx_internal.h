@@ -60,6 +60,7 @@ struct Bell {
   int32_t *wg_interior = nullptr, *wg_boundary = nullptr;
   int32_t n_wg_interior = 0, n_wg_boundary = 0;
   int64_t nblocks = 0;          // real (non padding) blocks
+  bool placed = false;          // the value array went through the placement search (once per symbolic build)
   size_t bytes() const { return (size_t)npairs * 64 * (9 * 8 + 4) + (size_t)(nslices + 1) * 4; }
 };
 
@@ -239,6 +240,13 @@ struct fx_context {
   // non-temporal stream loads): SpMV 1.14-1.17 -> 1.105-1.11 ms; colour sweeps 1.685 -> 1.61 ms per apply.
   // (With the earlier padded layout it cost the SpMV 1.19 -> 1.30 ms: re-measure when the layout changes.)
   bool pipe_spmv = true, pipe_ssor = true;  // FX_PIPE_SPMV / FX_PIPE_SSOR override
+  // Placement search of the SpMV's value array.  The identical kernel on identical data runs at 1.03-1.19 ms (10.1M DOF)
+  // depending on WHERE hipMalloc put the 6.5 GB value array physically: same virtual layout, same alignment, different speed
+  // (scripts/experiments/ab_ssor.py with FX_DUMMY_MB / FX_PLACEMENT_DEBUG).  So the library measures: up to tune_tries
+  // candidate allocations are filled and timed (3 SpMV launches each), the fastest is kept, the others are released.
+  // Large systems only (>= tune_min_slices), once per symbolic build, bounded by free device memory.  FX_TUNE_PLACEMENT=0 off.
+  int tune_tries = 12;
+  int32_t tune_min_slices = 8192;
   // work vectors (3*NP each)
   double *W[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int iterpremax = 1;  // additive-Schwarz sweeps of hecmw_precond_33_apply
