@@ -140,7 +140,9 @@ template <int ND, int MODE>
 __global__ __launch_bounds__(256) void k_nn_rows(int32_t s0, int32_t s1, const int64_t *__restrict__ slice_ptr,
                                                  const int32_t *__restrict__ slot_row, const int32_t *__restrict__ col,
                                                  const double *__restrict__ val, const double *x, const double *__restrict__ b,
-                                                 double *y, const double *__restrict__ alu) {
+                                                 double *y, const double *__restrict__ alu, const int32_t *__restrict__ gate,
+                                                 int32_t gate_val) {
+  if (gate && *gate != gate_val) return;  // device-resident Krylov state: the kernel only runs while the state asks for it
   const int lane = threadIdx.x & 63;
   const int32_t s = s0 + blockIdx.x * 4 + (threadIdx.x >> 6);
   if (s >= s1) return;
@@ -450,18 +452,18 @@ static int nn_halo(fx_context *c, double *x) {  // hecmw_update_m_R
 
 template <int ND, int MODE>
 static void nn_rows_launch(fx_context *c, const NnBell &b, int32_t s0, int32_t s1, const double *x, const double *rhs, double *y,
-                           const double *alu) {
+                           const double *alu, const int32_t *gate = nullptr, int32_t gate_val = 0) {
   if (s1 <= s0) return;
   hipLaunchKernelGGL((k_nn_rows<ND, MODE>), dim3((s1 - s0 + 3) / 4), dim3(256), 0, c->stream, s0, s1, b.slice_ptr, b.slot_row, b.col,
-                     b.val, x, rhs, y, alu);
+                     b.val, x, rhs, y, alu, gate, gate_val);
 }
 
 // y = A x (mode 0) or y = b - A x (mode 1); x gets its halo first (las_nn.f90:247)
-static int nn_spmv(fx_context *c, int mode, double *x, const double *b, double *y) {
+static int nn_spmv(fx_context *c, int mode, double *x, const double *b, double *y, const int32_t *gate = nullptr, int32_t gate_val = 0) {
   NnDev *n = nn_of(c);
-  if (nn_halo(c, x)) return FX_ERROR_RUNTIME;
-  if (mode == 0) { NN_DISPATCH(n->ndof, nn_rows_launch<ND, 0>(c, n->M, 0, n->M.nslices, x, nullptr, y, nullptr)) }
-  else { NN_DISPATCH(n->ndof, nn_rows_launch<ND, 1>(c, n->M, 0, n->M.nslices, x, b, y, nullptr)) }
+  if (nn_halo(c, x)) return FX_ERROR_RUNTIME;  // collective: every rank exchanges whether or not its state lets the product run
+  if (mode == 0) { NN_DISPATCH(n->ndof, nn_rows_launch<ND, 0>(c, n->M, 0, n->M.nslices, x, nullptr, y, nullptr, gate, gate_val)) }
+  else { NN_DISPATCH(n->ndof, nn_rows_launch<ND, 1>(c, n->M, 0, n->M.nslices, x, b, y, nullptr, gate, gate_val)) }
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -587,89 +589,150 @@ static int nn_precond_apply(fx_context *c, int iterpremax, const double *r, doub
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Krylov loops (host-driven scalars)
+// Krylov loops: CG and BiCGSTAB with the scalars RESIDENT ON THE DEVICE, exactly as the 3x3 path runs them (KrylovState,
+// k_scalar<OP>: fixed-order reduction of the partial sums + the reference's scalar logic in one single-block kernel; every
+// update kernel early-outs unless the state is RUNNING).  The host enqueues whole iterations and polls one word every few
+// iterations -- no host round trip per dot product (the first version synchronised 3-6 times per iteration, and so does
+// the reference: hecmw_InnerProduct_R, hecmw_solver_misc.f90:46-70).  Multi-rank: reduce -> in-stream all-reduce -> logic.
 // ---------------------------------------------------------------------------------------------------------------
 struct NnResult { int iter = 0, error = 0; double resid = 0.0; std::vector<double> hist; };
 
-static int nn_cg(fx_context *c, int MAXIT, double TOL, int iterpremax, NnResult *o) {  // hecmw_solver_CG.f90:19-312
-  NnDev *n = nn_of(c);
-  const int64_t nlen = (int64_t)n->ndof * n->N;
-  double *X = n->X, *B = n->B, *R = n->W[0], *Z = n->W[1], *Q = n->W[1], *P = n->W[2];
-  double RHO = 0, RHO1 = 0, BETA, C1, ALPHA, DNRM2, BNRM2, RESID = 0;
-  int n_indef = 0, iter;
-  if (nn_spmv(c, 1, X, B, R) || nn_dot(c, B, B, &BNRM2)) return FX_ERROR_RUNTIME;
-  if (BNRM2 == 0.0) { MAXIT = 0; HIP_TRY(hipMemsetAsync(X, 0, (size_t)n->ndof * n->NP * 8, c->stream)); }
-  for (iter = 1; iter <= MAXIT; iter++) {
-    if (nn_precond_apply(c, iterpremax, R, Z) || nn_dot(c, R, Z, &RHO)) return FX_ERROR_RUNTIME;
-    if (RHO == 0.0) break;
-    if (iter > 1 && RHO * RHO1 <= 0) { if (++n_indef >= 3) { o->error = FX_ERROR_DIVERGE_PC; break; } }
-    if (iter == 1) HIP_TRY(hipMemcpyAsync(P, Z, (size_t)nlen * 8, hipMemcpyDeviceToDevice, c->stream));
-    else { BETA = RHO / RHO1; NN_LIN(P, 1.0, Z, BETA, P, 0.0, (const double *)nullptr); }
-    if (nn_spmv(c, 0, P, nullptr, Q) || nn_dot(c, P, Q, &C1)) return FX_ERROR_RUNTIME;
-    if (C1 <= 0) { o->error = FX_ERROR_DIVERGE_MAT; break; }
-    ALPHA = RHO / C1;
-    NN_LIN(X, 1.0, X, ALPHA, P, 0.0, (const double *)nullptr);
-    if (iter % 50 == 0) { if (nn_spmv(c, 1, X, B, R)) return FX_ERROR_RUNTIME; }
-    else NN_LIN(R, 1.0, R, -ALPHA, Q, 0.0, (const double *)nullptr);
-    if (nn_dot(c, R, R, &DNRM2)) return FX_ERROR_RUNTIME;
-    RESID = sqrt(DNRM2 / BNRM2);
-    o->hist.push_back(RESID);
-    if (!(RESID == RESID) || std::isinf(RESID)) { o->error = FX_ERROR_NOCONV_MAXIT; break; }  // same guard as the 3x3 path
-    if (RESID <= TOL) {
-      if (iter % 50 == 0) break;
-      if (nn_spmv(c, 1, X, B, R) || nn_dot(c, R, R, &DNRM2)) return FX_ERROR_RUNTIME;
-      RESID = sqrt(DNRM2 / BNRM2);
-      if (RESID <= TOL) break;
+__global__ __launch_bounds__(FX_BLOCK) void k_nn_cg_p(int64_t n, const KrylovState *__restrict__ st, const double *__restrict__ z,
+                                                      double *__restrict__ p) {  // hecmw_solver_CG.f90:188-197
+  if (st->status != 0) return;
+  const bool first = (st->iter == 1);
+  const double beta = st->beta;
+  for (int64_t i = (int64_t)blockIdx.x * FX_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FX_BLOCK)
+    p[i] = first ? z[i] : z[i] + beta * p[i];
+}
+template <bool UPDATE_R>
+__global__ __launch_bounds__(FX_BLOCK) void k_nn_cg_xr(int64_t n, const KrylovState *__restrict__ st, const double *__restrict__ p,
+                                                       const double *__restrict__ q, double *__restrict__ x, double *__restrict__ r,
+                                                       double *__restrict__ partials) {  // :227-240
+  if (st->status != 0) return;
+  const double alpha = st->alpha;
+  double d[1] = {0.0};
+  for (int64_t i = (int64_t)blockIdx.x * FX_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FX_BLOCK) {
+    x[i] = x[i] + alpha * p[i];
+    if (UPDATE_R) {
+      const double rv = r[i] - alpha * q[i];
+      r[i] = rv;
+      d[0] += rv * rv;
     }
-    if (iter == MAXIT) o->error = FX_ERROR_NOCONV_MAXIT;
-    RHO1 = RHO;
   }
-  o->iter = iter; o->resid = RESID;
+  if (UPDATE_R) block_sum_store<1>(d, partials, 0);
+}
+
+static int nn_partials(fx_context *c) {  // the partial-sum buffer of the scalar stages (shared with the 3x3 path)
+  if (c->max_partials < 4096 + 8) {
+    dev_free(c->partials);
+    if (dev_alloc(&c->partials, (size_t)(4096 + 8) * 3)) return FX_ERROR_RUNTIME;
+    c->max_partials = 4096 + 8;
+  }
+  return 0;
+}
+static int nn_dot_parts(fx_context *c, const double *x, const double *y, const int32_t *gate, int32_t gate_val, int *np) {
+  NnDev *n = nn_of(c);
+  const int64_t len = (int64_t)n->ndof * n->nn_internal;  // hecmw_InnerProduct_R: NDOF * nn_internal entries
+  const int g = grid_for(len, FX_BLOCK, 2048);
+  hipLaunchKernelGGL(k_dot, dim3(g), dim3(FX_BLOCK), 0, c->stream, len, x, y, c->partials, gate, gate_val);
+  HIP_TRY(hipGetLastError());
+  *np = g;
   return 0;
 }
 
-static int nn_bicgstab(fx_context *c, int MAXIT, double TOL, int iterpremax, NnResult *o) {  // hecmw_solver_BiCGSTAB.f90:16-297
+static int nn_cg_iteration(fx_context *c, int it, int iterpremax) {  // hecmw_solver_CG.f90:153-271
   NnDev *n = nn_of(c);
-  const int64_t nlen = (int64_t)n->ndof * n->N;
-  double *X = n->X, *B = n->B, *R = n->W[0], *RT = n->W[1], *P = n->W[2], *PT = n->W[3], *S = n->W[4], *ST = n->W[0], *T = n->W[5],
-         *V = n->W[6];
-  double RHO = 0, RHO1 = 0, BETA, ALPHA = 0, OMEGA = 0, C2, CG0, CG1, DNRM2, BNRM2, RESID = 0;
-  int iter;
-  if (nn_spmv(c, 1, X, B, R)) return FX_ERROR_RUNTIME;
-  HIP_TRY(hipMemcpyAsync(RT, R, (size_t)nlen * 8, hipMemcpyDeviceToDevice, c->stream));
-  if (nn_dot(c, B, B, &BNRM2)) return FX_ERROR_RUNTIME;
-  if (BNRM2 == 0.0) { MAXIT = 0; HIP_TRY(hipMemsetAsync(X, 0, (size_t)n->ndof * n->NP * 8, c->stream)); }
-  for (iter = 1; iter <= MAXIT; iter++) {
-    if (nn_dot(c, R, RT, &RHO)) return FX_ERROR_RUNTIME;
-    if (iter > 1) {
-      BETA = (RHO / RHO1) * (ALPHA / OMEGA);
-      hipLaunchKernelGGL(k_nn_bicg_p, dim3(nn_vgrid(nlen)), dim3(256), 0, c->stream, nlen, BETA, OMEGA, R, V, P);
-    } else HIP_TRY(hipMemcpyAsync(P, R, (size_t)nlen * 8, hipMemcpyDeviceToDevice, c->stream));
-    if (nn_precond_apply(c, iterpremax, P, PT) || nn_spmv(c, 0, PT, nullptr, V) || nn_dot(c, RT, V, &C2)) return FX_ERROR_RUNTIME;
-    ALPHA = RHO / C2;
-    NN_LIN(S, 1.0, R, -ALPHA, V, 0.0, (const double *)nullptr);
-    if (nn_precond_apply(c, iterpremax, S, ST) || nn_spmv(c, 0, ST, nullptr, T)) return FX_ERROR_RUNTIME;  // ST aliases R (:50)
-    if (nn_dot(c, T, S, &CG0) || nn_dot(c, T, T, &CG1)) return FX_ERROR_RUNTIME;
-    OMEGA = CG0 / CG1;
-    NN_LIN(X, 1.0, X, ALPHA, PT, OMEGA, ST);
-    if (iter % 100 == 0) { if (nn_spmv(c, 1, X, B, R)) return FX_ERROR_RUNTIME; }
-    else NN_LIN(R, 1.0, S, -OMEGA, T, 0.0, (const double *)nullptr);
-    if (nn_dot(c, R, R, &DNRM2)) return FX_ERROR_RUNTIME;
-    RESID = sqrt(DNRM2 / BNRM2);
-    o->hist.push_back(RESID);
-    if (!(RESID == RESID) || std::isinf(RESID)) { o->error = FX_ERROR_NOCONV_MAXIT; break; }
-    if (RESID <= TOL) {
-      if (iter % 100 == 0) break;
-      if (nn_spmv(c, 1, X, B, R) || nn_dot(c, R, R, &DNRM2)) return FX_ERROR_RUNTIME;
-      RESID = sqrt(DNRM2 / BNRM2);
-      if (RESID <= TOL) break;
-    }
-    if (iter == MAXIT) o->error = FX_ERROR_NOCONV_MAXIT;
-    RHO1 = RHO;
+  const int64_t nlen = (int64_t)n->ndof * n->N, dlen = (int64_t)n->ndof * n->nn_internal;
+  double *X = n->X, *B = n->B, *R = n->W[0], *Z = n->W[1], *Q = n->W[1], *P = n->W[2];
+  const int RECOMPUTE = 50, vgrid = grid_for(dlen, FX_BLOCK, 2048);
+  int np;
+  if (nn_precond_apply(c, iterpremax, R, Z) || nn_dot_parts(c, R, Z, gate_status(c), 0, &np)) return FX_ERROR_RUNTIME;
+  if (scalar_stage<OP_CG_RHO>(c, np, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
+  hipLaunchKernelGGL(k_nn_cg_p, dim3(nn_vgrid(nlen)), dim3(FX_BLOCK), 0, c->stream, nlen, c->st, Z, P);
+  if (nn_spmv(c, 0, P, nullptr, Q) || nn_dot_parts(c, P, Q, gate_status(c), 0, &np)) return FX_ERROR_RUNTIME;
+  if (scalar_stage<OP_CG_C1>(c, np, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
+  if (it % RECOMPUTE == 0) {
+    hipLaunchKernelGGL((k_nn_cg_xr<false>), dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, dlen, c->st, P, Q, X, R, c->partials);
+    if (nn_spmv(c, 1, X, B, R, gate_status(c), 0) || nn_dot_parts(c, R, R, gate_status(c), 0, &np)) return FX_ERROR_RUNTIME;
+  } else {
+    hipLaunchKernelGGL((k_nn_cg_xr<true>), dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, dlen, c->st, P, Q, X, R, c->partials);
+    np = vgrid;
   }
-  o->iter = iter; o->resid = RESID;
+  if (scalar_stage<OP_RESID>(c, np, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
+  if (it % RECOMPUTE != 0) {  // converged by the recurrence: true residual, re-test (:259-266) -- runs only when the device asks
+    if (nn_spmv(c, 1, X, B, R, gate_verify(c), 1) || nn_dot_parts(c, R, R, gate_verify(c), 1, &np)) return FX_ERROR_RUNTIME;
+    if (scalar_stage<OP_VERIFY>(c, np, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
+  }
+  HIP_TRY(hipGetLastError());
   return 0;
 }
+
+static int nn_bicgstab_iteration(fx_context *c, int it, int iterpremax) {  // hecmw_solver_BiCGSTAB.f90:146-264
+  NnDev *n = nn_of(c);
+  const int64_t dlen = (int64_t)n->ndof * n->nn_internal;
+  double *X = n->X, *B = n->B, *R = n->W[0], *RT = n->W[1], *P = n->W[2], *PT = n->W[3], *S = n->W[4], *ST = n->W[0], *T = n->W[5],
+         *V = n->W[6];
+  const int RECOMPUTE = 100, vgrid = grid_for(dlen, FX_BLOCK, 2048);
+  int np;
+  if (nn_dot_parts(c, R, RT, gate_status(c), 0, &np) || scalar_stage<OP_BI_RHO>(c, np, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
+  hipLaunchKernelGGL(k_bi_update_p, dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, dlen, c->st, R, V, P);
+  if (nn_precond_apply(c, iterpremax, P, PT) || nn_spmv(c, 0, PT, nullptr, V)) return FX_ERROR_RUNTIME;
+  if (nn_dot_parts(c, RT, V, gate_status(c), 0, &np) || scalar_stage<OP_BI_C2>(c, np, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
+  hipLaunchKernelGGL(k_bi_update_s, dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, dlen, c->st, R, V, S);
+  if (nn_precond_apply(c, iterpremax, S, ST) || nn_spmv(c, 0, ST, nullptr, T)) return FX_ERROR_RUNTIME;  // ST aliases R (:50)
+  hipLaunchKernelGGL(k_dot2, dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, dlen, T, S, c->partials, c->max_partials, gate_status(c));
+  if (scalar_stage<OP_BI_OMEGA>(c, vgrid, c->max_partials, RECOMPUTE)) return FX_ERROR_RUNTIME;
+  if (it % RECOMPUTE == 0) {
+    hipLaunchKernelGGL((k_bi_update_xr<false>), dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, dlen, c->st, PT, ST, S, T, X, R, c->partials);
+    if (nn_spmv(c, 1, X, B, R, gate_status(c), 0) || nn_dot_parts(c, R, R, gate_status(c), 0, &np)) return FX_ERROR_RUNTIME;
+  } else {
+    hipLaunchKernelGGL((k_bi_update_xr<true>), dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, dlen, c->st, PT, ST, S, T, X, R, c->partials);
+    np = vgrid;
+  }
+  if (scalar_stage<OP_RESID>(c, np, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
+  if (it % RECOMPUTE != 0) {
+    if (nn_spmv(c, 1, X, B, R, gate_verify(c), 1) || nn_dot_parts(c, R, R, gate_verify(c), 1, &np)) return FX_ERROR_RUNTIME;
+    if (scalar_stage<OP_VERIFY>(c, np, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// begin (r0, ||b||), then iterations enqueued in chunks with one poll of the device state per chunk
+static int nn_krylov(fx_context *c, int method, int MAXIT, double TOL, int iterpremax, NnResult *o) {
+  NnDev *n = nn_of(c);
+  const int64_t nlen = (int64_t)n->ndof * n->N;
+  const size_t vbytes = (size_t)n->ndof * n->NP * 8;
+  double *X = n->X, *B = n->B, *R = n->W[0];
+  int np;
+  if (nn_partials(c) || krylov_init_state(c, MAXIT, TOL)) return FX_ERROR_RUNTIME;
+  HIP_TRY(hipMemsetAsync(n->W[2], 0, vbytes, c->stream));               // P (beta = 0 on the first iteration; keep it finite)
+  if (method == 2) HIP_TRY(hipMemsetAsync(n->W[6], 0, vbytes, c->stream));  // V
+  if (nn_spmv(c, 1, X, B, R)) return FX_ERROR_RUNTIME;                   // CG :120 / BiCGSTAB :107
+  if (method == 2) HIP_TRY(hipMemcpyAsync(n->W[1], R, (size_t)nlen * 8, hipMemcpyDeviceToDevice, c->stream));  // r~ = r0
+  if (nn_dot_parts(c, B, B, nullptr, 0, &np) || scalar_stage<OP_BNRM2>(c, np, 0, 50)) return FX_ERROR_RUNTIME;
+  const int chunk = method == 1 ? 16 : 8;
+  KrylovState s;
+  memset(&s, 0, sizeof s);
+  if (MAXIT <= 0) { if (poll_state(c, &s)) return FX_ERROR_RUNTIME; }
+  for (int it = 1; it <= MAXIT; it++) {
+    if (method == 1 ? nn_cg_iteration(c, it, iterpremax) : nn_bicgstab_iteration(c, it, iterpremax)) return FX_ERROR_RUNTIME;
+    if (it % chunk == 0 || it == MAXIT) {
+      if (poll_state(c, &s)) return FX_ERROR_RUNTIME;
+      if (s.status != 0) break;
+    }
+  }
+  if (s.status == 0 && poll_state(c, &s)) return FX_ERROR_RUNTIME;
+  o->iter = s.iter;
+  o->resid = s.resid;
+  o->error = s.status > 1 ? s.status : 0;
+  o->hist.assign((size_t)std::max(0, s.n_hist), 0.0);
+  if (s.n_hist > 0) HIP_TRY(hipMemcpy(o->hist.data(), c->hist, (size_t)s.n_hist * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+static int nn_cg(fx_context *c, int MAXIT, double TOL, int iterpremax, NnResult *o) { return nn_krylov(c, 1, MAXIT, TOL, iterpremax, o); }
+static int nn_bicgstab(fx_context *c, int MAXIT, double TOL, int iterpremax, NnResult *o) { return nn_krylov(c, 2, MAXIT, TOL, iterpremax, o); }
 
 static int nn_scale_bell(fx_context *c, NnBell &b, int back) {
   NnDev *n = nn_of(c);

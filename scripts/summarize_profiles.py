@@ -40,5 +40,5 @@ out.append("k_ssor_color: %d launches = %.1f applies x %d colour sweeps; per app
 open(os.path.join(ROOT, "profiles", "%s_pmc_summary.txt" % tag), "w").write("\n".join(out) + "\n")
 json.dump({"_comment": "HBM traffic per launch from rocprofv3 PMC passes (profiles/%s_pmc_summary.txt): 2*FETCH_SIZE*1024 + WRITE_SIZE*1024, gfx950 correction per MI355X_MICROARCH.md. Keyed by block rows of the workload." % tag,
            "k_spmv": {"3375000": {"traffic_bytes": round(spmv_traffic), "fetch_bytes": round(f / n), "write_bytes": round(w / n), "source": "profiles/%s_pmc_summary.txt" % tag}}},
-          open(os.path.join(ROOT, "profiles", "r01_traffic.json"), "w"), indent=1)
+          open(os.path.join(ROOT, "profiles", "%s_traffic.json" % tag), "w"), indent=1)
 print("\n".join(out[-3:]))
