@@ -27,6 +27,16 @@ for v in variants:
     ctx.precond_setup(m)
     ctxs[v] = ctx
     print("set up", v, flush=True)
+import time
+def cg_ms(ctx, steps=40):
+    m.Iarray[0] = 1000; m.Rarray[0] = 1e-30
+    ctx.krylov_begin(m)
+    ctx.krylov_steps(8)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    ctx.krylov_steps(steps)
+    ctx.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / steps
 for rep in range(3):
     for v in variants:
-        print("rep %d  %-40s precond_apply %.4f ms   spmv(dot) %.4f ms" % (rep, v, ctxs[v].precond_apply_ms(20), ctxs[v].spmv_resident_ms(1, 20)), flush=True)
+        print("rep %d  %-40s precond_apply %.4f ms   spmv(dot) %.4f ms   CG iteration %.4f ms" % (rep, v, ctxs[v].precond_apply_ms(20), ctxs[v].spmv_resident_ms(1, 20), cg_ms(ctxs[v])), flush=True)
