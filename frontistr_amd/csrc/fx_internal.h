@@ -169,6 +169,8 @@ struct NlDev {
   double *bc_v = nullptr;
   int32_t bc_cap = 0;
   int32_t *err = nullptr;
+  double maxres = 1.0e10;  // step_ctrl%maxres (m_step.f90:78): Newton gives up when rres exceeds it
+  bool is_linear = false;   // fstr_Newton's isLinear: one pass, no convergence test
   int latch = 0;  // MatlMatrix's saved `flag` (calMatMatrix.f90:39): set by the first elastoplastic stress update
 };
 

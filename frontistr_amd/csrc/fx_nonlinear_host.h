@@ -378,7 +378,7 @@ extern "C" int fx_newton_substep(fx_context *c, double factor0, double factor1, 
   for (int32_t k = 0; k < n_bc; k++) inc[k] = bc_val[k] * (factor1 - factor0);
   int e = fx_nl_begin_substep(c, cload ? gl.data() : nullptr);
   if (e) return e;
-  bool done = false;
+  bool done = false, blown = false;
   int32_t it = 0;
   for (it = 1; it <= max_iter; it++) {
     e = fx_nl_stiffness(c, n_bc, bc_node, bc_dof, it == 1 ? inc.data() : zero.data(), nullptr);
@@ -400,16 +400,26 @@ extern "C" int fx_newton_substep(fx_context *c, double factor0, double factor1, 
       double *l = log + (size_t)7 * (it - 1);
       l[0] = it; l[1] = info.iterations; l[2] = code; l[3] = res; l[4] = xnrm; l[5] = qnrm; l[6] = dunrm;
     }
+    if (c->nl.is_linear) { done = true; break; }  // `if( isLinear ) exit` (:107): a linear analysis takes one pass, no convergence test
     if (Iarray[80] == 1) {  // hecmw_mat_get_flag_converged (:132-135)
       if (res / qnrm < converg) done = true;
       if (xnrm / dunrm < converg) done = true;
     }
     if (done) break;
+    if (res / qnrm > c->nl.maxres) { blown = true; break; }  // `rres > maxres` (:140): give up at once, the caller cuts back (knstDRESN = 2)
   }
   if (n_iter) *n_iter = std::min(it, max_iter);
+  if (blown) return FX_NEWTON_MAXRES;  // like the reference's `return`: nothing is committed
   if (done || commit_unconverged) {
     e = fx_nl_commit(c);
     if (e) return e;
   }
   return done ? 0 : FX_ERROR_NOCONV_MAXIT;
+}
+
+// step_ctrl(cstep)%maxres (m_step.f90:31, default 1.d+10 :78) and fstr_Newton's isLinear (.not. fstrPR%nlgeom, :50-51).
+extern "C" int fx_nl_set_step_control(fx_context *c, double maxres, int is_linear) {
+  c->nl.maxres = maxres > 0.0 ? maxres : 1.0e10;
+  c->nl.is_linear = is_linear != 0;
+  return 0;
 }

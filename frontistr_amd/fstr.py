@@ -154,8 +154,17 @@ def fstr_Newton(fstrSOLID, hecMAT, factor, bc, cload, max_iter, converg, commit_
     code = lib().fx_newton_substep(fstrSOLID.ctx.h, C.c_double(factor[0]), C.c_double(factor[1]), int(bn.size), _ptr(bn),
                                    _ptr(bd), _ptr(bv), _ptr(cl), int(max_iter), C.c_double(converg), _ptr(hecMAT.Iarray),
                                    _ptr(hecMAT.Rarray), _ptr(log), C.byref(nit), int(commit_unconverged))
-    _chk(code, allow=(hecmw.HECMW_SOLVER_ERROR_NOCONV_MAXIT,))
+    _chk(code, allow=(hecmw.HECMW_SOLVER_ERROR_NOCONV_MAXIT, FX_NEWTON_MAXRES))
+    fstrSOLID.last_code = code
     return code == 0, log[:nit.value].copy()
+
+
+FX_NEWTON_MAXRES = 4002
+
+
+def fstr_set_step_control(fstrSOLID, maxres=1.0e10, is_linear=False):
+    """step_ctrl(cstep)%maxres (m_step.f90:31, :78) and fstr_Newton's isLinear (.not. fstrPR%nlgeom)."""
+    _chk(lib().fx_nl_set_step_control(fstrSOLID.ctx.h, C.c_double(maxres), int(is_linear)))
 
 
 def fstr_solve_NLGEOM(fstrSOLID, hecMAT, bc, cload, substeps, max_iter, converg, commit_unconverged=True):

@@ -32,6 +32,7 @@ enum fx_status {
   FX_ERROR_NOCONV_MAXIT = 3001, /* W: not converged within ceratin iterations   */
   FX_ERROR_DIVERGE_MAT = 3002,  /* W: diverged due to indefinite/neg-def matrix */
   FX_ERROR_DIVERGE_PC = 3003,   /* W: diverged due to indefinite preconditioner */
+  FX_NEWTON_MAXRES = 4002,      /* fx_newton_substep: NR residual above step_ctrl%maxres (knstDRESN = 2): cut back */
   FX_ERROR_RUNTIME = -1,        /* HIP / RCCL failure, see fx_last_error()      */
   FX_ERROR_UNSUPPORTED = -2     /* NDOF outside 1..6, or an option outside the hot path */
 };
@@ -234,11 +235,17 @@ int fx_nl_element_tangents(fx_context *ctx, double *ke);
 int fx_nl_element_update(fx_context *ctx, double *qf);
 /* One substep of fstr_Newton around fx_solve_resident.  log: 7 doubles per Newton iteration
  * (iter, solver iterations, solver code, |B|, |X|, |QFORCE|, |dunode|).  Returns 0 (converged),
- * FX_ERROR_NOCONV_MAXIT (max_iter ran out; committed only if commit_unconverged) or an error. */
+ * FX_ERROR_NOCONV_MAXIT (max_iter ran out; committed only if commit_unconverged), FX_NEWTON_MAXRES (residual above maxres,
+ * fx_nl_set_step_control; never committed) or an error. */
 int fx_newton_substep(fx_context *ctx, double factor0, double factor1, int32_t n_bc,
                       const int32_t *bc_node, const int32_t *bc_dof, const double *bc_val,
                       const double *cload, int32_t max_iter, double converg, int32_t *Iarray,
                       double *Rarray, double *log, int32_t *n_iter, int commit_unconverged);
+
+/* step_ctrl(cstep)%maxres (fistr1/src/lib/m_step.f90:31, default 1.d+10): fx_newton_substep returns FX_NEWTON_MAXRES as soon as
+ * |B|/|QFORCE| exceeds it (fstr_solve_NonLinear.f90:140-152, nothing committed); is_linear = fstr_Newton's isLinear
+ * (.not. fstrPR%nlgeom, :50-51, :107): one pass without a convergence test. */
+int fx_nl_set_step_control(fx_context *ctx, double maxres, int is_linear);
 
 /* ---- multi-GPU (one process per GPU, RCCL over xGMI) -------------------- */
 /* 128-byte ncclUniqueId made by rank 0 and broadcast by the host side

@@ -311,3 +311,40 @@ def test_load_steps_with_bicgstab_ilu0(hip, oracle):
     _close(st["stress"], model.state["stress"], 1e-6, "stress")
     assert np.array_equal(st["istat"], model.state["istat"]) and model.state["plstrain"].max() > 1e-3
     ctx.close()
+
+
+def test_newton_exits_maxres_and_linear(hip):
+    """The two exits of fstr_Newton besides convergence and MAXITER (fstr_solve_NonLinear.f90:107, :140-152): a linear analysis
+    (isLinear = .not. nlgeom) leaves after one pass without a convergence test and commits; a residual above
+    step_ctrl%maxres returns at once (FX_NEWTON_MAXRES, the caller cuts back) with nothing committed."""
+    from frontistr_amd import fstr
+    T = _T()
+    mat = T.materials()["mises_multilinear_ul"]
+    m = CubeMesh(4, skew=0.1)
+    bn, bd, bv = m.dirichlet()
+    tn = np.repeat(m.top_nodes, 3).astype(np.int32)
+    td = np.tile(np.array([1, 2, 3], dtype=np.int32), m.top_nodes.size)
+    tv = np.tile(np.array([0.03, 0.0, 0.15]), m.top_nodes.size)
+    bc = (np.concatenate([bn, tn]), np.concatenate([bd, td]), np.concatenate([bv, tv]))
+    ctx, hecMAT, solid = _solid(hip, mat, m)
+    hecMAT.Iarray[0] = 10000; hecMAT.Iarray[1] = 1; hecMAT.Iarray[2] = 1; hecMAT.Rarray[0] = 1e-10
+    # (1) maxres: the plastic first iteration leaves a relative residual of order 0.1-1; a bound of 1e-6 is exceeded at once
+    fstr.fstr_set_step_control(solid, maxres=1e-6)
+    ok, log = fstr.fstr_Newton(solid, hecMAT, (0.0, 1.0), bc, None, 20, 1e-12, True)
+    assert not ok and solid.last_code == fstr.FX_NEWTON_MAXRES and log.shape[0] == 1
+    assert log[0, 3] / log[0, 5] > 1e-6
+    assert np.abs(solid.get_state(("unode",))["unode"]).max() == 0.0          # nothing committed
+    # (2) the default bound (1.d+10) lets the same substep run its iterations
+    fstr.fstr_set_step_control(solid)
+    ok, log2 = fstr.fstr_Newton(solid, hecMAT, (0.0, 1.0), bc, None, 4, 1e-12, False)
+    assert log2.shape[0] == 4 and solid.last_code == hip.HECMW_SOLVER_ERROR_NOCONV_MAXIT
+    ctx.close()
+    # (3) isLinear: one pass, committed, whatever the residual
+    ctx, hecMAT, solid = _solid(hip, T.materials()["elastic_ul"], m)
+    hecMAT.Iarray[0] = 10000; hecMAT.Iarray[1] = 1; hecMAT.Iarray[2] = 3; hecMAT.Rarray[0] = 1e-10
+    fstr.fstr_set_step_control(solid, is_linear=True)
+    ok, log3 = fstr.fstr_Newton(solid, hecMAT, (0.0, 1.0), bc, None, 20, 1e-30, False)
+    assert ok and log3.shape[0] == 1
+    u = solid.get_state(("unode",))["unode"].reshape(-1, 3)
+    assert np.abs(u[m.top_nodes - 1] - np.array([0.03, 0.0, 0.15])).max() < 1e-9     # committed: the prescribed top displacement
+    ctx.close()
