@@ -261,6 +261,7 @@ extern "C" int fx_create(int device, fx_context **out) {
   if (const char *e = getenv("FX_SPMV_SPATIAL")) c->spmv_spatial = atoi(e) != 0;
   if (const char *e = getenv("FX_GRAPH")) c->graph_mode = atoi(e);
   if (const char *e = getenv("FX_OVERLAP")) c->overlap = atoi(e) != 0;
+  if (const char *e = getenv("FX_EISENSTAT")) c->eisenstat = atoi(e) != 0;
   if (const char *e = getenv("FX_SPLIT_MAX_SLICES")) c->split_max_slices = atoi(e);
   if (const char *e = getenv("FX_DATAFLOW")) c->df_mode = atoi(e);
   if (const char *e = getenv("FX_DF_GRID")) c->df_grid = atoi(e);
@@ -304,7 +305,7 @@ static void free_matrix(fx_context *c) {
 static void free_precond(fx_context *c) {
   dev_free(c->diag.alu);
   bell_free(c->ssor.L); bell_free(c->ssor.U);
-  dev_free(c->ssor.alu); dev_free(c->ssor.slot_node); dev_free(c->ssor.zs); dev_free(c->ssor.zb);
+  dev_free(c->ssor.alu); dev_free(c->ssor.dblk); dev_free(c->ssor.slot_node); dev_free(c->ssor.zs); dev_free(c->ssor.zb);
   dev_free(c->ssor.lu_D); dev_free(c->ssor.lu_AL); dev_free(c->ssor.lu_AU);
   c->ssor = SsorDev();
   c->precond_valid = false;
@@ -946,15 +947,16 @@ static int spmv(fx_context *c, int mode, int dot, double *x, const double *b, do
 static inline int spmv_nparts(fx_context *c) { return (c->M.nslices + c->spmv_bs / 64 - 1) / (c->spmv_bs / 64); }
 
 template <int OP>
-static int scalar_stage(fx_context *c, int nparts, int stride, int recompute_every) {
+static int scalar_stage(fx_context *c, int nparts, int stride, int recompute_every, const double *parts = nullptr) {
+  if (!parts) parts = c->partials;
   if (multi_rank(c)) {
-    hipLaunchKernelGGL((k_scalar<OP>), dim3(1), dim3(1024), 0, c->stream, c->partials, nparts, stride, c->st, c->hist,
+    hipLaunchKernelGGL((k_scalar<OP>), dim3(1), dim3(1024), 0, c->stream, parts, nparts, stride, c->st, c->hist,
                        c->red_out, 1, recompute_every);
     if (allreduce_dev(c, c->red_out, 2)) return FX_ERROR_RUNTIME;
-    hipLaunchKernelGGL((k_scalar<OP>), dim3(1), dim3(64), 0, c->stream, c->partials, nparts, stride, c->st, c->hist,
+    hipLaunchKernelGGL((k_scalar<OP>), dim3(1), dim3(64), 0, c->stream, parts, nparts, stride, c->st, c->hist,
                        c->red_out, 2, recompute_every);
   } else {
-    hipLaunchKernelGGL((k_scalar<OP>), dim3(1), dim3(1024), 0, c->stream, c->partials, nparts, stride, c->st, c->hist,
+    hipLaunchKernelGGL((k_scalar<OP>), dim3(1), dim3(1024), 0, c->stream, parts, nparts, stride, c->st, c->hist,
                        c->red_out, 0, recompute_every);
   }
   HIP_TRY(hipGetLastError());
@@ -1129,6 +1131,11 @@ static int ssor_setup_numeric(fx_context *c, double sigma_diag) {
   const int nslots = S.L.nslices * 64;
   hipLaunchKernelGGL(k_alu_setup, dim3((nslots + 255) / 256), dim3(256), 0, c->stream, nslots, c->A.N, S.slot_node, c->A.D,
                      sigma_diag, S.alu);
+  S.sigma_diag = sigma_diag;
+  if (c->eisenstat) {  // Eisenstat form: the diagonal blocks themselves, next to their factors
+    if (!S.dblk && dev_alloc(&S.dblk, (size_t)(nslots / 64) * 576)) return FX_ERROR_RUNTIME;
+    hipLaunchKernelGGL(k_dblk_setup, dim3((nslots + 255) / 256), dim3(256), 0, c->stream, nslots, c->A.N, S.slot_node, c->A.D, S.dblk);
+  }
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1459,6 +1466,120 @@ static int poll_state(fx_context *c, KrylovState *out) {
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// Eisenstat's form of CG + multicolour SSOR (opt-in, fx_context::eisenstat; kernels and recurrences: fx_kernels.h).
+// Vectors: R W[0], P W[1], PH W[2] (= (D~+U) p), T W[3] (= (D~+L)^-1 r), DT W[4] (= D~ t), V W[5], WH W[6] (= (D~+L)^-1 A p), Q W[7].
+// Partial sums: ||r||^2 and ph.w in region 0 of c->partials, rho = t.dt in region 1 (it is consumed one scalar stage later).
+// ---------------------------------------------------------------------------
+static int eis_sweep_backward(fx_context *c, const double *rhs, double *out, const int32_t *gate) {  // out = (D~+U)^-1 rhs
+  SsorDev &S = c->ssor;
+  const int spb = c->ssor_bs / 64;
+  for (int col = S.ncolor - 1; col >= 0; col--) {
+    const int s0 = S.color_slice[col], s1 = S.color_slice[col + 1];
+    if (s1 <= s0) continue;
+    if (s1 - s0 <= c->split_max_slices)
+      hipLaunchKernelGGL((k_ssor_color_split<true, 4>), dim3(s1 - s0), dim3(256), 0, c->stream, s0, s1, S.U.pair_ptr, S.U.val2, S.U.col2,
+                         (const int32_t *)nullptr, S.alu, rhs, out, (double *)nullptr, (double *)nullptr, gate);
+    else if (c->ssor_bs == 64)
+      hipLaunchKernelGGL((k_ssor_color<true, true, 64>), dim3((s1 - s0 + spb - 1) / spb), dim3(64), 0, c->stream, s0, s1, S.U.pair_ptr,
+                         S.U.val2, S.U.col2, (const int32_t *)nullptr, S.alu, rhs, out, (double *)nullptr, (double *)nullptr, gate);
+    else
+      hipLaunchKernelGGL((k_ssor_color<true, true, 256>), dim3((s1 - s0 + spb - 1) / spb), dim3(256), 0, c->stream, s0, s1, S.U.pair_ptr,
+                         S.U.val2, S.U.col2, (const int32_t *)nullptr, S.alu, rhs, out, (double *)nullptr, (double *)nullptr, gate);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+static int eis_sweep_forward_solve(fx_context *c, const double *rhs, double *out, const int32_t *gate) {  // out = (D~+L)^-1 rhs
+  SsorDev &S = c->ssor;
+  const int spb = c->ssor_bs / 64;
+  for (int col = 0; col < S.ncolor; col++) {
+    const int s0 = S.color_slice[col], s1 = S.color_slice[col + 1];
+    if (s1 <= s0) continue;
+    if (s1 - s0 <= c->split_max_slices)
+      hipLaunchKernelGGL((k_ssor_color_split<true, 4>), dim3(s1 - s0), dim3(256), 0, c->stream, s0, s1, S.L.pair_ptr, S.L.val2, S.L.col2,
+                         (const int32_t *)nullptr, S.alu, rhs, out, (double *)nullptr, (double *)nullptr, gate);
+    else if (c->ssor_bs == 64)
+      hipLaunchKernelGGL((k_ssor_color<true, true, 64>), dim3((s1 - s0 + spb - 1) / spb), dim3(64), 0, c->stream, s0, s1, S.L.pair_ptr,
+                         S.L.val2, S.L.col2, (const int32_t *)nullptr, S.alu, rhs, out, (double *)nullptr, (double *)nullptr, gate);
+    else
+      hipLaunchKernelGGL((k_ssor_color<true, true, 256>), dim3((s1 - s0 + spb - 1) / spb), dim3(256), 0, c->stream, s0, s1, S.L.pair_ptr,
+                         S.L.val2, S.L.col2, (const int32_t *)nullptr, S.alu, rhs, out, (double *)nullptr, (double *)nullptr, gate);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+// t = (D~+L)^-1 r, dt = D~ t, partials of rho = t.dt -> region 1
+static int eis_refresh_t(fx_context *c, const int32_t *gate) {
+  SsorDev &S = c->ssor;
+  const int32_t ns = c->ord.nslots;
+  if (eis_sweep_forward_solve(c, c->W[0], c->W[3], gate)) return FX_ERROR_RUNTIME;
+  hipLaunchKernelGGL((k_eis_update<0>), dim3((ns + FX_BLOCK - 1) / FX_BLOCK), dim3(FX_BLOCK), 0, c->stream, ns, c->st, S.dblk,
+                     S.sigma_diag - 1.0, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, (double *)nullptr,
+                     (double *)nullptr, c->W[3], c->W[4], c->partials, c->partials + c->max_partials, gate);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+static int eis_begin(fx_context *c) {  // after the standard begin (r0 = b - A x0 in W[0], ||b||^2)
+  for (int k : {1, 2, 5, 6, 7}) HIP_TRY(hipMemsetAsync(c->W[k], 0, (size_t)c->wlen * 8, c->stream));
+  HIP_TRY(hipMemsetAsync(c->W[3], 0, (size_t)c->wlen * 8, c->stream));
+  return eis_refresh_t(c, nullptr);
+}
+static int eis_cg_iteration(fx_context *c, int it) {
+  SsorDev &S = c->ssor;
+  const int32_t ns = c->ord.nslots;
+  const int64_t n3 = (int64_t)3 * ns;
+  double *R = c->W[0], *P = c->W[1], *PH = c->W[2], *T = c->W[3], *DT = c->W[4], *V = c->W[5], *WH = c->W[6], *Q = c->W[7];
+  double *X = c->Xs, *B = c->Bs;
+  const int RECOMPUTE = 50, vgrid = grid_for(n3, FX_BLOCK, 2048), ugrid = (ns + FX_BLOCK - 1) / FX_BLOCK;
+  const double sm1 = S.sigma_diag - 1.0;
+  double *part_rho = c->partials + c->max_partials;
+  // rho = r.M^-1 r = t.D~t (:168), beta (:193); ph = D~ t + beta ph  [= (D~+U)(z + beta p)]
+  if (scalar_stage<OP_CG_RHO>(c, ugrid, 0, RECOMPUTE, part_rho)) return FX_ERROR_RUNTIME;
+  hipLaunchKernelGGL(k_cg_update_p, dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, n3, c->st, DT, PH);
+  // p = (D~+U)^-1 ph
+  if (eis_sweep_backward(c, PH, P, gate_status(c))) return FX_ERROR_RUNTIME;
+  // one pass over L: v, w = (D~+L)^-1 A p, q = A p, partial of p.q = ph.w (:204-211)
+  {
+    const int spb = c->ssor_bs / 64;
+    int off = 0;
+    for (int col = 0; col < S.ncolor; col++) {
+      const int s0 = S.color_slice[col], s1 = S.color_slice[col + 1];
+      if (s1 <= s0) continue;
+      const int g = (s1 - s0 + spb - 1) / spb;
+      if (c->ssor_bs == 64)
+        hipLaunchKernelGGL((k_eis_forward<64>), dim3(g), dim3(64), 0, c->stream, s0, s1, S.L.pair_ptr, S.L.val2, S.L.col2, S.alu, S.dblk,
+                           sm1, PH, P, V, WH, Q, c->partials, off, gate_status(c));
+      else
+        hipLaunchKernelGGL((k_eis_forward<256>), dim3(g), dim3(256), 0, c->stream, s0, s1, S.L.pair_ptr, S.L.val2, S.L.col2, S.alu, S.dblk,
+                           sm1, PH, P, V, WH, Q, c->partials, off, gate_status(c));
+      off += g;
+    }
+    HIP_TRY(hipGetLastError());
+    if (off > c->max_partials) { g_fx_error = "eisenstat: partial-sum buffer too small"; return FX_ERROR_RUNTIME; }
+    if (scalar_stage<OP_CG_C1>(c, off, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
+  }
+  int np;
+  if (it % RECOMPUTE == 0) {  // x += alpha p ; r = b - A x (:232-233) ; t, dt, rho from the new r
+    hipLaunchKernelGGL((k_eis_update<2>), dim3(ugrid), dim3(FX_BLOCK), 0, c->stream, ns, c->st, S.dblk, sm1, P, Q, WH, X, R, T, DT,
+                       c->partials, part_rho, gate_status(c));
+    if (spmv(c, 1, 2, X, B, R, gate_status(c), 0)) return FX_ERROR_RUNTIME;
+    np = spmv_nparts(c);
+    if (scalar_stage<OP_RESID>(c, np, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
+    if (eis_refresh_t(c, gate_status(c))) return FX_ERROR_RUNTIME;  // overwrites region 0 after OP_RESID has consumed it
+  } else {
+    hipLaunchKernelGGL((k_eis_update<1>), dim3(ugrid), dim3(FX_BLOCK), 0, c->stream, ns, c->st, S.dblk, sm1, P, Q, WH, X, R, T, DT,
+                       c->partials, part_rho, gate_status(c));
+    if (scalar_stage<OP_RESID>(c, ugrid, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
+    // converged by the recurrence: true residual, re-test (:259-266); if the loop goes on, r IS the true residual now: refresh t
+    if (spmv(c, 1, 2, X, B, R, gate_verify(c), 1)) return FX_ERROR_RUNTIME;
+    if (scalar_stage<OP_VERIFY>(c, spmv_nparts(c), 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
+    if (eis_refresh_t(c, &c->st->t_current)) return FX_ERROR_RUNTIME;  // runs only while t_current == 0 (set by OP_VERIFY, cleared by OP_CG_RHO)
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // hecmw_solve_CG (hecmw_solver_CG.f90:19-312) / hecmw_solve_BiCGSTAB (hecmw_solver_BiCGSTAB.f90:16-297)
 // split into begin (r0, ||b||) / steps (n iterations enqueued) / poll, so that callers can
 // time an exact number of iterations with nothing else in the bracket.
@@ -1488,10 +1609,15 @@ static int krylov_begin(fx_context *c, int method, int maxit, double tol) {
   if (dot_into_partials(c, B, B, nullptr, 0, &np)) return FX_ERROR_RUNTIME;
   if (scalar_stage<OP_BNRM2>(c, np, 0, 50)) return FX_ERROR_RUNTIME;
   HIP_TRY(hipGetLastError());
+  // Eisenstat's form: CG + multicolour SSOR(1) on one rank in the colour-major numbering, when asked for
+  c->eis_active = c->eisenstat && method == 1 && c->precond_kind == 1 && c->ord.kind == 1 && c->iterpremax == 1 && c->ssor.dblk &&
+                  !halo_active(c) && !multi_rank(c);
+  if (c->eis_active) { c->k_graph = false; if (eis_begin(c)) return FX_ERROR_RUNTIME; }
   return 0;
 }
 
 static int cg_iteration(fx_context *c, int it) {
+  if (c->eis_active) return eis_cg_iteration(c, it);
   const int64_t n3 = (int64_t)3 * c->ord.nslots;
   double *R = c->W[0], *Z = c->W[1], *Q = c->W[1], *P = c->W[2];
   double *X = c->Xs, *B = c->Bs;
@@ -2059,6 +2185,7 @@ extern "C" int fx_get_stats(fx_context *c, int64_t out[16]) {
   out[8] = c->ssor.L.npairs; out[9] = c->ssor.L.nblocks; out[10] = c->ssor.U.npairs; out[11] = c->ssor.U.nblocks;
   out[12] = c->ssor.L.nslices;
   out[13] = c->M.n_wg_interior; out[14] = c->M.n_wg_boundary;  // SpMV workgroups overlapped with / ordered after the halo exchange
+  out[15] = c->eis_active ? 1 : 0;                              // the last Krylov loop ran in Eisenstat's form
   return 0;
 }
 

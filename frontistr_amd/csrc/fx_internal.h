@@ -88,6 +88,8 @@ struct SsorDev {
   std::vector<int32_t> color_slice;  // slice range per colour: [color_slice[c], color_slice[c+1])
   Bell L, U;                         // strictly-lower / strictly-upper parts in colour-slot order
   double *alu = nullptr;             // LU of the diagonal blocks, [slice][e][lane] layout
+  double *dblk = nullptr;            // Eisenstat form: the diagonal blocks themselves (unfactored, unscaled), same layout
+  double sigma_diag = 1.0;           // SIGMA_DIAG the factors in alu were built with
   int32_t nslots = 0;                // colour-major slots (each colour padded to a 64 multiple)
   int32_t *slot_node = nullptr;      // device: slot -> 0-based node, -1 = padding
   double *zs = nullptr;              // private sweep vector, 3*nslots, colour-major
@@ -114,7 +116,7 @@ struct KrylovState {
   int32_t maxit;
   int32_t error;        // 3001 set while running (reference sets error and falls out of the DO)
   int32_t n_hist;       // residual-history lines written (the ITERLOG lines the reference would have printed)
-  int32_t pad[1];
+  int32_t t_current;    // Eisenstat form: 1 = t = (D~+L)^-1 r is current; 0 = r was replaced by the true residual, refresh t (set by OP_VERIFY, cleared by OP_CG_RHO)
 };
 
 struct HaloDev {
@@ -242,6 +244,12 @@ struct fx_context {
   // non-temporal stream loads): SpMV 1.14-1.17 -> 1.105-1.11 ms; colour sweeps 1.685 -> 1.61 ms per apply.
   // (With the earlier padded layout it cost the SpMV 1.19 -> 1.30 ms: re-measure when the layout changes.)
   bool pipe_spmv = true, pipe_ssor = true;  // FX_PIPE_SPMV / FX_PIPE_SSOR override
+  // Eisenstat's form of CG + SSOR (opt-in, FX_EISENSTAT=1): with M = (D~+L) D~^-1 (D~+U) and A = (D~+L) + (D~+U) + (D - 2D~),
+  // one backward and one forward triangular sweep per iteration deliver p, q = A p and w = (D~+L)^-1 q -- the matrix is
+  // streamed ONCE instead of twice (SpMV + the two half sweeps).  Same x_k, r_k, rho_k, alpha_k in exact arithmetic; the
+  // summation order of q and of the dot products differs, so histories agree to rounding, not bit for bit: hence opt-in.
+  // Single rank, multicolour SSOR with iterPREmax = 1, colour-major numbering; anything else runs the standard loop.
+  bool eisenstat = false, eis_active = false;
   // Placement search of the SpMV's value array.  The identical kernel on identical data runs at 1.03-1.19 ms (10.1M DOF)
   // depending on WHERE hipMalloc put the 6.5 GB value array physically: same virtual layout, same alignment, different speed
   // (scripts/experiments/ab_ssor.py with FX_DUMMY_MB / FX_PLACEMENT_DEBUG).  So the library measures: up to tune_tries

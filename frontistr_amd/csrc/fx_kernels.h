@@ -482,6 +482,148 @@ __global__ __launch_bounds__(64 * WPS) void k_ssor_color_split(int32_t slice0, i
 }
 
 // ------------------------------------------------------------------------
+// Eisenstat's form of CG + multicolour SSOR (opt-in; fx_context::eisenstat).  Per iteration, with ph = (D~+U) p carried
+// instead of p:   ph = D~ t + beta ph                      (k_cg_update_p on (dt, ph))
+//                 p  = (D~+U)^-1 ph                        (backward sweep = k_ssor_color<FWD> on the U layout, colours descending)
+//                 v  = (D~+L)^-1 (ph + (D - 2D~) p),  w = p + v = (D~+L)^-1 A p,  q = ph + L p + (D - D~) p = A p
+//                                                           (k_eis_forward: ONE pass over the L layout, two gathers per block)
+//                 alpha = rho / (ph . w)                    (p.q = p.(D~+L) w = ((D~+U) p).w for a symmetric matrix)
+//                 x += alpha p; r -= alpha q; t -= alpha w; dt = D~ t; rho' = t.dt  (= r.M^-1 r)      (k_eis_update)
+// L / U = strictly lower / upper part in the colour ordering, halo columns dropped (single rank: none exist).
+// ------------------------------------------------------------------------
+template <int BS>
+__global__ __launch_bounds__(BS) void k_eis_forward(int32_t slice0, int32_t slice1, const int32_t *__restrict__ pair_ptr,
+                                                    const double *__restrict__ val2, const int *__restrict__ col2,
+                                                    const double *__restrict__ alu, const double *__restrict__ dblk, double sm1,
+                                                    const double *__restrict__ ph, const double *__restrict__ p,
+                                                    double *__restrict__ v, double *__restrict__ w, double *__restrict__ q,
+                                                    double *__restrict__ partials, int32_t part0, const int32_t *__restrict__ gate) {
+  if (gate && *gate != 0) return;
+  const int vb = xcd_block(blockIdx.x, gridDim.x);
+  const int slice = slice0 + vb * (BS / 64) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  double d[1] = {0.0};
+  if (slice < slice1) {
+    const int slot = slice * 64 + lane;
+    const int h0 = pair_ptr[slice], h1 = pair_ptr[slice + 1];
+    const int np = (h1 - h0) >> 1;
+    double sv0 = 0.0, sv1 = 0.0, sv2 = 0.0, sp0 = 0.0, sp1 = 0.0, sp2 = 0.0;
+    if ((h1 - h0) & 1) {  // odd last block of the slice, stored alone
+      const double *vt = val2 + (size_t)(h0 + 2 * np) * 576 + lane;
+      const int cc = ld_stream(col2 + (size_t)(h0 + 2 * np) * 64 + lane);
+      double a[9];
+#pragma unroll
+      for (int e = 0; e < 9; e++) a[e] = ld_stream(vt + e * 64);
+      const double xv[3] = {v[(size_t)3 * cc], v[(size_t)3 * cc + 1], v[(size_t)3 * cc + 2]};
+      const double xp[3] = {p[(size_t)3 * cc], p[(size_t)3 * cc + 1], p[(size_t)3 * cc + 2]};
+      bell_single_fma(a, xv, sv0, sv1, sv2);
+      bell_single_fma(a, xp, sp0, sp1, sp2);
+    }
+    const double2 *vp = (const double2 *)(val2 + (size_t)h0 * 576) + lane;
+    const int2 *cp = (const int2 *)(col2 + (size_t)h0 * 64) + lane;
+    for (int i = 0; i < np; i++, vp += 576, cp += 64) {
+      const int2 cc = ld_stream(cp);
+      double2 a[9];
+#pragma unroll
+      for (int e = 0; e < 9; e++) a[e] = ld_stream(vp + e * 64);
+      const double *va = v + (size_t)3 * cc.x, *vb2 = v + (size_t)3 * cc.y, *pa = p + (size_t)3 * cc.x, *pb = p + (size_t)3 * cc.y;
+      const double xv[6] = {va[0], va[1], va[2], vb2[0], vb2[1], vb2[2]};
+      const double xp[6] = {pa[0], pa[1], pa[2], pb[0], pb[1], pb[2]};
+      bell_pair_fma(a, xv, sv0, sv1, sv2);
+      bell_pair_fma(a, xp, sp0, sp1, sp2);
+    }
+    double u[9], D[9];
+    const size_t base = (size_t)slice * 576 + lane;
+#pragma unroll
+    for (int e = 0; e < 9; e++) { u[e] = alu[base + (size_t)e * 64]; D[e] = dblk[base + (size_t)e * 64]; }
+    const double p0 = p[(size_t)3 * slot], p1 = p[(size_t)3 * slot + 1], p2 = p[(size_t)3 * slot + 2];
+    const double h0v = ph[(size_t)3 * slot], h1v = ph[(size_t)3 * slot + 1], h2v = ph[(size_t)3 * slot + 2];
+    const double Dp0 = D[0] * p0 + D[1] * p1 + D[2] * p2, Dp1 = D[3] * p0 + D[4] * p1 + D[5] * p2, Dp2 = D[6] * p0 + D[7] * p1 + D[8] * p2;
+    const double e0 = sm1 * D[0] * p0, e1 = sm1 * D[4] * p1, e2 = sm1 * D[8] * p2;  // (D~ - D) p: SIGMA_DIAG scales the three scalar diagonal entries only
+    // g = ph + (D - 2 D~) p = ph - D p - 2 (D~ - D) p ;  v = D~^-1 (g - L v)
+    double x1 = h0v - Dp0 - 2.0 * e0 - sv0, x2 = h1v - Dp1 - 2.0 * e1 - sv1, x3 = h2v - Dp2 - 2.0 * e2 - sv2;
+    lusolve33_dev(u, x1, x2, x3);
+    v[(size_t)3 * slot] = x1; v[(size_t)3 * slot + 1] = x2; v[(size_t)3 * slot + 2] = x3;
+    const double w0 = p0 + x1, w1 = p1 + x2, w2 = p2 + x3;
+    w[(size_t)3 * slot] = w0; w[(size_t)3 * slot + 1] = w1; w[(size_t)3 * slot + 2] = w2;
+    // q = A p = ph + L p + (D - D~) p
+    q[(size_t)3 * slot] = h0v + sp0 - e0; q[(size_t)3 * slot + 1] = h1v + sp1 - e1; q[(size_t)3 * slot + 2] = h2v + sp2 - e2;
+    d[0] = h0v * w0 + h1v * w1 + h2v * w2;
+  }
+  block_sum_store<1, BS>(d, partials, 0, part0 + vb);
+}
+
+// dt = D~ t and the partial of rho = t.dt; MODE 1 also x += alpha p, r -= alpha q (+ partial ||r||^2), t -= alpha w first;
+// MODE 2: x += alpha p only (the iterations that recompute r = b - A x).  One thread per slot, blocks in [slice][e][lane] layout.
+template <int MODE>
+__global__ __launch_bounds__(FX_BLOCK) void k_eis_update(int32_t nslots, const KrylovState *__restrict__ st,
+                                                         const double *__restrict__ dblk, double sm1, const double *__restrict__ p,
+                                                         const double *__restrict__ q, const double *__restrict__ w,
+                                                         double *__restrict__ x, double *__restrict__ r, double *__restrict__ t,
+                                                         double *__restrict__ dt, double *__restrict__ part_rr,
+                                                         double *__restrict__ part_rho, const int32_t *__restrict__ gate) {
+  if (gate && *gate != 0) return;
+  const int slot = blockIdx.x * FX_BLOCK + threadIdx.x;
+  double d[2] = {0.0, 0.0};
+  if (slot < nslots) {
+    const size_t o = (size_t)3 * slot;
+    if (MODE == 2) {
+      const double alpha = st->alpha;
+      x[o] += alpha * p[o]; x[o + 1] += alpha * p[o + 1]; x[o + 2] += alpha * p[o + 2];
+    } else {
+      double t0 = t[o], t1 = t[o + 1], t2 = t[o + 2];
+      if (MODE == 1) {
+        const double alpha = st->alpha;
+        x[o] += alpha * p[o]; x[o + 1] += alpha * p[o + 1]; x[o + 2] += alpha * p[o + 2];
+        const double r0 = r[o] - alpha * q[o], r1 = r[o + 1] - alpha * q[o + 1], r2 = r[o + 2] - alpha * q[o + 2];
+        r[o] = r0; r[o + 1] = r1; r[o + 2] = r2;
+        d[0] = r0 * r0 + r1 * r1 + r2 * r2;
+        t0 -= alpha * w[o]; t1 -= alpha * w[o + 1]; t2 -= alpha * w[o + 2];
+        t[o] = t0; t[o + 1] = t1; t[o + 2] = t2;
+      }
+      double D[9];
+      const size_t base = (size_t)(slot >> 6) * 576 + (slot & 63);
+#pragma unroll
+      for (int e = 0; e < 9; e++) D[e] = dblk[base + (size_t)e * 64];
+      const double y0 = D[0] * t0 + D[1] * t1 + D[2] * t2 + sm1 * D[0] * t0;
+      const double y1 = D[3] * t0 + D[4] * t1 + D[5] * t2 + sm1 * D[4] * t1;
+      const double y2 = D[6] * t0 + D[7] * t1 + D[8] * t2 + sm1 * D[8] * t2;
+      dt[o] = y0; dt[o + 1] = y1; dt[o + 2] = y2;
+      d[1] = t0 * y0 + t1 * y1 + t2 * y2;
+    }
+  }
+  if (MODE == 2) return;
+  __shared__ double sm[2][FX_BLOCK / 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const double s0 = wave_sum(d[0]), s1 = wave_sum(d[1]);
+  if (lane == 0) { sm[0][wv] = s0; sm[1][wv] = s1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int k = 0; k < FX_BLOCK / 64; k++) { a += sm[0][k]; b += sm[1][k]; }
+    if (MODE == 1) part_rr[blockIdx.x] = a;
+    part_rho[blockIdx.x] = b;
+  }
+}
+
+// the diagonal blocks themselves in the [slice][e][lane] layout of the factors (padding slots: identity)
+__global__ void k_dblk_setup(int32_t nslots, int32_t nrows, const int32_t *__restrict__ slot_row, const double *__restrict__ D,
+                             double *__restrict__ dblk) {
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= nslots) return;
+  const int row = slot_row ? slot_row[slot] : slot;
+  double a[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if (row >= 0 && row < nrows) {
+#pragma unroll
+    for (int e = 0; e < 9; e++) a[e] = D[(size_t)9 * row + e];
+  }
+  const size_t base = (size_t)(slot >> 6) * 576 + (slot & 63);
+#pragma unroll
+  for (int e = 0; e < 9; e++) dblk[base + (size_t)e * 64] = a[e];
+}
+
+// ------------------------------------------------------------------------
 // Dataflow triangular sweeps: ONE persistent launch per preconditioner apply instead of one launch per colour / per
 // ILU(0) dependency level (1,044 levels x 2 half sweeps at 10M DOF; each level is ~50 slices, i.e. a few microseconds
 // of dependent latency and almost no bandwidth).  There is no grid barrier either: the DATA is the flag.  Both sweep
@@ -1081,6 +1223,7 @@ __global__ void k_scalar(const double *__restrict__ partials, int32_t nparts, in
     st->bnrm2 = v0;
     if (v0 == 0.0) { st->status = 1; st->resid = 0.0; st->iter = 1; }  // MAXIT=0: DO leaves ITER=1
   } else if (OP == OP_CG_RHO) {
+    st->t_current = 1;
     st->rho = v0;
     if (v0 == 0.0) { st->status = 1; return; }
     if (st->iter > 1 && v0 * st->rho1 <= 0.0) {
@@ -1115,6 +1258,7 @@ __global__ void k_scalar(const double *__restrict__ partials, int32_t nparts, in
     } else {
       st->need_verify = 0;
       if (resid <= st->tol) { st->status = 1; return; }
+      st->t_current = 0;  // r now holds the true residual and the loop goes on: the Eisenstat form refreshes t from it
     }
     if (it == st->maxit) { st->error = FX_ERROR_NOCONV_MAXIT; st->status = FX_ERROR_NOCONV_MAXIT; st->iter = it + 1; return; }
     st->rho1 = st->rho;

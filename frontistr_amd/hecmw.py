@@ -248,7 +248,7 @@ class SolverContext:
         out = (C.c_int64 * 16)()
         _chk(lib().fx_get_stats(self.h, out))
         keys = ("N", "NP", "NPL", "NPU", "M_pairs", "M_blocks", "M_slices", "ncolor", "L_pairs", "L_blocks",
-                "U_pairs", "U_blocks", "ssor_slices", "wg_interior", "wg_boundary")
+                "U_pairs", "U_blocks", "ssor_slices", "wg_interior", "wg_boundary", "eisenstat")
         return {k: int(out[i]) for i, k in enumerate(keys)}
 
     def krylov_begin(self, hecMAT):

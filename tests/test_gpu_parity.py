@@ -757,3 +757,43 @@ def test_divergence_retries_against_reference_golden(hip, oracle, k):
     if code == 0:
         assert relerr(m.X, g[tag + "X"]) < 1e-7
     ctx.close()
+
+
+@pytest.mark.parametrize("deck", DECKS + ["cube12"])
+@pytest.mark.parametrize("sigma", [1.0, 1.3])
+def test_eisenstat_form_of_cg_ssor(hip, oracle, deck, sigma, monkeypatch):
+    """FX_EISENSTAT=1 (opt-in): CG + multicolour SSOR with the matrix streamed once per iteration (one backward and one forward
+    triangular sweep deliver p, q = A p and (D~+L)^-1 q).  Same iterates in exact arithmetic, so the same checks as the standard
+    loop against the oracle: history lines 1-10 to 1e-10, count +-1, field 1e-8 -- and against the standard GPU loop itself.
+    SIGMA_DIAG /= 1 exercises the (D - D~) terms."""
+    from oracle.refrun import default_params
+    if deck == "cube12":
+        from frontistr_amd.mesh import CubeMesh
+        mesh = CubeMesh(12, skew=0.05)
+        A = oracle.assemble(1, mesh.coord, mesh.conn, 210000.0, 0.3, bc=mesh.dirichlet(), load=mesh.load())
+    else:
+        A = golden_matrix(load_golden(deck))
+    I, R = default_params(method=1, precond=1, sigma_diag=sigma)
+    o = oracle.solve_iterative(A, I.copy(), R.copy(), nthreads=4)
+    res = {}
+    for tag, val in (("std", "0"), ("eis", "1")):
+        monkeypatch.setenv("FX_EISENSTAT", val)
+        m = to_hecmat(hip, A)
+        m.Iarray[:] = I; m.Rarray[:] = R
+        ctx = hip.SolverContext()
+        code = hip.hecmw_solve(None, m, ctx=ctx)
+        assert code == 0 and m.Iarray[80] == 1, (tag, code)
+        assert ctx.stats()["eisenstat"] == (1 if tag == "eis" else 0)        # the form that was asked for is the one that ran
+        res[tag] = (ctx.info.iterations, ctx.history.copy(), m.X.copy(), ctx.info.rel_resid)
+        ctx.close()
+    it, h, x, rr = res["eis"]
+    whole = deck != "exA_A361"
+    k = min(10, len(h), len(o["history"]))
+    assert np.all(np.abs(h[:k] - o["history"][:k]) <= 1e-10 * o["history"][:k])
+    assert abs(it - o["iter"]) <= (1 if whole else 0.1 * o["iter"])
+    assert relerr(x, o["X"]) < 1e-8 and rr < R[0]
+    it0, h0, x0, _ = res["std"]
+    assert abs(it - it0) <= (1 if whole else 0.1 * it0) and relerr(x, x0) < 1e-8
+    n = min(len(h), len(h0))
+    if whole:
+        assert np.all(np.abs(h[:n] - h0[:n]) <= 0.25 * h0[:n])
