@@ -63,6 +63,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-n", type=int, default=69)
     ap.add_argument("--cpu-sample-iters", type=int, default=40)
+    ap.add_argument("--eisenstat", action="store_true",
+                    help="opt-in: CG + SSOR in Eisenstat's one-pass form (FX_EISENSTAT=1; same iterates to rounding, matrix streamed once per iteration); the default line is the standard recurrence")
     ap.add_argument("--cpu-full", action="store_true",
                     help="time the reference on the FULL workload (same deck, --cpu-sample-iters iterations) instead of the sample")
     return ap.parse_args(argv)
@@ -206,6 +208,8 @@ def main():
         if world > 1:
             dist.barrier()
 
+    if a.eisenstat:
+        os.environ["FX_EISENSTAT"] = "1"
     t_setup0 = time.time()
     ctx = hip.SolverContext(device=dev)
     E, NU = 210000.0, 0.3
@@ -312,6 +316,7 @@ def main():
             "transport": "none" if world == 1 else ("rccl (ncclCommCount=%d)" % comm_ranks if transport != "gloo" else "gloo host callbacks (rehearsal)"),
             "devices_used": devices_used,
             "ncolor": st["ncolor"],
+            "recurrence": "eisenstat one-pass form (opt-in)" if ctx.stats()["eisenstat"] else "standard (hecmw_solve_CG / hecmw_solve_BiCGSTAB as written)",
             "block_rows": N, "blocks": nb,
         },
         "roofline": {

@@ -1546,8 +1546,12 @@ static int eis_cg_iteration(fx_context *c, int it) {
     for (int col = 0; col < S.ncolor; col++) {
       const int s0 = S.color_slice[col], s1 = S.color_slice[col + 1];
       if (s1 <= s0) continue;
-      const int g = (s1 - s0 + spb - 1) / spb;
-      if (c->ssor_bs == 64)
+      int g = (s1 - s0 + spb - 1) / spb;
+      if (s1 - s0 <= c->split_max_slices) {
+        g = s1 - s0;
+        hipLaunchKernelGGL((k_eis_forward_split<4>), dim3(g), dim3(256), 0, c->stream, s0, s1, S.L.pair_ptr, S.L.val2, S.L.col2, S.alu,
+                           S.dblk, sm1, PH, P, V, WH, Q, c->partials, off, gate_status(c));
+      } else if (c->ssor_bs == 64)
         hipLaunchKernelGGL((k_eis_forward<64>), dim3(g), dim3(64), 0, c->stream, s0, s1, S.L.pair_ptr, S.L.val2, S.L.col2, S.alu, S.dblk,
                            sm1, PH, P, V, WH, Q, c->partials, off, gate_status(c));
       else

@@ -491,6 +491,91 @@ __global__ __launch_bounds__(64 * WPS) void k_ssor_color_split(int32_t slice0, i
 //                 x += alpha p; r -= alpha q; t -= alpha w; dt = D~ t; rho' = t.dt  (= r.M^-1 r)      (k_eis_update)
 // L / U = strictly lower / upper part in the colour ordering, halo columns dropped (single rank: none exist).
 // ------------------------------------------------------------------------
+// Row loop with TWO gathered vectors per block (v and p share the matrix stream): 2-deep software pipeline as bell_row_sweep.
+__device__ __forceinline__ void bell_row_sweep_dual(int h0, int h1, const double *__restrict__ val, const int *__restrict__ col,
+                                                    int lane, const double *__restrict__ xv, const double *__restrict__ xp,
+                                                    double (&sv)[3], double (&sp)[3]) {
+  const int np = (h1 - h0) >> 1;
+  if ((h1 - h0) & 1) {  // odd last block of the slice, stored alone
+    const double *vt = val + (size_t)(h0 + 2 * np) * 576 + lane;
+    const int cc = ld_stream(col + (size_t)(h0 + 2 * np) * 64 + lane);
+    double a[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) a[e] = ld_stream(vt + e * 64);
+    const double av[3] = {xv[(size_t)3 * cc], xv[(size_t)3 * cc + 1], xv[(size_t)3 * cc + 2]};
+    const double ap[3] = {xp[(size_t)3 * cc], xp[(size_t)3 * cc + 1], xp[(size_t)3 * cc + 2]};
+    bell_single_fma(a, av, sv[0], sv[1], sv[2]);
+    bell_single_fma(a, ap, sp[0], sp[1], sp[2]);
+  }
+  if (np <= 0) return;
+  const double2 *v = (const double2 *)(val + (size_t)h0 * 576) + lane;
+  const int2 *c = (const int2 *)(col + (size_t)h0 * 64) + lane;
+  int2 cc1 = (np > 1) ? ld_stream(c + 64) : ld_stream(c);
+  double2 a[9];
+  double gv[6], gp[6];
+  {
+    const int2 cc0 = ld_stream(c);
+#pragma unroll
+    for (int e = 0; e < 9; e++) a[e] = ld_stream(v + e * 64);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      gv[k] = xv[(size_t)3 * cc0.x + k]; gv[3 + k] = xv[(size_t)3 * cc0.y + k];
+      gp[k] = xp[(size_t)3 * cc0.x + k]; gp[3 + k] = xp[(size_t)3 * cc0.y + k];
+    }
+  }
+  for (int i = 0; i < np; i++) {
+    const bool more = (i + 1 < np);
+    double2 an[9];
+    double nv[6] = {0, 0, 0, 0, 0, 0}, npv[6] = {0, 0, 0, 0, 0, 0};
+    int2 cc2 = cc1;
+    if (more) {
+      v += 576; c += 64;
+#pragma unroll
+      for (int e = 0; e < 9; e++) an[e] = ld_stream(v + e * 64);
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        nv[k] = xv[(size_t)3 * cc1.x + k]; nv[3 + k] = xv[(size_t)3 * cc1.y + k];
+        npv[k] = xp[(size_t)3 * cc1.x + k]; npv[3 + k] = xp[(size_t)3 * cc1.y + k];
+      }
+      if (i + 2 < np) cc2 = ld_stream(c + 64);
+    }
+    bell_pair_fma(a, gv, sv[0], sv[1], sv[2]);
+    bell_pair_fma(a, gp, sp[0], sp[1], sp[2]);
+    if (more) {
+#pragma unroll
+      for (int e = 0; e < 9; e++) a[e] = an[e];
+#pragma unroll
+      for (int k = 0; k < 6; k++) { gv[k] = nv[k]; gp[k] = npv[k]; }
+      cc1 = cc2;
+    }
+  }
+}
+
+// the row's own part of the forward Eisenstat sweep, from the two block sums sv = (L v)_i, sp = (L p)_i; returns ph_i . w_i
+__device__ __forceinline__ double eis_forward_finish(int slice, int lane, const double (&sv)[3], const double (&sp)[3],
+                                                     const double *__restrict__ alu, const double *__restrict__ dblk, double sm1,
+                                                     const double *__restrict__ ph, const double *__restrict__ p,
+                                                     double *__restrict__ v, double *__restrict__ w, double *__restrict__ q) {
+  const int slot = slice * 64 + lane;
+  double u[9], D[9];
+  const size_t base = (size_t)slice * 576 + lane;
+#pragma unroll
+  for (int e = 0; e < 9; e++) { u[e] = alu[base + (size_t)e * 64]; D[e] = dblk[base + (size_t)e * 64]; }
+  const double p0 = p[(size_t)3 * slot], p1 = p[(size_t)3 * slot + 1], p2 = p[(size_t)3 * slot + 2];
+  const double h0v = ph[(size_t)3 * slot], h1v = ph[(size_t)3 * slot + 1], h2v = ph[(size_t)3 * slot + 2];
+  const double Dp0 = D[0] * p0 + D[1] * p1 + D[2] * p2, Dp1 = D[3] * p0 + D[4] * p1 + D[5] * p2, Dp2 = D[6] * p0 + D[7] * p1 + D[8] * p2;
+  const double e0 = sm1 * D[0] * p0, e1 = sm1 * D[4] * p1, e2 = sm1 * D[8] * p2;  // (D~ - D) p: SIGMA_DIAG scales the three scalar diagonal entries only
+  // g = ph + (D - 2 D~) p = ph - D p - 2 (D~ - D) p ;  v = D~^-1 (g - L v)
+  double x1 = h0v - Dp0 - 2.0 * e0 - sv[0], x2 = h1v - Dp1 - 2.0 * e1 - sv[1], x3 = h2v - Dp2 - 2.0 * e2 - sv[2];
+  lusolve33_dev(u, x1, x2, x3);
+  v[(size_t)3 * slot] = x1; v[(size_t)3 * slot + 1] = x2; v[(size_t)3 * slot + 2] = x3;
+  const double w0 = p0 + x1, w1 = p1 + x2, w2 = p2 + x3;
+  w[(size_t)3 * slot] = w0; w[(size_t)3 * slot + 1] = w1; w[(size_t)3 * slot + 2] = w2;
+  // q = A p = ph + L p + (D - D~) p
+  q[(size_t)3 * slot] = h0v + sp[0] - e0; q[(size_t)3 * slot + 1] = h1v + sp[1] - e1; q[(size_t)3 * slot + 2] = h2v + sp[2] - e2;
+  return h0v * w0 + h1v * w1 + h2v * w2;
+}
+
 template <int BS>
 __global__ __launch_bounds__(BS) void k_eis_forward(int32_t slice0, int32_t slice1, const int32_t *__restrict__ pair_ptr,
                                                     const double *__restrict__ val2, const int *__restrict__ col2,
@@ -504,53 +589,71 @@ __global__ __launch_bounds__(BS) void k_eis_forward(int32_t slice0, int32_t slic
   const int lane = threadIdx.x & 63;
   double d[1] = {0.0};
   if (slice < slice1) {
-    const int slot = slice * 64 + lane;
-    const int h0 = pair_ptr[slice], h1 = pair_ptr[slice + 1];
-    const int np = (h1 - h0) >> 1;
-    double sv0 = 0.0, sv1 = 0.0, sv2 = 0.0, sp0 = 0.0, sp1 = 0.0, sp2 = 0.0;
-    if ((h1 - h0) & 1) {  // odd last block of the slice, stored alone
-      const double *vt = val2 + (size_t)(h0 + 2 * np) * 576 + lane;
-      const int cc = ld_stream(col2 + (size_t)(h0 + 2 * np) * 64 + lane);
-      double a[9];
-#pragma unroll
-      for (int e = 0; e < 9; e++) a[e] = ld_stream(vt + e * 64);
-      const double xv[3] = {v[(size_t)3 * cc], v[(size_t)3 * cc + 1], v[(size_t)3 * cc + 2]};
-      const double xp[3] = {p[(size_t)3 * cc], p[(size_t)3 * cc + 1], p[(size_t)3 * cc + 2]};
-      bell_single_fma(a, xv, sv0, sv1, sv2);
-      bell_single_fma(a, xp, sp0, sp1, sp2);
-    }
-    const double2 *vp = (const double2 *)(val2 + (size_t)h0 * 576) + lane;
-    const int2 *cp = (const int2 *)(col2 + (size_t)h0 * 64) + lane;
-    for (int i = 0; i < np; i++, vp += 576, cp += 64) {
-      const int2 cc = ld_stream(cp);
-      double2 a[9];
-#pragma unroll
-      for (int e = 0; e < 9; e++) a[e] = ld_stream(vp + e * 64);
-      const double *va = v + (size_t)3 * cc.x, *vb2 = v + (size_t)3 * cc.y, *pa = p + (size_t)3 * cc.x, *pb = p + (size_t)3 * cc.y;
-      const double xv[6] = {va[0], va[1], va[2], vb2[0], vb2[1], vb2[2]};
-      const double xp[6] = {pa[0], pa[1], pa[2], pb[0], pb[1], pb[2]};
-      bell_pair_fma(a, xv, sv0, sv1, sv2);
-      bell_pair_fma(a, xp, sp0, sp1, sp2);
-    }
-    double u[9], D[9];
-    const size_t base = (size_t)slice * 576 + lane;
-#pragma unroll
-    for (int e = 0; e < 9; e++) { u[e] = alu[base + (size_t)e * 64]; D[e] = dblk[base + (size_t)e * 64]; }
-    const double p0 = p[(size_t)3 * slot], p1 = p[(size_t)3 * slot + 1], p2 = p[(size_t)3 * slot + 2];
-    const double h0v = ph[(size_t)3 * slot], h1v = ph[(size_t)3 * slot + 1], h2v = ph[(size_t)3 * slot + 2];
-    const double Dp0 = D[0] * p0 + D[1] * p1 + D[2] * p2, Dp1 = D[3] * p0 + D[4] * p1 + D[5] * p2, Dp2 = D[6] * p0 + D[7] * p1 + D[8] * p2;
-    const double e0 = sm1 * D[0] * p0, e1 = sm1 * D[4] * p1, e2 = sm1 * D[8] * p2;  // (D~ - D) p: SIGMA_DIAG scales the three scalar diagonal entries only
-    // g = ph + (D - 2 D~) p = ph - D p - 2 (D~ - D) p ;  v = D~^-1 (g - L v)
-    double x1 = h0v - Dp0 - 2.0 * e0 - sv0, x2 = h1v - Dp1 - 2.0 * e1 - sv1, x3 = h2v - Dp2 - 2.0 * e2 - sv2;
-    lusolve33_dev(u, x1, x2, x3);
-    v[(size_t)3 * slot] = x1; v[(size_t)3 * slot + 1] = x2; v[(size_t)3 * slot + 2] = x3;
-    const double w0 = p0 + x1, w1 = p1 + x2, w2 = p2 + x3;
-    w[(size_t)3 * slot] = w0; w[(size_t)3 * slot + 1] = w1; w[(size_t)3 * slot + 2] = w2;
-    // q = A p = ph + L p + (D - D~) p
-    q[(size_t)3 * slot] = h0v + sp0 - e0; q[(size_t)3 * slot + 1] = h1v + sp1 - e1; q[(size_t)3 * slot + 2] = h2v + sp2 - e2;
-    d[0] = h0v * w0 + h1v * w1 + h2v * w2;
+    double sv[3] = {0.0, 0.0, 0.0}, sp[3] = {0.0, 0.0, 0.0};
+    bell_row_sweep_dual(pair_ptr[slice], pair_ptr[slice + 1], val2, col2, lane, v, p, sv, sp);
+    d[0] = eis_forward_finish(slice, lane, sv, sp, alu, dblk, sm1, ph, p, v, w, q);
   }
   block_sum_store<1, BS>(d, partials, 0, part0 + vb);
+}
+
+// the same sweep for latency-bound colours: WPS waves share a slice's block pairs (as k_ssor_color_split)
+template <int WPS>
+__global__ __launch_bounds__(64 * WPS) void k_eis_forward_split(int32_t slice0, int32_t slice1, const int32_t *__restrict__ pair_ptr,
+                                                                const double *__restrict__ val2, const int *__restrict__ col2,
+                                                                const double *__restrict__ alu, const double *__restrict__ dblk,
+                                                                double sm1, const double *__restrict__ ph, const double *__restrict__ p,
+                                                                double *__restrict__ v, double *__restrict__ w, double *__restrict__ q,
+                                                                double *__restrict__ partials, int32_t part0,
+                                                                const int32_t *__restrict__ gate) {
+  if (gate && *gate != 0) return;
+  __shared__ double part[WPS][6][64];
+  const int slice = slice0 + blockIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int h0 = pair_ptr[slice], h1 = pair_ptr[slice + 1];
+  const int np = (h1 - h0) >> 1;
+  double sv[3] = {0.0, 0.0, 0.0}, sp[3] = {0.0, 0.0, 0.0};
+  const double2 *vbase = (const double2 *)(val2 + (size_t)h0 * 576) + lane;
+  const int2 *cbase = (const int2 *)(col2 + (size_t)h0 * 64) + lane;
+  for (int i = wv; i < np; i += WPS) {
+    const int2 cc = ld_stream(cbase + (size_t)i * 64);
+    double2 a[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) a[e] = ld_stream(vbase + (size_t)i * 576 + e * 64);
+    double gv[6], gp[6];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      gv[k] = v[(size_t)3 * cc.x + k]; gv[3 + k] = v[(size_t)3 * cc.y + k];
+      gp[k] = p[(size_t)3 * cc.x + k]; gp[3 + k] = p[(size_t)3 * cc.y + k];
+    }
+    bell_pair_fma(a, gv, sv[0], sv[1], sv[2]);
+    bell_pair_fma(a, gp, sp[0], sp[1], sp[2]);
+  }
+  if (((h1 - h0) & 1) && wv == (np % WPS)) {
+    const double *vt = val2 + (size_t)(h0 + 2 * np) * 576 + lane;
+    const int cc = ld_stream(col2 + (size_t)(h0 + 2 * np) * 64 + lane);
+    double a[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) a[e] = ld_stream(vt + e * 64);
+    const double av[3] = {v[(size_t)3 * cc], v[(size_t)3 * cc + 1], v[(size_t)3 * cc + 2]};
+    const double ap[3] = {p[(size_t)3 * cc], p[(size_t)3 * cc + 1], p[(size_t)3 * cc + 2]};
+    bell_single_fma(a, av, sv[0], sv[1], sv[2]);
+    bell_single_fma(a, ap, sp[0], sp[1], sp[2]);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) { part[wv][k][lane] = sv[k]; part[wv][3 + k][lane] = sp[k]; }
+  __syncthreads();
+  double d = 0.0;
+  if (wv == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { sv[k] = part[0][k][lane]; sp[k] = part[0][3 + k][lane]; }
+#pragma unroll
+    for (int j = 1; j < WPS; j++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) { sv[k] += part[j][k][lane]; sp[k] += part[j][3 + k][lane]; }
+    d = eis_forward_finish(slice, lane, sv, sp, alu, dblk, sm1, ph, p, v, w, q);
+    d = wave_sum(d);
+    if (lane == 0) partials[part0 + blockIdx.x] = d;
+  }
 }
 
 // dt = D~ t and the partial of rho = t.dt; MODE 1 also x += alpha p, r -= alpha q (+ partial ||r||^2), t -= alpha w first;
