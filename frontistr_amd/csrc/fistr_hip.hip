@@ -24,6 +24,8 @@ struct Graph {
 Graph build_graph(int32_t N, const int32_t *indexL, const int32_t *itemL, const int32_t *indexU,
                   const int32_t *itemU);
 std::vector<int32_t> rcm_sequence(const Graph &g);
+std::vector<int32_t> rcm_starts(const Graph &g);
+int32_t level_order_host(const Graph &g, int32_t start, std::vector<int32_t> &seq);
 void multicolor(const Graph &g, const std::vector<int32_t> &seq, int ncolor_in, std::vector<int32_t> &perm,
                 std::vector<int32_t> &colorindex);
 bool color_elements(int32_t n_elem, int nn, const int32_t *conn, int32_t NP, std::vector<int32_t> &order,
@@ -252,6 +254,7 @@ extern "C" int fx_create(int device, fx_context **out) {
     (void)hipMalloc(&dummy, (size_t)atoll(e) << 20);  // kept for the life of the process on purpose
   }
   if (const char *e = getenv("FX_TUNE_PLACEMENT")) c->tune_tries = std::max(0, atoi(e));
+  if (const char *e = getenv("FX_BFS_DEVICE_MIN")) c->bfs_device_min = atoi(e);
   if (const char *e = getenv("FX_PIPE_SPMV")) c->pipe_spmv = atoi(e) != 0;
   if (const char *e = getenv("FX_PIPE_SSOR")) c->pipe_ssor = atoi(e) != 0;
   if (const char *e = getenv("FX_SSOR_MODE")) c->ssor_mode = atoi(e);
@@ -549,16 +552,18 @@ static inline int spmv_nparts(fx_context *c);
 // ends -- freeing one early would hand the same physical block to the next hipMalloc.  The search stops early once a
 // candidate streams at >= good_gbs (GB/s over `stream_bytes`).
 template <class Fill, class Time>
-static int tune_placement(fx_context *c, Bell &B, const char *what, double stream_bytes, double good_gbs, Fill fill, Time time_ms) {
+static int tune_placement(fx_context *c, Bell &B, const char *what, double stream_bytes, double good_gbs, Fill fill, Time time_ms,
+                          int max_tries = 1 << 30) {
   B.placed = true;
-  if (c->tune_tries <= 1 || B.nslices < c->tune_min_slices) return 0;
+  const int tries = std::min(c->tune_tries, max_tries);
+  if (tries <= 1 || B.nslices < c->tune_min_slices) return 0;
   const size_t bytes = (size_t)B.npairs * 576 * 8;
   std::vector<void *> cand;
   std::vector<float> t;
   cand.push_back(B.val2_base);
   t.push_back(0.f);
   if (time_ms(&t[0])) return FX_ERROR_RUNTIME;
-  for (int k = 1; k < c->tune_tries; k++) {
+  for (int k = 1; k < tries; k++) {
     if (stream_bytes / (1e-3 * *std::min_element(t.begin(), t.end())) / 1e9 >= good_gbs) break;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + (bytes >> 1) + ((size_t)4 << 30)) break;  // keep headroom
@@ -977,6 +982,66 @@ static int diag_setup(fx_context *c, double sigma_diag) {
   return 0;
 }
 
+// hecmw_matrix_ordering_CM's "RCM" (level ordering from the best of <= 5 minimum-degree starts + the id mirror of
+// reverse_ordering, hecmw_matrix_ordering_CM.f90:16-55, :169-178) with the breadth-first levels on the DEVICE (kernels
+// k_bfs_*: 150 levels x 5 starts at 150^3 nodes, ~3 k small launches instead of five 0.3 s host walks).  Any start whose
+// graph is disconnected (the reference then jumps to the lowest unvisited node) falls back to the host walk for that start.
+static int rcm_sequence_device(fx_context *c, const fxo::Graph &g, std::vector<int32_t> &seq_out) {
+  const int32_t N = c->A.N;
+  const std::vector<int32_t> starts = fxo::rcm_starts(g);
+  DevScratch tmp;
+  uint8_t *seen = nullptr;
+  uint32_t *claim = nullptr;
+  int32_t *seq = nullptr, *cnt = nullptr, *off = nullptr, *total = nullptr;
+  if (tmp.alloc(&seen, (size_t)N) || tmp.alloc(&claim, (size_t)N) || tmp.alloc(&seq, (size_t)N) || tmp.alloc(&cnt, (size_t)N) ||
+      tmp.alloc(&off, (size_t)N) || tmp.alloc(&total, 4))
+    return FX_ERROR_RUNTIME;
+  int32_t *h_total = (int32_t *)(c->st_host + 3) + 4;  // pinned
+  const DevCSR &A = c->A;
+  int32_t best_levels = -1;
+  std::vector<int32_t> cur;
+  for (size_t si = 0; si < starts.size(); si++) {
+    const int32_t start = starts[si];
+    HIP_TRY(hipMemsetAsync(seen, 0, (size_t)N, c->stream));
+    HIP_TRY(hipMemsetAsync(claim, 0xFF, (size_t)N * 4, c->stream));
+    HIP_TRY(hipMemcpyAsync(seq, &start, 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_bfs_mark, dim3(1), dim3(64), 0, c->stream, 1, seq, seen);
+    int32_t lo = 0, hi = 1, nlevel = 1;
+    bool ok = true;
+    while (hi < N) {
+      const int32_t nf = hi - lo;
+      const dim3 grid((nf + 255) / 256), blk(256);
+      hipLaunchKernelGGL(k_bfs_claim, grid, blk, 0, c->stream, nf, seq + lo, (uint32_t)lo, N, A.indexL, A.itemL, A.indexU, A.itemU, seen, claim);
+      hipLaunchKernelGGL((k_bfs_children<false>), grid, blk, 0, c->stream, nf, seq + lo, (uint32_t)lo, N, A.indexL, A.itemL, A.indexU,
+                         A.itemU, seen, claim, cnt, (const int32_t *)nullptr, (int32_t *)nullptr);
+      hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, c->stream, nf, cnt, off, total);
+      hipLaunchKernelGGL((k_bfs_children<true>), grid, blk, 0, c->stream, nf, seq + lo, (uint32_t)lo, N, A.indexL, A.itemL, A.indexU,
+                         A.itemU, seen, claim, cnt, off, seq + hi);
+      HIP_TRY(hipMemcpyAsync(h_total, total, 4, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      const int32_t nnew = *h_total;
+      if (nnew <= 0 || hi + nnew > N) { ok = false; break; }  // disconnected graph (or nonsense): the host walk handles it
+      hipLaunchKernelGGL(k_bfs_mark, dim3((nnew + 255) / 256), blk, 0, c->stream, nnew, seq + hi, seen);
+      lo = hi;
+      hi += nnew;
+      nlevel++;
+    }
+    HIP_TRY(hipGetLastError());
+    if (!ok) {
+      nlevel = fxo::level_order_host(g, start, cur);
+      if (nlevel > best_levels) { best_levels = nlevel; seq_out = cur; }
+      continue;
+    }
+    if (nlevel > best_levels) {  // strictly more levels wins: the first of equals stays (hecmw_matrix_ordering_CM.f90:41-47)
+      best_levels = nlevel;
+      seq_out.resize((size_t)N);
+      HIP_TRY(hipMemcpy(seq_out.data(), seq, (size_t)N * 4, hipMemcpyDeviceToHost));
+    }
+  }
+  for (auto &v : seq_out) v = N - 1 - v;  // reverse_ordering: id mirror
+  return 0;
+}
+
 // hecmw_precond_SSOR_33_setup (hecmw_precond_SSOR_33.f90:55-223), always on the
 // multicolour path (the reference's nthreads > 1 branch :102-111): ordering on the
 // host, values gathered on the device.  Within a colour the slots are sorted by the
@@ -989,7 +1054,9 @@ static int ssor_setup_symbolic(fx_context *c, int ncolor_in) {
   PhaseTimer pt("ssor symbolic");
   fxo::Graph g = fxo::build_graph(N, iL, jL, iU, jU);
   pt.lap("graph");
-  std::vector<int32_t> seq = fxo::rcm_sequence(g);
+  std::vector<int32_t> seq;
+  if (N >= c->bfs_device_min) { if (rcm_sequence_device(c, g, seq)) return FX_ERROR_RUNTIME; }
+  else seq = fxo::rcm_sequence(g);
   pt.lap("level ordering");
   std::vector<int32_t> perm0, cidx;
   fxo::multicolor(g, seq, ncolor_in, perm0, cidx);
@@ -1121,8 +1188,9 @@ static int tune_sweep_placement(fx_context *c, const double *lu_D, const double 
   const double bytes = 76.0 * 64 * (double)(S.L.npairs + S.U.npairs) + (2 * 72.0 + 120.0) * S.nslots;
   const double good = c->precond_kind == 10 ? 1e9 : 5450.0;  // level-scheduled ILU(0) is latency-bound: placement does not show
   if (c->precond_kind == 10) { S.L.placed = S.U.placed = true; return 0; }
-  if (tune_placement(c, S.L, "sweep L", bytes, good, [&]() { return bell_fill_values(c, S.L, lu_D, lu_AL, lu_AU); }, time_apply)) return FX_ERROR_RUNTIME;
-  return tune_placement(c, S.U, "sweep U", bytes, good, [&]() { return bell_fill_values(c, S.U, lu_D, lu_AL, lu_AU); }, time_apply);
+  // the sweeps gain 1-3 % at best (their speed classes lie closer together than the SpMV's): four candidates each
+  if (tune_placement(c, S.L, "sweep L", bytes, good, [&]() { return bell_fill_values(c, S.L, lu_D, lu_AL, lu_AU); }, time_apply, 4)) return FX_ERROR_RUNTIME;
+  return tune_placement(c, S.U, "sweep U", bytes, good, [&]() { return bell_fill_values(c, S.U, lu_D, lu_AL, lu_AU); }, time_apply, 4);
 }
 
 static int ssor_setup_numeric(fx_context *c, double sigma_diag) {
@@ -2190,6 +2258,17 @@ extern "C" int fx_get_stats(fx_context *c, int64_t out[16]) {
   out[12] = c->ssor.L.nslices;
   out[13] = c->M.n_wg_interior; out[14] = c->M.n_wg_boundary;  // SpMV workgroups overlapped with / ordered after the halo exchange
   out[15] = c->eis_active ? 1 : 0;                              // the last Krylov loop ran in Eisenstat's form
+  return 0;
+}
+
+// The ordering the resident multicolour SSOR was built with: perm (new -> old, 1-based) and COLORindex(0:ncolor).
+extern "C" int fx_get_ssor_ordering(fx_context *c, int32_t *perm, int32_t *colorindex, int32_t colorindex_cap, int32_t *ncolor) {
+  const SsorDev &S = c->ssor;
+  if (c->precond_kind != 1 || S.perm.empty()) { g_fx_error = "fx_get_ssor_ordering: no multicolour SSOR resident"; return FX_ERROR_RUNTIME; }
+  if ((int32_t)S.colorindex.size() > colorindex_cap) { g_fx_error = "fx_get_ssor_ordering: colorindex too small"; return FX_ERROR_RUNTIME; }
+  std::copy(S.perm.begin(), S.perm.end(), perm);
+  std::copy(S.colorindex.begin(), S.colorindex.end(), colorindex);
+  *ncolor = S.ncolor;
   return 0;
 }
 

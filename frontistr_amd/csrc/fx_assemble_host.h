@@ -4,39 +4,66 @@
 // hecmw_mat_con (hecmw_mat_con.f90:23-268): CRS block profile from element connectivity.
 // Node -> element incidence by counting sort, then per node the sorted unique set of the
 // nodes of its elements, split into lower / upper; rows are independent => host threads.
+// The two-call protocol (count, then fill) would build the node -> element incidence and every row's neighbour list twice;
+// the first call keeps the lists (one flat array, ~ (NPL + NPU + NP) ints) for the second, which then only splits them.
+struct MatConCache {
+  const int32_t *conn = nullptr;
+  int32_t NP = 0, n_elem = 0, nn = 0;
+  std::vector<int64_t> rptr;
+  std::vector<int32_t> rows;  // per node: sorted unique neighbour ids (1-based), itself included
+  void clear() { conn = nullptr; std::vector<int64_t>().swap(rptr); std::vector<int32_t>().swap(rows); }
+};
+static MatConCache g_matcon;
+
 extern "C" int fx_mat_con(int32_t NP, int32_t n_elem, int32_t nn, const int32_t *conn, int32_t *indexL, int32_t *indexU,
                           int32_t *itemL, int32_t *itemU) {
-  std::vector<int64_t> ptr((size_t)NP + 2, 0);
-  const int64_t tot = (int64_t)n_elem * nn;
-  for (int64_t k = 0; k < tot; k++) {
-    const int32_t v = conn[k];
-    if (v < 1 || v > NP) { g_fx_error = "fx_mat_con: node id out of range"; return FX_ERROR_RUNTIME; }
-    ptr[v + 1]++;
-  }
-  for (int32_t i = 1; i <= NP + 1; i++) ptr[i] += ptr[i - 1];
-  std::vector<int32_t> inc((size_t)tot);
-  {
-    std::vector<int64_t> pos(ptr.begin(), ptr.end());
-    for (int32_t e = 0; e < n_elem; e++)
-      for (int j = 0; j < nn; j++) inc[pos[conn[(size_t)e * nn + j]]++] = e;
-  }
-  std::vector<int32_t> nl((size_t)NP + 1, 0), nu((size_t)NP + 1, 0);
-  auto row_nodes = [&](int32_t i, std::vector<int32_t> &buf) {
-    buf.clear();
-    for (int64_t a = ptr[i]; a < ptr[i + 1]; a++) {
-      const int32_t *en = conn + (size_t)inc[a] * nn;
-      buf.insert(buf.end(), en, en + nn);
+  MatConCache &mc = g_matcon;
+  const bool fill = itemL && itemU;
+  if (!(fill && mc.conn == conn && mc.NP == NP && mc.n_elem == n_elem && mc.nn == nn && !mc.rptr.empty())) {
+    mc.clear();
+    std::vector<int64_t> ptr((size_t)NP + 2, 0);
+    const int64_t tot = (int64_t)n_elem * nn;
+    for (int64_t k = 0; k < tot; k++) {
+      const int32_t v = conn[k];
+      if (v < 1 || v > NP) { g_fx_error = "fx_mat_con: node id out of range"; return FX_ERROR_RUNTIME; }
+      ptr[v + 1]++;
     }
-    std::sort(buf.begin(), buf.end());
-    buf.erase(std::unique(buf.begin(), buf.end()), buf.end());
-  };
-  if (!itemL || !itemU) {
+    for (int32_t i = 1; i <= NP + 1; i++) ptr[i] += ptr[i - 1];
+    std::vector<int32_t> inc((size_t)tot);
+    {
+      std::vector<int64_t> pos(ptr.begin(), ptr.end());
+      for (int32_t e = 0; e < n_elem; e++)
+        for (int j = 0; j < nn; j++) inc[pos[conn[(size_t)e * nn + j]]++] = e;
+    }
+    auto row_nodes = [&](int32_t i, std::vector<int32_t> &buf) {
+      buf.clear();
+      for (int64_t a = ptr[i]; a < ptr[i + 1]; a++) {
+        const int32_t *en = conn + (size_t)inc[a] * nn;
+        buf.insert(buf.end(), en, en + nn);
+      }
+      std::sort(buf.begin(), buf.end());
+      buf.erase(std::unique(buf.begin(), buf.end()), buf.end());
+    };
+    // pass 1: sizes (parallel), pass 2: lists into one flat array (parallel)
+    mc.rptr.assign((size_t)NP + 1, 0);
     parallel_for(NP, [&](int64_t a, int64_t b) {
       std::vector<int32_t> buf;
+      for (int64_t i = a + 1; i <= b; i++) { row_nodes((int32_t)i, buf); mc.rptr[i] = (int64_t)buf.size(); }
+    });
+    for (int32_t i = 1; i <= NP; i++) mc.rptr[i] += mc.rptr[i - 1];
+    mc.rows.resize((size_t)mc.rptr[NP]);
+    parallel_for(NP, [&](int64_t a, int64_t b) {
+      std::vector<int32_t> buf;
+      for (int64_t i = a + 1; i <= b; i++) { row_nodes((int32_t)i, buf); std::copy(buf.begin(), buf.end(), mc.rows.begin() + mc.rptr[i - 1]); }
+    });
+    mc.conn = conn; mc.NP = NP; mc.n_elem = n_elem; mc.nn = nn;
+  }
+  if (!fill) {
+    std::vector<int32_t> nl((size_t)NP + 1, 0), nu((size_t)NP + 1, 0);
+    parallel_for(NP, [&](int64_t a, int64_t b) {
       for (int64_t i = a + 1; i <= b; i++) {
-        row_nodes((int32_t)i, buf);
         int32_t l = 0, u = 0;
-        for (int32_t v : buf) { l += (v < i); u += (v > i); }
+        for (int64_t k = mc.rptr[i - 1]; k < mc.rptr[i]; k++) { l += (mc.rows[k] < i); u += (mc.rows[k] > i); }
         nl[i] = l; nu[i] = u;
       }
     });
@@ -44,22 +71,37 @@ extern "C" int fx_mat_con(int32_t NP, int32_t n_elem, int32_t nn, const int32_t 
     int64_t cl = 0, cu = 0;
     for (int32_t i = 1; i <= NP; i++) {
       cl += nl[i]; cu += nu[i];
-      if (cl > INT32_MAX || cu > INT32_MAX) { g_fx_error = "fx_mat_con: profile exceeds int32 (kint=4)"; return FX_ERROR_RUNTIME; }
+      if (cl > INT32_MAX || cu > INT32_MAX) { g_fx_error = "fx_mat_con: profile exceeds int32 (kint=4)"; mc.clear(); return FX_ERROR_RUNTIME; }
       indexL[i] = (int32_t)cl; indexU[i] = (int32_t)cu;
     }
-    return 0;
+    return 0;  // the lists stay for the fill call
   }
   parallel_for(NP, [&](int64_t a, int64_t b) {
-    std::vector<int32_t> buf;
     for (int64_t i = a + 1; i <= b; i++) {
-      row_nodes((int32_t)i, buf);
       int32_t *pl = itemL + indexL[i - 1], *pu = itemU + indexU[i - 1];
-      for (int32_t v : buf) {
+      for (int64_t k = mc.rptr[i - 1]; k < mc.rptr[i]; k++) {
+        const int32_t v = mc.rows[k];
         if (v < i) *pl++ = v;
         else if (v > i) *pu++ = v;
       }
     }
   });
+  mc.clear();
+  return 0;
+}
+
+// Host only: the ordering of the multicolour SSOR (hecmw_precond_SSOR_33.f90:102-111 -> hecmw_matrix_ordering_CM.f90:16-178,
+// hecmw_matrix_ordering_MC.f90:15-72) as the library computes it: perm (new -> old, 1-based, N entries) and COLORindex(0:ncolor).
+extern "C" int fx_ssor_ordering(int32_t N, const int32_t *indexL, const int32_t *itemL, const int32_t *indexU, const int32_t *itemU,
+                                int32_t ncolor_in, int32_t *perm, int32_t *colorindex, int32_t colorindex_cap, int32_t *ncolor) {
+  if (N < 1 || ncolor_in < 1) { g_fx_error = "fx_ssor_ordering: N and ncolor_in must be >= 1"; return FX_ERROR_RUNTIME; }
+  fxo::Graph g = fxo::build_graph(N, indexL, itemL, indexU, itemU);
+  std::vector<int32_t> seq = fxo::rcm_sequence(g), p0, cidx;
+  fxo::multicolor(g, seq, ncolor_in, p0, cidx);
+  *ncolor = (int32_t)cidx.size() - 1;
+  if ((int32_t)cidx.size() > colorindex_cap) { g_fx_error = "fx_ssor_ordering: colorindex too small"; return FX_ERROR_RUNTIME; }
+  for (int32_t i = 0; i < N; i++) perm[i] = p0[i] + 1;
+  std::copy(cidx.begin(), cidx.end(), colorindex);
   return 0;
 }
 

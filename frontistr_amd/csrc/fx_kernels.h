@@ -1378,6 +1378,76 @@ __global__ void k_scalar(const double *__restrict__ partials, int32_t nparts, in
   }
 }
 
+// ------------------------------------------------------------------------
+// Level ordering on the device (set-up of the multicolour SSOR): the breadth-first levels of hecmw_matrix_ordering_CM
+// (ordering_CM_inner, hecmw_matrix_ordering_CM.f90:68-136) on the resident CRS arrays.  The reference appends a node when
+// its first parent -- in visiting order -- reaches it, neighbours in the order lower items then upper items; here every
+// unvisited neighbour is claimed by the smallest parent position (atomicMin), each parent counts and then writes the
+// children it won, in its adjacency order, behind an exclusive scan: the sequence is the sequential one, node for node.
+// ------------------------------------------------------------------------
+template <class F>
+__device__ __forceinline__ void bfs_for_neighbours(int32_t u, int32_t N, const int32_t *__restrict__ indexL,
+                                                   const int32_t *__restrict__ itemL, const int32_t *__restrict__ indexU,
+                                                   const int32_t *__restrict__ itemU, F f) {
+  for (int32_t j = indexL[u]; j < indexL[u + 1]; j++) f(itemL[j] - 1);
+  for (int32_t j = indexU[u]; j < indexU[u + 1]; j++) {
+    const int32_t v = itemU[j] - 1;
+    if (v < N) f(v);  // halo columns are not part of the graph
+  }
+}
+__global__ void k_bfs_claim(int32_t nf, const int32_t *__restrict__ frontier, uint32_t f0, int32_t N, const int32_t *__restrict__ indexL,
+                            const int32_t *__restrict__ itemL, const int32_t *__restrict__ indexU, const int32_t *__restrict__ itemU,
+                            const uint8_t *__restrict__ seen, uint32_t *__restrict__ claim) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nf) return;
+  bfs_for_neighbours(frontier[q], N, indexL, itemL, indexU, itemU, [&](int32_t v) {
+    if (!seen[v]) atomicMin(&claim[v], f0 + (uint32_t)q);
+  });
+}
+template <bool WRITE>
+__global__ void k_bfs_children(int32_t nf, const int32_t *__restrict__ frontier, uint32_t f0, int32_t N,
+                               const int32_t *__restrict__ indexL, const int32_t *__restrict__ itemL,
+                               const int32_t *__restrict__ indexU, const int32_t *__restrict__ itemU,
+                               const uint8_t *__restrict__ seen, const uint32_t *__restrict__ claim, int32_t *__restrict__ cnt,
+                               const int32_t *__restrict__ off, int32_t *__restrict__ out) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nf) return;
+  int32_t k = 0;
+  const int32_t o = WRITE ? off[q] : 0;
+  bfs_for_neighbours(frontier[q], N, indexL, itemL, indexU, itemU, [&](int32_t v) {
+    if (!seen[v] && claim[v] == f0 + (uint32_t)q) {
+      if (WRITE) out[o + k] = v;
+      k++;
+    }
+  });
+  if (!WRITE) cnt[q] = k;
+}
+// exclusive scan of n ints by ONE workgroup (n <= a few hundred thousand: a frontier), total -> *total
+__global__ __launch_bounds__(1024) void k_scan_excl(int32_t n, const int32_t *__restrict__ in, int32_t *__restrict__ out,
+                                                    int32_t *__restrict__ total) {
+  __shared__ int32_t sh[1024];
+  const int t = threadIdx.x;
+  const int chunk = (n + 1023) / 1024;
+  const int a = min(n, t * chunk), b = min(n, a + chunk);
+  int32_t s = 0;
+  for (int i = a; i < b; i++) s += in[i];
+  sh[t] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int32_t v = (t >= d) ? sh[t - d] : 0;
+    __syncthreads();
+    sh[t] += v;
+    __syncthreads();
+  }
+  int32_t run = sh[t] - s;  // exclusive prefix of this thread's chunk
+  for (int i = a; i < b; i++) { const int32_t v = in[i]; out[i] = run; run += v; }
+  if (t == 1023) *total = sh[1023];
+}
+__global__ void k_bfs_mark(int32_t n, const int32_t *__restrict__ nodes, uint8_t *__restrict__ seen) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) seen[nodes[i]] = 1;
+}
+
 // natural <-> slot numbering of a 3-dof vector
 __global__ void k_to_slots(int32_t vslots, const int32_t *__restrict__ slot_node, const double *__restrict__ nat,
                            double *__restrict__ out) {

@@ -9,12 +9,27 @@
 // Work is on a 0-based adjacency (lower neighbours first, then upper, halo columns
 // dropped) built once; the up-to-5 candidate start nodes are explored concurrently.
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <thread>
 #include <vector>
 
 namespace fxo {
+
+static int order_threads() {
+  const char *e = getenv("FX_HOST_THREADS");
+  int n = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+  return std::max(1, std::min(n, 32));
+}
+template <class F>
+static void par_for(int64_t n, F f) {  // f(begin, end) on contiguous chunks
+  const int nt = (int)std::min<int64_t>(order_threads(), std::max<int64_t>(1, n / 8192));
+  if (nt <= 1) { f((int64_t)0, n); return; }
+  std::vector<std::thread> th;
+  for (int t = 0; t < nt; t++) th.emplace_back([=] { f(n * t / nt, n * (t + 1) / nt); });
+  for (auto &t : th) t.join();
+}
 
 struct Graph {
   int32_t n = 0;
@@ -27,18 +42,23 @@ Graph build_graph(int32_t N, const int32_t *indexL, const int32_t *itemL, const 
   Graph g;
   g.n = N;
   g.ptr.assign((size_t)N + 1, 0);
-  for (int32_t i = 0; i < N; i++) {
-    int64_t c = indexL[i + 1] - indexL[i];
-    for (int32_t j = indexU[i]; j < indexU[i + 1]; j++) c += (itemU[j] <= N);
-    g.ptr[i + 1] = g.ptr[i] + c;
-  }
+  par_for(N, [&](int64_t a, int64_t b) {
+    for (int64_t i = a; i < b; i++) {
+      int64_t c = indexL[i + 1] - indexL[i];
+      for (int32_t j = indexU[i]; j < indexU[i + 1]; j++) c += (itemU[j] <= N);
+      g.ptr[i + 1] = c;
+    }
+  });
+  for (int32_t i = 0; i < N; i++) g.ptr[i + 1] += g.ptr[i];
   g.adj.resize((size_t)g.ptr[N]);
-  for (int32_t i = 0; i < N; i++) {
-    int64_t w = g.ptr[i];
-    for (int32_t j = indexL[i]; j < indexL[i + 1]; j++) g.adj[w++] = itemL[j] - 1;
-    for (int32_t j = indexU[i]; j < indexU[i + 1]; j++)
-      if (itemU[j] <= N) g.adj[w++] = itemU[j] - 1;
-  }
+  par_for(N, [&](int64_t a, int64_t b) {
+    for (int64_t i = a; i < b; i++) {
+      int64_t w = g.ptr[i];
+      for (int32_t j = indexL[i]; j < indexL[i + 1]; j++) g.adj[w++] = itemL[j] - 1;
+      for (int32_t j = indexU[i]; j < indexU[i + 1]; j++)
+        if (itemU[j] <= N) g.adj[w++] = itemU[j] - 1;
+    }
+  });
   return g;
 }
 
@@ -80,7 +100,8 @@ static int32_t level_order(const Graph &g, int32_t start, std::vector<int32_t> &
 // "RCM" of the reference = level ordering from the best of <= 5 minimum-degree starts,
 // followed by reverse_ordering, which maps node id k -> N-1-k (0-based) instead of
 // reversing the sequence.  Returns the visiting sequence (new -> old, 0-based).
-std::vector<int32_t> rcm_sequence(const Graph &g) {
+// the up-to-5 minimum-degree start candidates (find_minimum_degrees, hecmw_matrix_ordering_CM.f90:138-167)
+std::vector<int32_t> rcm_starts(const Graph &g) {
   const int32_t n = g.n;
   int64_t degmin = n;
   std::vector<int32_t> starts;
@@ -92,6 +113,13 @@ std::vector<int32_t> rcm_sequence(const Graph &g) {
     else if (deg == degmin) { if (++nties <= 5) starts.push_back(i); }
   }
   if (starts.empty()) starts.push_back(0);
+  return starts;
+}
+int32_t level_order_host(const Graph &g, int32_t start, std::vector<int32_t> &seq) { return level_order(g, start, seq); }
+
+std::vector<int32_t> rcm_sequence(const Graph &g) {
+  const int32_t n = g.n;
+  const std::vector<int32_t> starts = rcm_starts(g);
   std::vector<std::vector<int32_t>> seqs(starts.size());
   std::vector<int32_t> nlev(starts.size(), 0);
   std::vector<std::thread> th;
@@ -113,11 +141,29 @@ void multicolor(const Graph &g, const std::vector<int32_t> &seq, int ncolor_in, 
                 std::vector<int32_t> &colorindex) {
   const int32_t n = g.n;
   const int32_t cap = n / ncolor_in;
-  std::vector<int32_t> mark((size_t)n, 0);  // >0 coloured, -1 blocked this round
+  // The walk is sequential by nature (a node is picked iff no neighbour earlier in the order was picked this round: the
+  // lexicographically first independent set, cut off at `cap`), so what can be bought is locality: the graph is relabelled by
+  // position in `seq` first (in parallel), after which the marks a pick touches lie within one level width of the walker instead
+  // of all over the mesh.  Same picks, same order: only the names of the nodes differ during the walk.
+  std::vector<int32_t> pos((size_t)n);
+  par_for(n, [&](int64_t a, int64_t b) { for (int64_t k = a; k < b; k++) pos[seq[k]] = (int32_t)k; });
+  std::vector<int64_t> rptr((size_t)n + 1, 0);
+  par_for(n, [&](int64_t a, int64_t b) { for (int64_t k = a; k < b; k++) rptr[k + 1] = g.ptr[seq[k] + 1] - g.ptr[seq[k]]; });
+  for (int32_t k = 0; k < n; k++) rptr[k + 1] += rptr[k];
+  std::vector<int32_t> radj((size_t)rptr[n]);
+  par_for(n, [&](int64_t a, int64_t b) {
+    for (int64_t k = a; k < b; k++) {
+      int64_t w = rptr[k];
+      const int32_t u = seq[k];
+      for (int64_t e = g.ptr[u]; e < g.ptr[u + 1]; e++) radj[w++] = pos[g.adj[e]];
+    }
+  });
+  std::vector<int32_t> mark((size_t)n, 0);  // by position: >0 coloured, -1 blocked this round
   std::vector<int32_t> blocked;
   // the reference rescans the whole sequence for every colour (:29-60); visiting only the nodes still uncoloured,
   // in the same order, picks the same nodes
-  std::vector<int32_t> rem(seq), next;
+  std::vector<int32_t> rem((size_t)n), next;
+  for (int32_t k = 0; k < n; k++) rem[k] = k;
   next.reserve(rem.size());
   perm.clear();
   perm.reserve(n);
@@ -128,14 +174,14 @@ void multicolor(const Graph &g, const std::vector<int32_t> &seq, int ncolor_in, 
     next.clear();
     size_t q = 0;
     for (; q < rem.size(); q++) {
-      const int32_t u = rem[q];
-      if (mark[u] != 0) { next.push_back(u); continue; }  // blocked in this round: stays for the next one
-      mark[u] = color;
-      perm.push_back(u);
+      const int32_t k = rem[q];
+      if (mark[k] != 0) { next.push_back(k); continue; }  // blocked in this round: stays for the next one
+      mark[k] = color;
+      perm.push_back(seq[k]);
       cnt++;
       if (cnt == cap || (int32_t)perm.size() == n) { q++; break; }
-      for (int64_t e = g.ptr[u]; e < g.ptr[u + 1]; e++) {
-        const int32_t v = g.adj[e];
+      for (int64_t e = rptr[k]; e < rptr[k + 1]; e++) {
+        const int32_t v = radj[e];
         if (mark[v] == 0) { mark[v] = -1; blocked.push_back(v); }
       }
     }

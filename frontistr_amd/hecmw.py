@@ -355,7 +355,7 @@ def hecmw_mat_con(hecMESH, hecMAT):
     _chk(lib().fx_mat_con(NP, conn.shape[0], 8, _ptr(conn), _ptr(indexL), _ptr(indexU), _ptr(itemL), _ptr(itemU)))
     hecMAT.N, hecMAT.NP = hecMESH.nn_internal, NP
     hecMAT.indexL, hecMAT.indexU = indexL, indexU
-    hecMAT.itemL, hecMAT.itemU = itemL[:indexL[NP]].copy(), itemU[:indexU[NP]].copy()
+    hecMAT.itemL, hecMAT.itemU = itemL[:indexL[NP]], itemU[:indexU[NP]]       # exact-size arrays (views when nothing is cut)
     hecMAT.NPL, hecMAT.NPU = int(indexL[NP]), int(indexU[NP])
     hecMAT.B = np.zeros(3 * NP)
     hecMAT.X = np.zeros(3 * NP)

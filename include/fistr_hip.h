@@ -157,6 +157,15 @@ int fx_dot_host(fx_context *ctx, const double *x, const double *y, double *resul
 int fx_mat_con(int32_t NP, int32_t n_elem, int32_t nn, const int32_t *conn, int32_t *indexL,
                int32_t *indexU, int32_t *itemL, int32_t *itemU);
 
+/* Host only: the ordering of the multicolour SSOR as the library computes it (reference: hecmw_precond_SSOR_33.f90:102-111 ->
+ * hecmw_matrix_ordering_CM.f90:16-178 "RCM" + hecmw_matrix_ordering_MC.f90:15-72 greedy capped multicolouring; the path the
+ * reference takes with more than one OpenMP thread).  perm: N entries, new -> old, 1-based; colorindex: COLORindex(0:ncolor). */
+int fx_ssor_ordering(int32_t N, const int32_t *indexL, const int32_t *itemL, const int32_t *indexU, const int32_t *itemU,
+                     int32_t ncolor_in, int32_t *perm, int32_t *colorindex, int32_t colorindex_cap, int32_t *ncolor);
+
+/* The same two arrays as the resident preconditioner was built with (large systems run the level ordering on the device). */
+int fx_get_ssor_ordering(fx_context *ctx, int32_t *perm, int32_t *colorindex, int32_t colorindex_cap, int32_t *ncolor);
+
 /* Host only: the element colouring behind the atomic-free stiffness scatter (no two elements of a colour share a node;
  * the reference serialises the same conflicts with `!$omp atomic`, hecmw_mat_ass.f90:72-134).  order: n_elem element ids
  * (0-based) grouped by colour; offsets: 65 entries, offsets[k]..offsets[k+1] = colour k; *ncolor = 0 when a node belongs

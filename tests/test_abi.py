@@ -5,7 +5,7 @@ import re
 
 import numpy as np
 
-from conftest import load_golden, ROOT
+from conftest import golden_matrix, load_golden, ROOT
 
 
 def _declared():
@@ -100,3 +100,34 @@ def test_color_elements_is_a_valid_colouring():
     off = np.zeros(65, dtype=np.int32)
     nc = C.c_int32(0)
     assert L.fx_color_elements(m.n_node, bad.shape[0], 8, hecmw._ptr(bad), hecmw._ptr(order), hecmw._ptr(off), C.byref(nc)) != 0
+
+
+def _lib_ordering(m, ncolor_in):
+    import ctypes as C
+    from frontistr_amd import hecmw
+    L = hecmw.lib()
+    perm = np.zeros(m.N, dtype=np.int32)
+    cidx = np.zeros(m.N + 2, dtype=np.int32)
+    nc = C.c_int32(0)
+    ptr = lambda a: np.ascontiguousarray(a, dtype=np.int32).ctypes.data_as(C.c_void_p)
+    iL, jL, iU, jU = (np.ascontiguousarray(a, dtype=np.int32) for a in (m.indexL, m.itemL, m.indexU, m.itemU))
+    assert L.fx_ssor_ordering(m.N, ptr(iL), ptr(jL), ptr(iU), ptr(jU), ncolor_in, perm.ctypes.data_as(C.c_void_p),
+                              cidx.ctypes.data_as(C.c_void_p), cidx.size, C.byref(nc)) == 0
+    return perm, cidx[:nc.value + 1].copy()
+
+
+def test_ssor_ordering_is_the_references(oracle):
+    """Host only: the library's level ordering + capped greedy multicolouring (threaded graph build, the colouring walk on a
+    graph relabelled by visiting position) against the oracle's restatement of hecmw_matrix_ordering_CM / _MC, which produces
+    the reference's colours (bit-exact SSOR runs, tests/test_oracle_golden.py): same perm, same COLORindex, several
+    NCOLOR_IN, a structured cube large enough for the threaded paths and a skewed one."""
+    from frontistr_amd.mesh import CubeMesh
+    cases = [(golden_matrix(load_golden(d)), nc) for d in ("cube4", "cube3s", "exA_A361") for nc in (10, 3)]
+    for n, skew, nc in ((12, 0.05, 10), (33, 0.0, 10), (20, 0.0, 4)):
+        mesh = CubeMesh(n, skew=skew)
+        cases.append((oracle.assemble(1, mesh.coord, mesh.conn, 210000.0, 0.3, bc=mesh.dirichlet(), load=mesh.load()), nc))
+    for A, nc in cases:
+        P = oracle.Precond(A, 1, ncolor_in=nc, nthreads=4)
+        perm, cidx = _lib_ordering(A, nc)
+        assert np.array_equal(cidx, P.colorindex), (A.N, nc)
+        assert np.array_equal(perm, P.perm), (A.N, nc)

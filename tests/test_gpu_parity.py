@@ -797,3 +797,30 @@ def test_eisenstat_form_of_cg_ssor(hip, oracle, deck, sigma, monkeypatch):
     n = min(len(h), len(h0))
     if whole:
         assert np.all(np.abs(h[:n] - h0[:n]) <= 0.25 * h0[:n])
+
+
+@pytest.mark.parametrize("n,skew", [(4, 0.0), (12, 0.05), (47, 0.0)])
+def test_device_level_ordering_equals_host_ordering(hip, n, skew, monkeypatch):
+    """The breadth-first level ordering of the SSOR set-up on the device (k_bfs_*: claim by the smallest parent position, count,
+    scan, write) must give the host walk's sequence node for node, hence the same colours: perm and COLORindex of the resident
+    preconditioner against the host-only fx_ssor_ordering, with the device path forced on small meshes and taken by default on
+    the 110k-node one."""
+    import ctypes as C
+    from frontistr_amd.mesh import CubeMesh
+    from test_abi import _lib_ordering
+    mesh = CubeMesh(n, skew=skew)
+    hm = hip.hecmwST_local_mesh(n_node=mesh.n_node)
+    hm.elem_node_item = mesh.conn.ravel()
+    m = hip.hecmw_mat_con(hm, hip.hecmwST_matrix())
+    if n < 47:
+        monkeypatch.setenv("FX_BFS_DEVICE_MIN", "0")
+    ctx = hip.SolverContext()
+    ctx.upload(m, what=hip.FX_UP_PROFILE)
+    ctx.assemble_c3d8(mesh.coord, mesh.conn, 210000.0, 0.3, elemopt=1, load=mesh.load(), bc=mesh.dirichlet())
+    m.Iarray[2] = 1
+    ctx.precond_setup(m)
+    perm = np.zeros(m.N, dtype=np.int32); cidx = np.zeros(m.N + 2, dtype=np.int32); nc = C.c_int32(0)
+    assert hip.lib().fx_get_ssor_ordering(ctx.h, perm.ctypes.data_as(C.c_void_p), cidx.ctypes.data_as(C.c_void_p), cidx.size, C.byref(nc)) == 0
+    hperm, hcidx = _lib_ordering(m, 10)
+    assert np.array_equal(cidx[:nc.value + 1], hcidx) and np.array_equal(perm, hperm)
+    ctx.close()
