@@ -255,6 +255,7 @@ extern "C" int fx_create(int device, fx_context **out) {
   }
   if (const char *e = getenv("FX_TUNE_PLACEMENT")) c->tune_tries = std::max(0, atoi(e));
   if (const char *e = getenv("FX_BFS_DEVICE_MIN")) c->bfs_device_min = atoi(e);
+  if (const char *e = getenv("FX_LAYOUT_DEVICE")) c->layout_device = atoi(e) != 0;
   if (const char *e = getenv("FX_PIPE_SPMV")) c->pipe_spmv = atoi(e) != 0;
   if (const char *e = getenv("FX_PIPE_SSOR")) c->pipe_ssor = atoi(e) != 0;
   if (const char *e = getenv("FX_SSOR_MODE")) c->ssor_mode = atoi(e);
@@ -425,6 +426,58 @@ static int bell_build2(fx_context *c, Bell &b, int32_t nslots, const std::vector
   return 0;
 }
 
+// The same layout built on the device (kernels k_bell_count / k_bell_map, fx_kernels.h): d_slot_row, d_slot_of (node -> vector
+// slot, NP entries) and d_newpos (node -> new index, SSOR variants only) are device arrays.  Returns 1 when a row is longer than
+// the kernels' per-thread buffer (the caller then uses the host builder), 0 on success, < 0 on a runtime failure.
+static int bell_build_device(fx_context *c, Bell &b, int variant, int32_t nslots, const int32_t *d_slot_row,
+                             const int32_t *d_slot_of, const int32_t *d_newpos) {
+  if (!c->layout_device) return 1;
+  bell_free(b);
+  b.nslots = nslots;
+  b.nslices = (nslots + 63) / 64;
+  const DevCSR &A = c->A;
+  DevScratch tmp;
+  int32_t *width = nullptr;
+  unsigned long long *totals = nullptr;
+  if (tmp.alloc(&width, (size_t)b.nslices + 1) || tmp.alloc(&totals, 4)) return FX_ERROR_RUNTIME;
+  HIP_TRY(hipMemsetAsync(totals, 0, 32, c->stream));
+  if (dev_alloc(&b.pair_ptr, (size_t)b.nslices + 1)) return FX_ERROR_RUNTIME;
+  const dim3 g1((nslots + 255) / 256), b1(256);
+#define BELL_VAR(K, ...)                                                        \
+  switch (variant) {                                                            \
+    case BV_FULL: hipLaunchKernelGGL((K<BV_FULL>), __VA_ARGS__); break;         \
+    case BV_SSOR_L: hipLaunchKernelGGL((K<BV_SSOR_L>), __VA_ARGS__); break;     \
+    case BV_SSOR_U: hipLaunchKernelGGL((K<BV_SSOR_U>), __VA_ARGS__); break;     \
+    case BV_ILU_L: hipLaunchKernelGGL((K<BV_ILU_L>), __VA_ARGS__); break;       \
+    default: hipLaunchKernelGGL((K<BV_ILU_U>), __VA_ARGS__); break;             \
+  }
+  BELL_VAR(k_bell_count, g1, b1, 0, c->stream, nslots, d_slot_row, A.N, A.indexL, A.itemL, A.indexU, A.itemU, d_newpos, width, totals)
+  hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, c->stream, b.nslices, width, b.pair_ptr, b.pair_ptr + b.nslices);
+  unsigned long long h_tot[4];
+  HIP_TRY(hipMemcpyAsync(h_tot, totals, 32, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipGetLastError());
+  if (h_tot[2] > FX_BELL_MAXROW) { bell_free(b); return 1; }
+  if (h_tot[1] > (unsigned long long)INT32_MAX) { g_fx_error = "BELL: block-position count overflows int32"; return FX_ERROR_RUNTIME; }
+  b.nblocks = (int64_t)h_tot[0];
+  b.npairs = (int64_t)h_tot[1];
+  const size_t tot = (size_t)b.npairs;
+  if (dev_alloc(&b.col2, tot * 64) || dev_alloc(&b.src2, tot * 64)) return FX_ERROR_RUNTIME;
+  {
+    size_t pad = 0;
+    if (const char *e = getenv("FX_VAL2_PAD")) pad = (size_t)atoll(e);
+    char *base = nullptr;
+    if (dev_alloc(&base, tot * 576 * 8 + pad)) return FX_ERROR_RUNTIME;
+    b.val2_base = base;
+    b.val2 = (double *)(base + pad);
+  }
+  BELL_VAR(k_bell_map, dim3(b.nslices), dim3(64), 0, c->stream, nslots, b.nslices, d_slot_row, A.N, A.indexL, A.itemL, A.indexU,
+           A.itemU, d_slot_of, d_newpos, b.pair_ptr, b.col2, b.src2)
+#undef BELL_VAR
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 static int bell_fill_values(fx_context *c, Bell &b, const double *D = nullptr, const double *AL = nullptr,
                             const double *AU = nullptr) {
   if (b.nslices == 0) return 0;
@@ -495,7 +548,11 @@ static int build_full_bell(fx_context *c) {
     return FX_ERROR_UNSUPPORTED;
   }
   std::vector<int32_t> sr(o.slot_node.begin(), o.slot_node.begin() + o.nslots);
-  if (bell_build2(c, c->M, o.nslots, &sr, count, fill)) return FX_ERROR_RUNTIME;
+  {
+    const int e = bell_build_device(c, c->M, BV_FULL, o.nslots, o.d_slot_node, o.d_slot_of, nullptr);
+    if (e < 0) return FX_ERROR_RUNTIME;
+    if (e > 0 && bell_build2(c, c->M, o.nslots, &sr, count, fill)) return FX_ERROR_RUNTIME;  // a row longer than the device buffer
+  }
   if (o.kind == 1 && c->spmv_spatial) {  // walk the slices by the mesh position of their rows, all colours of a region together
     const int32_t nsl = c->M.nslices;
     std::vector<int32_t> key((size_t)nsl, INT32_MAX), ordv((size_t)nsl);
@@ -1153,10 +1210,19 @@ static int ssor_setup_symbolic(fx_context *c, int ncolor_in) {
   };
   auto fillL = [&](int32_t slot, std::vector<BellEntry> &e) { collect(slot, e, true); };
   auto fillU = [&](int32_t slot, std::vector<BellEntry> &e) { collect(slot, e, false); };
-  if (bell_build2(c, S.L, nslots, &slot_row, countL, fillL)) return FX_ERROR_RUNTIME;
-  pt.lap("lower layout");
-  if (bell_build2(c, S.U, nslots, &slot_row, countU, fillU)) return FX_ERROR_RUNTIME;
-  pt.lap("upper layout");
+  {  // the two sweep layouts on the device (host builder only for rows longer than the kernels' buffer)
+    DevScratch tmp;
+    int32_t *d_so = nullptr, *d_np = nullptr;
+    if (tmp.alloc(&d_so, (size_t)N) || tmp.alloc(&d_np, (size_t)N)) return FX_ERROR_RUNTIME;
+    HIP_TRY(hipMemcpy(d_so, slot_of.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_np, newpos.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+    int e = bell_build_device(c, S.L, BV_SSOR_L, nslots, S.slot_node, d_so, d_np);
+    if (e < 0 || (e > 0 && bell_build2(c, S.L, nslots, &slot_row, countL, fillL))) return FX_ERROR_RUNTIME;
+    pt.lap("lower layout");
+    e = bell_build_device(c, S.U, BV_SSOR_U, nslots, S.slot_node, d_so, d_np);
+    if (e < 0 || (e > 0 && bell_build2(c, S.U, nslots, &slot_row, countU, fillU))) return FX_ERROR_RUNTIME;
+    pt.lap("upper layout");
+  }
   dev_free(S.alu);
   if (dev_alloc(&S.alu, (size_t)(nslots / 64) * 576)) return FX_ERROR_RUNTIME;
   return 0;
@@ -1267,10 +1333,18 @@ static int ilu_setup_symbolic(fx_context *c) {
     for (int32_t j = iU[r + 1] - 1; j >= iU[r]; j--)
       if (jU[j] <= N) e.push_back({3 * j + 2, so[jU[j] - 1]});
   };
-  if (bell_build2(c, S.L, nslots, &slot_row, countL, fillL)) return FX_ERROR_RUNTIME;
-  pt.lap("lower layout");
-  if (bell_build2(c, S.U, nslots, &slot_row, countU, fillU)) return FX_ERROR_RUNTIME;
-  pt.lap("upper layout");
+  {
+    DevScratch tmp;
+    int32_t *d_so = nullptr;
+    if (tmp.alloc(&d_so, (size_t)N)) return FX_ERROR_RUNTIME;
+    HIP_TRY(hipMemcpy(d_so, slot_of.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+    int e = bell_build_device(c, S.L, BV_ILU_L, nslots, S.slot_node, d_so, nullptr);
+    if (e < 0 || (e > 0 && bell_build2(c, S.L, nslots, &slot_row, countL, fillL))) return FX_ERROR_RUNTIME;
+    pt.lap("lower layout");
+    e = bell_build_device(c, S.U, BV_ILU_U, nslots, S.slot_node, d_so, nullptr);
+    if (e < 0 || (e > 0 && bell_build2(c, S.U, nslots, &slot_row, countU, fillU))) return FX_ERROR_RUNTIME;
+    pt.lap("upper layout");
+  }
   dev_free(S.alu);
   if (dev_alloc(&S.alu, (size_t)(nslots / 64) * 576)) return FX_ERROR_RUNTIME;
   return 0;

@@ -255,6 +255,7 @@ struct fx_context {
   // (scripts/experiments/ab_ssor.py with FX_DUMMY_MB / FX_PLACEMENT_DEBUG).  So the library measures: up to tune_tries
   // candidate allocations are filled and timed (3 SpMV launches each), the fastest is kept, the others are released.
   // Large systems only (>= tune_min_slices), once per symbolic build, bounded by free device memory.  FX_TUNE_PLACEMENT=0 off.
+  bool layout_device = true;        // BELL source maps built by k_bell_count / k_bell_map (FX_LAYOUT_DEVICE=0: host threads)
   int32_t bfs_device_min = 100000;  // block rows from which the level ordering of the SSOR set-up runs on the device (FX_BFS_DEVICE_MIN)
   int tune_tries = 12;
   int32_t tune_min_slices = 8192;

@@ -1448,6 +1448,126 @@ __global__ void k_bfs_mark(int32_t n, const int32_t *__restrict__ nodes, uint8_t
   if (i < n) seen[nodes[i]] = 1;
 }
 
+// ------------------------------------------------------------------------
+// BELL source maps built on the DEVICE (set-up): which block goes where is a pure function of the resident CRS profile, the
+// slot order and -- for the SSOR sweeps -- the new numbering, so it needs neither the host threads nor a 720 MB upload.
+// One thread per slot generates its row's entries in the order the sweep consumes them:
+//   FULL    D, then the lower items, then the upper items, ascending (the reference's summation order, las_33.f90:263-300)
+//   SSOR_L  blocks whose column comes EARLIER in the colour ordering, ascending new index   (SSOR_33.f90:312)
+//   SSOR_U  blocks whose column comes LATER, descending new index                          (SSOR_33.f90:369); halo columns dropped
+//   ILU_L   lower items ascending (BILU_33.f90:104-111);  ILU_U  upper items descending, halo columns dropped (:133)
+// Pass 1 (k_bell_count) gives every slice its width (the longest row) and the block total; an exclusive scan turns widths into
+// pair_ptr; pass 2 (k_bell_map) writes column slots and source codes (3 * index + {0 D, 1 AL, 2 AU}, -1 padding) into the layout.
+// ------------------------------------------------------------------------
+enum BellVariant { BV_FULL = 0, BV_SSOR_L, BV_SSOR_U, BV_ILU_L, BV_ILU_U };
+#define FX_BELL_MAXROW 160
+
+template <int VAR>
+__device__ __forceinline__ int bell_row_entries(int32_t r, int32_t self_slot, int32_t N, const int32_t *__restrict__ iL,
+                                                const int32_t *__restrict__ jL, const int32_t *__restrict__ iU,
+                                                const int32_t *__restrict__ jU, const int32_t *__restrict__ slot_of,
+                                                const int32_t *__restrict__ newpos, int32_t *src, int32_t *col, int32_t *key) {
+  int k = 0;
+  if (VAR == BV_FULL) {
+    if (src) { src[0] = 3 * r; col[0] = self_slot; }
+    k = 1;
+    for (int32_t j = iL[r]; j < iL[r + 1]; j++, k++)
+      if (src && k < FX_BELL_MAXROW) { src[k] = 3 * j + 1; col[k] = slot_of[jL[j] - 1]; }
+    for (int32_t j = iU[r]; j < iU[r + 1]; j++, k++)
+      if (src && k < FX_BELL_MAXROW) { src[k] = 3 * j + 2; col[k] = slot_of[jU[j] - 1]; }
+    return k;
+  }
+  if (VAR == BV_ILU_L) {
+    for (int32_t j = iL[r]; j < iL[r + 1]; j++, k++)
+      if (src && k < FX_BELL_MAXROW) { src[k] = 3 * j + 1; col[k] = slot_of[jL[j] - 1]; }
+    return k;
+  }
+  if (VAR == BV_ILU_U) {
+    for (int32_t j = iU[r + 1] - 1; j >= iU[r]; j--) {
+      if (jU[j] > N) continue;
+      if (src && k < FX_BELL_MAXROW) { src[k] = 3 * j + 2; col[k] = slot_of[jU[j] - 1]; }
+      k++;
+    }
+    return k;
+  }
+  // SSOR_L / SSOR_U: select by the new index of the column, then order by it
+  const bool lower = (VAR == BV_SSOR_L);
+  const int32_t me = newpos[r];
+  for (int32_t j = iL[r]; j < iL[r + 1]; j++) {
+    const int32_t co = jL[j] - 1, kp = newpos[co];
+    if ((kp < me) != lower) continue;
+    if (src && k < FX_BELL_MAXROW) { src[k] = 3 * j + 1; col[k] = slot_of[co]; key[k] = kp; }
+    k++;
+  }
+  for (int32_t j = iU[r]; j < iU[r + 1]; j++) {
+    const int32_t co = jU[j] - 1;
+    if (co >= N) continue;
+    const int32_t kp = newpos[co];
+    if ((kp < me) != lower) continue;
+    if (src && k < FX_BELL_MAXROW) { src[k] = 3 * j + 2; col[k] = slot_of[co]; key[k] = kp; }
+    k++;
+  }
+  if (src) {  // insertion sort by key (distinct keys: the order is unique); ascending for L, descending for U
+    const int n = k < FX_BELL_MAXROW ? k : FX_BELL_MAXROW;
+    for (int a = 1; a < n; a++) {
+      const int32_t ks = key[a], ss = src[a], cs = col[a];
+      int b = a - 1;
+      while (b >= 0 && (lower ? key[b] > ks : key[b] < ks)) { key[b + 1] = key[b]; src[b + 1] = src[b]; col[b + 1] = col[b]; b--; }
+      key[b + 1] = ks; src[b + 1] = ss; col[b + 1] = cs;
+    }
+  }
+  return k;
+}
+
+template <int VAR>
+__global__ __launch_bounds__(256) void k_bell_count(int32_t nslots, const int32_t *__restrict__ slot_row, int32_t N,
+                                                    const int32_t *__restrict__ iL, const int32_t *__restrict__ jL,
+                                                    const int32_t *__restrict__ iU, const int32_t *__restrict__ jU,
+                                                    const int32_t *__restrict__ newpos, int32_t *__restrict__ width,
+                                                    unsigned long long *__restrict__ totals /* [0] blocks, [1] positions, [2] longest row */) {
+  const int slot = blockIdx.x * 256 + threadIdx.x;
+  int k = 0;
+  if (slot < nslots) {
+    const int32_t r = slot_row[slot];
+    if (r >= 0) k = bell_row_entries<VAR>(r, slot, N, iL, jL, iU, jU, nullptr, newpos, nullptr, nullptr, nullptr);
+  }
+  int w = k;
+  long long sum = k;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    w = max(w, __shfl_down(w, off, 64));
+    sum += __shfl_down(sum, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0 && slot < nslots) {
+    width[slot >> 6] = w;
+    atomicAdd(&totals[0], (unsigned long long)sum);
+    atomicAdd(&totals[1], (unsigned long long)w);
+    atomicMax(&totals[2], (unsigned long long)w);
+  }
+}
+
+template <int VAR>
+__global__ __launch_bounds__(64) void k_bell_map(int32_t nslots, int32_t nslices, const int32_t *__restrict__ slot_row, int32_t N,
+                                                 const int32_t *__restrict__ iL, const int32_t *__restrict__ jL,
+                                                 const int32_t *__restrict__ iU, const int32_t *__restrict__ jU,
+                                                 const int32_t *__restrict__ slot_of, const int32_t *__restrict__ newpos,
+                                                 const int32_t *__restrict__ pair_ptr, int *__restrict__ col2, int *__restrict__ src2) {
+  const int slice = blockIdx.x, lane = threadIdx.x;
+  const int slot = slice * 64 + lane;
+  const int32_t h0 = pair_ptr[slice], h1 = pair_ptr[slice + 1];
+  const int32_t npair2 = ((h1 - h0) >> 1) << 1;
+  int32_t src[FX_BELL_MAXROW], col[FX_BELL_MAXROW], key[FX_BELL_MAXROW];
+  int k = 0;
+  const int32_t r = slot < nslots ? slot_row[slot] : -1;
+  if (r >= 0) k = bell_row_entries<VAR>(r, slot, N, iL, jL, iU, jU, slot_of, newpos, src, col, key);
+  const int32_t self = min(slot, nslices * 64 - 1);  // padding: value 0 against the row's own (always valid) vector slot
+  for (int32_t q = 0; q < h1 - h0; q++) {
+    const size_t idx = q < npair2 ? (size_t)(h0 + (q & ~1)) * 64 + (size_t)lane * 2 + (q & 1) : (size_t)(h0 + q) * 64 + lane;
+    col2[idx] = q < k ? col[q] : self;
+    src2[idx] = q < k ? src[q] : -1;
+  }
+}
+
 // natural <-> slot numbering of a 3-dof vector
 __global__ void k_to_slots(int32_t vslots, const int32_t *__restrict__ slot_node, const double *__restrict__ nat,
                            double *__restrict__ out) {
