@@ -672,6 +672,7 @@ static int ensure_solver(fx_context *c) {
   if (!c->bell_valid && c->have_values) {
     if (bell_fill_values(c, c->M)) return FX_ERROR_RUNTIME;
     c->bell_valid = true;
+    c->values_epoch++;  // the SpMV layout holds new values from here on
     if (!c->M.placed && tune_value_placement(c)) return FX_ERROR_RUNTIME;
   }
   return 0;
@@ -1266,6 +1267,7 @@ static int ssor_setup_numeric(fx_context *c, double sigma_diag) {
   hipLaunchKernelGGL(k_alu_setup, dim3((nslots + 255) / 256), dim3(256), 0, c->stream, nslots, c->A.N, S.slot_node, c->A.D,
                      sigma_diag, S.alu);
   S.sigma_diag = sigma_diag;
+  S.values_epoch = c->values_epoch;  // the sweep layouts hold the values the SpMV layout holds (fx_precond_setup ran ensure_solver first)
   if (c->eisenstat) {  // Eisenstat form: the diagonal blocks themselves, next to their factors
     if (!S.dblk && dev_alloc(&S.dblk, (size_t)(nslots / 64) * 576)) return FX_ERROR_RUNTIME;
     hipLaunchKernelGGL(k_dblk_setup, dim3((nslots + 255) / 256), dim3(256), 0, c->stream, nslots, c->A.N, S.slot_node, c->A.D, S.dblk);
@@ -1614,6 +1616,7 @@ static int poll_state(fx_context *c, KrylovState *out) {
 // Partial sums: ||r||^2 and ph.w in region 0 of c->partials, rho = t.dt in region 1 (it is consumed one scalar stage later).
 // ---------------------------------------------------------------------------
 static int eis_sweep_backward(fx_context *c, const double *rhs, double *out, const int32_t *gate) {  // out = (D~+U)^-1 rhs
+  ClockScope cs(c, 1);  // TIMELOG: the triangular solves count as solver/precond, the pass that delivers q = A p as solver/matvec
   SsorDev &S = c->ssor;
   const int spb = c->ssor_bs / 64;
   for (int col = S.ncolor - 1; col >= 0; col--) {
@@ -1633,6 +1636,7 @@ static int eis_sweep_backward(fx_context *c, const double *rhs, double *out, con
   return 0;
 }
 static int eis_sweep_forward_solve(fx_context *c, const double *rhs, double *out, const int32_t *gate) {  // out = (D~+L)^-1 rhs
+  ClockScope cs(c, 1);
   SsorDev &S = c->ssor;
   const int spb = c->ssor_bs / 64;
   for (int col = 0; col < S.ncolor; col++) {
@@ -1683,6 +1687,7 @@ static int eis_cg_iteration(fx_context *c, int it) {
   if (eis_sweep_backward(c, PH, P, gate_status(c))) return FX_ERROR_RUNTIME;
   // one pass over L: v, w = (D~+L)^-1 A p, q = A p, partial of p.q = ph.w (:204-211)
   {
+    ClockScope cs(c, 0);
     const int spb = c->ssor_bs / 64;
     int off = 0;
     for (int col = 0; col < S.ncolor; col++) {
@@ -1756,8 +1761,10 @@ static int krylov_begin(fx_context *c, int method, int maxit, double tol) {
   if (scalar_stage<OP_BNRM2>(c, np, 0, 50)) return FX_ERROR_RUNTIME;
   HIP_TRY(hipGetLastError());
   // Eisenstat's form: CG + multicolour SSOR(1) on one rank in the colour-major numbering, when asked for
+  // ... and only while M was built from the very values A holds: a recycled preconditioner (hecmw_mat_recycle_precond_setting keeps
+  // the old one for up to three changed matrices) is a different splitting, and the identity A = (D~+L) + (D~+U) + (D - 2D~) is gone
   c->eis_active = c->eisenstat && method == 1 && c->precond_kind == 1 && c->ord.kind == 1 && c->iterpremax == 1 && c->ssor.dblk &&
-                  !halo_active(c) && !multi_rank(c);
+                  c->ssor.values_epoch == c->values_epoch && !halo_active(c) && !multi_rank(c);
   if (c->eis_active) { c->k_graph = false; if (eis_begin(c)) return FX_ERROR_RUNTIME; }
   return 0;
 }

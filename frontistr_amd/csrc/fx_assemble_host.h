@@ -13,7 +13,7 @@ struct MatConCache {
   std::vector<int32_t> rows;  // per node: sorted unique neighbour ids (1-based), itself included
   void clear() { conn = nullptr; std::vector<int64_t>().swap(rptr); std::vector<int32_t>().swap(rows); }
 };
-static MatConCache g_matcon;
+static thread_local MatConCache g_matcon;  // per calling thread: the count and the fill call of one profile come from the same thread; concurrent callers (one thread per subdomain) do not share it
 
 extern "C" int fx_mat_con(int32_t NP, int32_t n_elem, int32_t nn, const int32_t *conn, int32_t *indexL, int32_t *indexU,
                           int32_t *itemL, int32_t *itemU) {

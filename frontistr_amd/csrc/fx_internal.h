@@ -90,6 +90,7 @@ struct SsorDev {
   double *alu = nullptr;             // LU of the diagonal blocks, [slice][e][lane] layout
   double *dblk = nullptr;            // Eisenstat form: the diagonal blocks themselves (unfactored, unscaled), same layout
   double sigma_diag = 1.0;           // SIGMA_DIAG the factors in alu were built with
+  int64_t values_epoch = -1;         // fx_context::values_epoch the sweep layouts were filled at
   int32_t nslots = 0;                // colour-major slots (each colour padded to a 64 multiple)
   int32_t *slot_node = nullptr;      // device: slot -> 0-based node, -1 = padding
   double *zs = nullptr;              // private sweep vector, 3*nslots, colour-major
@@ -250,6 +251,7 @@ struct fx_context {
   // summation order of q and of the dot products differs, so histories agree to rounding, not bit for bit: hence opt-in.
   // Single rank, multicolour SSOR with iterPREmax = 1, colour-major numbering; anything else runs the standard loop.
   bool eisenstat = false, eis_active = false;
+  int64_t values_epoch = 0;  // counts the refreshes of the SpMV layout's values
   // Placement search of the SpMV's value array.  The identical kernel on identical data runs at 1.03-1.19 ms (10.1M DOF)
   // depending on WHERE hipMalloc put the 6.5 GB value array physically: same virtual layout, same alignment, different speed
   // (scripts/experiments/ab_ssor.py with FX_DUMMY_MB / FX_PLACEMENT_DEBUG).  So the library measures: up to tune_tries
