@@ -661,6 +661,8 @@ static int tune_value_placement(fx_context *c) {
     return 0;
   };
   const double bytes = (double)M.npairs * 64 * 76 + 48.0 * c->ord.nslots;
+  // (The vector the product writes was tried as a second knob -- scripts/experiments/ab_vectors.py showed 1.066 against 1.11 ms
+  // between work vectors in one context -- but at set-up time the ten candidates lie within 0.5 % of each other: not kept.)
   return tune_placement(c, M, "SpMV", bytes, 6600.0, [&]() { return bell_fill_values(c, M); }, time_spmv);
 }
 
@@ -2212,10 +2214,18 @@ extern "C" int fx_spmv_resident(fx_context *c, int variant, int nrepeat, float *
   if (ensure_solver(c)) return FX_ERROR_RUNTIME;
   if (to_slots(c, c->A.B, c->Bs)) return FX_ERROR_RUNTIME;
   const int mode = variant == 2 ? 1 : 0, dot = variant;
-  if (spmv(c, mode, dot, c->Bs, c->Bs, c->W[7], nullptr, 0)) return FX_ERROR_RUNTIME;  // untimed first touch
+  double *xin = c->Bs, *yout = c->W[7];
+  if (const char *e = getenv("FX_SPMV_XY")) {  // placement experiments: which work vectors play x and y ("2,1" = the CG loop's p and q)
+    int a = -1, b = -1;
+    if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && a < 10 && b >= 0 && b < 10 && a != b) {
+      xin = c->W[a]; yout = c->W[b];
+      HIP_TRY(hipMemcpyAsync(xin, c->Bs, (size_t)c->wlen * 8, hipMemcpyDeviceToDevice, c->stream));
+    }
+  }
+  if (spmv(c, mode, dot, xin, c->Bs, yout, nullptr, 0)) return FX_ERROR_RUNTIME;  // untimed first touch
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
   for (int i = 0; i < nrepeat; i++)
-    if (spmv(c, mode, dot, c->Bs, c->Bs, c->W[7], nullptr, 0)) return FX_ERROR_RUNTIME;
+    if (spmv(c, mode, dot, xin, c->Bs, yout, nullptr, 0)) return FX_ERROR_RUNTIME;
   HIP_TRY(hipEventRecord(c->ev1, c->stream));
   HIP_TRY(hipEventSynchronize(c->ev1));
   HIP_TRY(hipGetLastError());

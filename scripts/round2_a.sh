@@ -5,7 +5,8 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/r02
 mkdir -p $OUT
 cd $R
-timeout -k 10 300 python bench.py > $OUT/bench_10m_cg_ssor.json 2> $OUT/bench_10m_cg_ssor.err && echo "bench ok" && \
+FX_TIMING=1 timeout -k 10 300 python bench.py > $OUT/bench_10m_cg_ssor.json 2> $OUT/bench_10m_cg_ssor.err && echo "bench ok" && \
+timeout -k 10 300 python bench.py --eisenstat --no-cpu-baseline > $OUT/bench_10m_cg_ssor_eisenstat.json 2> $OUT/bench_eis.err && echo "bench eisenstat ok" && \
 timeout -k 10 300 python bench.py --elems 69 --precond 3 > $OUT/bench_1m_cg_diag.json 2> $OUT/bench_1m.err && echo "bench1m ok" && \
 timeout -k 10 300 python bench.py --method 2 --precond 10 --steps 40 --warmup 5 --no-cpu-baseline > $OUT/bench_10m_bicgstab_ilu0.json 2> $OUT/bench_ilu.err && echo "benchilu ok" && \
 FX_BENCH_TRANSPORT=gloo timeout -k 10 400 python bench.py --gpus 2 --steps 30 --warmup 5 > $OUT/bench_2rank_rehearsal.json 2> $OUT/bench_2rank.err && echo "2rank ok" && \
