@@ -14,8 +14,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ilu -- python3 $R/b
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/ilu_fetch -- python3 $R/bench.py --method 2 --precond 10 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/ilu_fetch.json 2> $OUT/ilu_fetch.err && echo ilu fetch ok && \
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/nl -- python3 $R/scripts/bench_nonlinear.py 149 2 10 2 > $OUT/nl.log 2> $OUT/nl.err && echo nl ok && \
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/asm -- python3 $R/scripts/bench_assembly.py 149 > $OUT/asm.log 2> $OUT/asm.err && echo asm ok && \
+FX_EISENSTAT=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/eis -- python3 $R/bench.py $ARGS > $OUT/eis.json 2> $OUT/eis.err && echo eis ok && \
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/nn1 -- python3 $R/scripts/bench_nn.py 1 150 > $OUT/nn1.log 2> $OUT/nn1.err && echo nn1 ok
-for d in ilu nl asm nn1; do f=$(find $OUT/$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${d}_kernel_stats.csv; done
+for d in ilu nl asm nn1 eis; do f=$(find $OUT/$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${d}_kernel_stats.csv; done
 f=$(find $OUT/ilu_fetch -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python3 - "$f" <<'PY' > $OUT/ilu_fetch_summary.txt
 import collections, csv, sys
 agg = collections.defaultdict(list)
