@@ -308,7 +308,7 @@ static void free_matrix(fx_context *c) {
 
 static void free_precond(fx_context *c) {
   dev_free(c->diag.alu);
-  bell_free(c->ssor.L); bell_free(c->ssor.U);
+  bell_free(c->ssor.L); bell_free(c->ssor.U); bell_free(c->ssor.H);
   dev_free(c->ssor.alu); dev_free(c->ssor.dblk); dev_free(c->ssor.slot_node); dev_free(c->ssor.zs); dev_free(c->ssor.zb);
   dev_free(c->ssor.lu_D); dev_free(c->ssor.lu_AL); dev_free(c->ssor.lu_AU);
   c->ssor = SsorDev();
@@ -449,6 +449,7 @@ static int bell_build_device(fx_context *c, Bell &b, int variant, int32_t nslots
     case BV_SSOR_L: hipLaunchKernelGGL((K<BV_SSOR_L>), __VA_ARGS__); break;     \
     case BV_SSOR_U: hipLaunchKernelGGL((K<BV_SSOR_U>), __VA_ARGS__); break;     \
     case BV_ILU_L: hipLaunchKernelGGL((K<BV_ILU_L>), __VA_ARGS__); break;       \
+    case BV_HALO: hipLaunchKernelGGL((K<BV_HALO>), __VA_ARGS__); break;         \
     default: hipLaunchKernelGGL((K<BV_ILU_U>), __VA_ARGS__); break;             \
   }
   BELL_VAR(k_bell_count, g1, b1, 0, c->stream, nslots, d_slot_row, A.N, A.indexL, A.itemL, A.indexU, A.itemU, d_newpos, width, totals)
@@ -619,8 +620,8 @@ static int tune_placement(fx_context *c, Bell &B, const char *what, double strea
   std::vector<float> t;
   cand.push_back(B.val2_base);
   t.push_back(0.f);
-  if (time_ms(&t[0])) return FX_ERROR_RUNTIME;
-  for (int k = 1; k < tries; k++) {
+  int err = time_ms(&t[0]);
+  for (int k = 1; k < tries && !err; k++) {
     if (stream_bytes / (1e-3 * *std::min_element(t.begin(), t.end())) / 1e9 >= good_gbs) break;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + (bytes >> 1) + ((size_t)4 << 30)) break;  // keep headroom
@@ -628,10 +629,16 @@ static int tune_placement(fx_context *c, Bell &B, const char *what, double strea
     if (hipMalloc((void **)&base, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
     B.val2_base = base;
     B.val2 = (double *)base;
-    if (fill()) return FX_ERROR_RUNTIME;
     cand.push_back(base);
-    t.push_back(0.f);
-    if (time_ms(&t.back())) return FX_ERROR_RUNTIME;
+    t.push_back(1e30f);
+    err = fill();
+    if (!err) err = time_ms(&t.back());
+  }
+  if (err) {  // keep the first allocation (it is filled), release everything tried after it
+    for (size_t k = 1; k < cand.size(); k++) (void)hipFree(cand[k]);
+    B.val2_base = cand[0];
+    B.val2 = (double *)cand[0];
+    return FX_ERROR_RUNTIME;
   }
   const int best = (int)(std::min_element(t.begin(), t.end()) - t.begin());
   if (getenv("FX_TIMING") && atoi(getenv("FX_TIMING"))) {
@@ -1273,6 +1280,14 @@ static int ssor_setup_numeric(fx_context *c, double sigma_diag) {
   if (c->eisenstat) {  // Eisenstat form: the diagonal blocks themselves, next to their factors
     if (!S.dblk && dev_alloc(&S.dblk, (size_t)(nslots / 64) * 576)) return FX_ERROR_RUNTIME;
     hipLaunchKernelGGL(k_dblk_setup, dim3((nslots + 255) / 256), dim3(256), 0, c->stream, nslots, c->A.N, S.slot_node, c->A.D, S.dblk);
+    if (c->halo.n_neighbor > 0 && c->ord.kind == 1) {  // subdomain: the halo-column blocks, in the same slot order, columns = Krylov vector slots
+      if (S.H.nslices == 0) {
+        const int e = bell_build_device(c, S.H, BV_HALO, nslots, S.slot_node, c->ord.d_slot_of, nullptr);
+        if (e < 0) return FX_ERROR_RUNTIME;
+        if (e > 0) bell_free(S.H);  // rows longer than the device buffer: no halo layout, the standard loop serves this system
+      }
+      if (S.H.nslices > 0 && bell_fill_values(c, S.H)) return FX_ERROR_RUNTIME;
+    }
   }
   HIP_TRY(hipGetLastError());
   return 0;
@@ -1687,6 +1702,14 @@ static int eis_cg_iteration(fx_context *c, int it) {
   hipLaunchKernelGGL(k_cg_update_p, dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, n3, c->st, DT, PH);
   // p = (D~+U)^-1 ph
   if (eis_sweep_backward(c, PH, P, gate_status(c))) return FX_ERROR_RUNTIME;
+  const double *HP = nullptr;
+  if (halo_active(c)) {  // subdomain: halo part of p from its owners, then hp = H p (W[8])
+    if (halo_update(c, P)) return FX_ERROR_RUNTIME;
+    ClockScope cs(c, 0);
+    hipLaunchKernelGGL(k_eis_halo, dim3((S.H.nslices + 3) / 4), dim3(256), 0, c->stream, S.H.nslices, S.H.pair_ptr, S.H.val2, S.H.col2, P,
+                       c->W[8], gate_status(c));
+    HP = c->W[8];
+  }
   // one pass over L: v, w = (D~+L)^-1 A p, q = A p, partial of p.q = ph.w (:204-211)
   {
     ClockScope cs(c, 0);
@@ -1699,13 +1722,13 @@ static int eis_cg_iteration(fx_context *c, int it) {
       if (s1 - s0 <= c->split_max_slices) {
         g = s1 - s0;
         hipLaunchKernelGGL((k_eis_forward_split<4>), dim3(g), dim3(256), 0, c->stream, s0, s1, S.L.pair_ptr, S.L.val2, S.L.col2, S.alu,
-                           S.dblk, sm1, PH, P, V, WH, Q, c->partials, off, gate_status(c));
+                           S.dblk, sm1, PH, P, V, WH, Q, c->partials, off, gate_status(c), HP);
       } else if (c->ssor_bs == 64)
         hipLaunchKernelGGL((k_eis_forward<64>), dim3(g), dim3(64), 0, c->stream, s0, s1, S.L.pair_ptr, S.L.val2, S.L.col2, S.alu, S.dblk,
-                           sm1, PH, P, V, WH, Q, c->partials, off, gate_status(c));
+                           sm1, PH, P, V, WH, Q, c->partials, off, gate_status(c), HP);
       else
         hipLaunchKernelGGL((k_eis_forward<256>), dim3(g), dim3(256), 0, c->stream, s0, s1, S.L.pair_ptr, S.L.val2, S.L.col2, S.alu, S.dblk,
-                           sm1, PH, P, V, WH, Q, c->partials, off, gate_status(c));
+                           sm1, PH, P, V, WH, Q, c->partials, off, gate_status(c), HP);
       off += g;
     }
     HIP_TRY(hipGetLastError());
@@ -1762,11 +1785,11 @@ static int krylov_begin(fx_context *c, int method, int maxit, double tol) {
   if (dot_into_partials(c, B, B, nullptr, 0, &np)) return FX_ERROR_RUNTIME;
   if (scalar_stage<OP_BNRM2>(c, np, 0, 50)) return FX_ERROR_RUNTIME;
   HIP_TRY(hipGetLastError());
-  // Eisenstat's form: CG + multicolour SSOR(1) on one rank in the colour-major numbering, when asked for
+  // Eisenstat's form: CG + multicolour SSOR(1) in the colour-major numbering, when asked for (subdomains: with the halo term H p)
   // ... and only while M was built from the very values A holds: a recycled preconditioner (hecmw_mat_recycle_precond_setting keeps
   // the old one for up to three changed matrices) is a different splitting, and the identity A = (D~+L) + (D~+U) + (D - 2D~) is gone
   c->eis_active = c->eisenstat && method == 1 && c->precond_kind == 1 && c->ord.kind == 1 && c->iterpremax == 1 && c->ssor.dblk &&
-                  c->ssor.values_epoch == c->values_epoch && !halo_active(c) && !multi_rank(c);
+                  c->ssor.values_epoch == c->values_epoch && (!halo_active(c) || c->ssor.H.nslices > 0);
   if (c->eis_active) { c->k_graph = false; if (eis_begin(c)) return FX_ERROR_RUNTIME; }
   return 0;
 }

@@ -87,6 +87,7 @@ struct SsorDev {
   int32_t ncolor = 0;
   std::vector<int32_t> color_slice;  // slice range per colour: [color_slice[c], color_slice[c+1])
   Bell L, U;                         // strictly-lower / strictly-upper parts in colour-slot order
+  Bell H;                            // Eisenstat form on a subdomain: the halo-column blocks (what the localized L / U drop)
   double *alu = nullptr;             // LU of the diagonal blocks, [slice][e][lane] layout
   double *dblk = nullptr;            // Eisenstat form: the diagonal blocks themselves (unfactored, unscaled), same layout
   double sigma_diag = 1.0;           // SIGMA_DIAG the factors in alu were built with
@@ -249,7 +250,8 @@ struct fx_context {
   // one backward and one forward triangular sweep per iteration deliver p, q = A p and w = (D~+L)^-1 q -- the matrix is
   // streamed ONCE instead of twice (SpMV + the two half sweeps).  Same x_k, r_k, rho_k, alpha_k in exact arithmetic; the
   // summation order of q and of the dot products differs, so histories agree to rounding, not bit for bit: hence opt-in.
-  // Single rank, multicolour SSOR with iterPREmax = 1, colour-major numbering; anything else runs the standard loop.
+  // Multicolour SSOR with iterPREmax = 1, colour-major numbering, preconditioner built from the resident values (subdomains: plus
+  // the halo term H p); anything else runs the standard loop.
   bool eisenstat = false, eis_active = false;
   int64_t values_epoch = 0;  // counts the refreshes of the SpMV layout's values
   // Placement search of the SpMV's value array.  The identical kernel on identical data runs at 1.03-1.19 ms (10.1M DOF)

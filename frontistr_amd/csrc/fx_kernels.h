@@ -555,25 +555,30 @@ __device__ __forceinline__ void bell_row_sweep_dual(int h0, int h1, const double
 __device__ __forceinline__ double eis_forward_finish(int slice, int lane, const double (&sv)[3], const double (&sp)[3],
                                                      const double *__restrict__ alu, const double *__restrict__ dblk, double sm1,
                                                      const double *__restrict__ ph, const double *__restrict__ p,
-                                                     double *__restrict__ v, double *__restrict__ w, double *__restrict__ q) {
+                                                     double *__restrict__ v, double *__restrict__ w, double *__restrict__ q,
+                                                     const double *__restrict__ hp) {
   const int slot = slice * 64 + lane;
   double u[9], D[9];
   const size_t base = (size_t)slice * 576 + lane;
 #pragma unroll
   for (int e = 0; e < 9; e++) { u[e] = alu[base + (size_t)e * 64]; D[e] = dblk[base + (size_t)e * 64]; }
   const double p0 = p[(size_t)3 * slot], p1 = p[(size_t)3 * slot + 1], p2 = p[(size_t)3 * slot + 2];
-  const double h0v = ph[(size_t)3 * slot], h1v = ph[(size_t)3 * slot + 1], h2v = ph[(size_t)3 * slot + 2];
+  double h0v = ph[(size_t)3 * slot], h1v = ph[(size_t)3 * slot + 1], h2v = ph[(size_t)3 * slot + 2];
+  const double pd = h0v, pe = h1v, pf = h2v;  // ph itself (the dot product p.q = ph.w uses it without the halo term)
+  if (hp) {  // subdomain: A = (D~+L) + (D~+U) + (D - 2D~) + H with H the halo columns; H p enters g and q alike
+    h0v += hp[(size_t)3 * slot]; h1v += hp[(size_t)3 * slot + 1]; h2v += hp[(size_t)3 * slot + 2];
+  }
   const double Dp0 = D[0] * p0 + D[1] * p1 + D[2] * p2, Dp1 = D[3] * p0 + D[4] * p1 + D[5] * p2, Dp2 = D[6] * p0 + D[7] * p1 + D[8] * p2;
   const double e0 = sm1 * D[0] * p0, e1 = sm1 * D[4] * p1, e2 = sm1 * D[8] * p2;  // (D~ - D) p: SIGMA_DIAG scales the three scalar diagonal entries only
-  // g = ph + (D - 2 D~) p = ph - D p - 2 (D~ - D) p ;  v = D~^-1 (g - L v)
+  // g = ph + H p + (D - 2 D~) p = ph + H p - D p - 2 (D~ - D) p ;  v = D~^-1 (g - L v)
   double x1 = h0v - Dp0 - 2.0 * e0 - sv[0], x2 = h1v - Dp1 - 2.0 * e1 - sv[1], x3 = h2v - Dp2 - 2.0 * e2 - sv[2];
   lusolve33_dev(u, x1, x2, x3);
   v[(size_t)3 * slot] = x1; v[(size_t)3 * slot + 1] = x2; v[(size_t)3 * slot + 2] = x3;
   const double w0 = p0 + x1, w1 = p1 + x2, w2 = p2 + x3;
   w[(size_t)3 * slot] = w0; w[(size_t)3 * slot + 1] = w1; w[(size_t)3 * slot + 2] = w2;
-  // q = A p = ph + L p + (D - D~) p
+  // q = A p = ph + H p + L p + (D - D~) p
   q[(size_t)3 * slot] = h0v + sp[0] - e0; q[(size_t)3 * slot + 1] = h1v + sp[1] - e1; q[(size_t)3 * slot + 2] = h2v + sp[2] - e2;
-  return h0v * w0 + h1v * w1 + h2v * w2;
+  return pd * w0 + pe * w1 + pf * w2;
 }
 
 template <int BS>
@@ -582,7 +587,8 @@ __global__ __launch_bounds__(BS) void k_eis_forward(int32_t slice0, int32_t slic
                                                     const double *__restrict__ alu, const double *__restrict__ dblk, double sm1,
                                                     const double *__restrict__ ph, const double *__restrict__ p,
                                                     double *__restrict__ v, double *__restrict__ w, double *__restrict__ q,
-                                                    double *__restrict__ partials, int32_t part0, const int32_t *__restrict__ gate) {
+                                                    double *__restrict__ partials, int32_t part0, const int32_t *__restrict__ gate,
+                                                    const double *__restrict__ hp) {
   if (gate && *gate != 0) return;
   const int vb = xcd_block(blockIdx.x, gridDim.x);
   const int slice = slice0 + vb * (BS / 64) + (threadIdx.x >> 6);
@@ -591,7 +597,7 @@ __global__ __launch_bounds__(BS) void k_eis_forward(int32_t slice0, int32_t slic
   if (slice < slice1) {
     double sv[3] = {0.0, 0.0, 0.0}, sp[3] = {0.0, 0.0, 0.0};
     bell_row_sweep_dual(pair_ptr[slice], pair_ptr[slice + 1], val2, col2, lane, v, p, sv, sp);
-    d[0] = eis_forward_finish(slice, lane, sv, sp, alu, dblk, sm1, ph, p, v, w, q);
+    d[0] = eis_forward_finish(slice, lane, sv, sp, alu, dblk, sm1, ph, p, v, w, q, hp);
   }
   block_sum_store<1, BS>(d, partials, 0, part0 + vb);
 }
@@ -604,7 +610,7 @@ __global__ __launch_bounds__(64 * WPS) void k_eis_forward_split(int32_t slice0, 
                                                                 double sm1, const double *__restrict__ ph, const double *__restrict__ p,
                                                                 double *__restrict__ v, double *__restrict__ w, double *__restrict__ q,
                                                                 double *__restrict__ partials, int32_t part0,
-                                                                const int32_t *__restrict__ gate) {
+                                                                const int32_t *__restrict__ gate, const double *__restrict__ hp) {
   if (gate && *gate != 0) return;
   __shared__ double part[WPS][6][64];
   const int slice = slice0 + blockIdx.x;
@@ -650,10 +656,23 @@ __global__ __launch_bounds__(64 * WPS) void k_eis_forward_split(int32_t slice0, 
     for (int j = 1; j < WPS; j++)
 #pragma unroll
       for (int k = 0; k < 3; k++) { sv[k] += part[j][k][lane]; sp[k] += part[j][3 + k][lane]; }
-    d = eis_forward_finish(slice, lane, sv, sp, alu, dblk, sm1, ph, p, v, w, q);
+    d = eis_forward_finish(slice, lane, sv, sp, alu, dblk, sm1, ph, p, v, w, q, hp);
     d = wave_sum(d);
     if (lane == 0) partials[part0 + blockIdx.x] = d;
   }
+}
+
+// hp = H p: the halo-column blocks of every row against the freshly exchanged halo part of p (rows without halo blocks get 0)
+__global__ __launch_bounds__(256) void k_eis_halo(int32_t nslices, const int32_t *__restrict__ pair_ptr, const double *__restrict__ val2,
+                                                  const int *__restrict__ col2, const double *__restrict__ p, double *__restrict__ hp,
+                                                  const int32_t *__restrict__ gate) {
+  if (gate && *gate != 0) return;
+  const int slice = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (slice >= nslices) return;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  bell_row_sweep<false>(pair_ptr[slice], pair_ptr[slice + 1], val2, col2, lane, p, s0, s1, s2);
+  const size_t o = (size_t)3 * (slice * 64 + lane);
+  hp[o] = s0; hp[o + 1] = s1; hp[o + 2] = s2;
 }
 
 // dt = D~ t and the partial of rho = t.dt; MODE 1 also x += alpha p, r -= alpha q (+ partial ||r||^2), t -= alpha w first;
@@ -1456,10 +1475,11 @@ __global__ void k_bfs_mark(int32_t n, const int32_t *__restrict__ nodes, uint8_t
 //   SSOR_L  blocks whose column comes EARLIER in the colour ordering, ascending new index   (SSOR_33.f90:312)
 //   SSOR_U  blocks whose column comes LATER, descending new index                          (SSOR_33.f90:369); halo columns dropped
 //   ILU_L   lower items ascending (BILU_33.f90:104-111);  ILU_U  upper items descending, halo columns dropped (:133)
+//   HALO    the halo-column blocks alone (what the localized preconditioner drops), ascending: Eisenstat's form on a subdomain
 // Pass 1 (k_bell_count) gives every slice its width (the longest row) and the block total; an exclusive scan turns widths into
 // pair_ptr; pass 2 (k_bell_map) writes column slots and source codes (3 * index + {0 D, 1 AL, 2 AU}, -1 padding) into the layout.
 // ------------------------------------------------------------------------
-enum BellVariant { BV_FULL = 0, BV_SSOR_L, BV_SSOR_U, BV_ILU_L, BV_ILU_U };
+enum BellVariant { BV_FULL = 0, BV_SSOR_L, BV_SSOR_U, BV_ILU_L, BV_ILU_U, BV_HALO };
 #define FX_BELL_MAXROW 160
 
 template <int VAR>
@@ -1480,6 +1500,14 @@ __device__ __forceinline__ int bell_row_entries(int32_t r, int32_t self_slot, in
   if (VAR == BV_ILU_L) {
     for (int32_t j = iL[r]; j < iL[r + 1]; j++, k++)
       if (src && k < FX_BELL_MAXROW) { src[k] = 3 * j + 1; col[k] = slot_of[jL[j] - 1]; }
+    return k;
+  }
+  if (VAR == BV_HALO) {  // the blocks the localized preconditioner drops: columns owned by other ranks (upper items > N), ascending
+    for (int32_t j = iU[r]; j < iU[r + 1]; j++) {
+      if (jU[j] <= N) continue;
+      if (src && k < FX_BELL_MAXROW) { src[k] = 3 * j + 2; col[k] = slot_of[jU[j] - 1]; }
+      k++;
+    }
     return k;
   }
   if (VAR == BV_ILU_U) {

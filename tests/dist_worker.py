@@ -44,7 +44,7 @@ def main():
         dims = {2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}[world]
         sub = cube_subdomain(int(m), dims, rank)
     E, NU = 210000.0, 0.3
-    wg = (0, 0)
+    wg = (0, 0, 0)
     if mode == "oracle":
         from oracle import pyoracle as po
         from oracle.refrun import default_params
@@ -96,7 +96,7 @@ def main():
         ctx.download_x(mat)
         X, it, hist = mat.X, ctx.info.iterations, ctx.history
         st = ctx.stats()
-        wg = (st["wg_interior"], st["wg_boundary"])
+        wg = (st["wg_interior"], st["wg_boundary"], st["eisenstat"])
         ctx.close()
     np.savez(out, X=X, it=it, hist=hist, code=code, gid=sub.global_id, nn_internal=sub.nn_internal, wg=np.array(wg))
     dist.barrier()

@@ -357,3 +357,22 @@ def test_eight_subdomains_of_the_reference_partitioner(oracle, meth, pc):
         xs = ser["X"].reshape(-1, 3)
         for r in res:
             assert np.abs(r["X"].reshape(-1, 3) - xs[r["gid"]]).max() < 2e-7 * np.abs(xs).max()
+
+
+@pytest.mark.parametrize("world,m", [(2, 8), (4, 6), (2, 16)])
+def test_eisenstat_form_on_subdomains(tmp_path, monkeypatch, world, m):
+    """FX_EISENSTAT=1 on a decomposed system: A = (D~+L) + (D~+U) + (D - 2D~) + H with H the halo columns the localized SSOR
+    drops; p's halo part is exchanged after the backward sweep and H p enters g and q.  Same iteration count (+-1), history
+    (first ten lines 1e-9) and field as the standard loop on every rank, and the form really ran."""
+    monkeypatch.setenv("FX_EISENSTAT", "0")
+    (tmp_path / "std").mkdir()
+    std = run_world("hip", world, m, 1, 1, tmp_path / "std")
+    monkeypatch.setenv("FX_EISENSTAT", "1")
+    (tmp_path / "eis").mkdir()
+    eis = run_world("hip", world, m, 1, 1, tmp_path / "eis")
+    for a, b in zip(std, eis):
+        assert int(a["code"]) == int(b["code"]) == 0 and int(a["wg"][2]) == 0 and int(b["wg"][2]) == 1
+        assert abs(int(a["it"]) - int(b["it"])) <= 1
+        k = min(10, len(a["hist"]), len(b["hist"]))
+        assert np.all(np.abs(a["hist"][:k] - b["hist"][:k]) <= 1e-9 * a["hist"][:k])
+        assert np.abs(a["X"] - b["X"]).max() < 1e-8 * np.abs(a["X"]).max()
