@@ -261,6 +261,7 @@ extern "C" int fx_create(int device, fx_context **out) {
   if (const char *e = getenv("FX_SSOR_MODE")) c->ssor_mode = atoi(e);
   if (const char *e = getenv("FX_PIPE_MAX_SLICES")) c->pipe_max_slices = atoi(e);
   if (const char *e = getenv("FX_SSOR_BS")) c->ssor_bs = (atoi(e) == 64) ? 64 : 256;
+  if (const char *e = getenv("FX_SSOR_SPW")) c->ssor_spw = std::max(1, std::min(8, atoi(e)));
   if (const char *e = getenv("FX_SPMV_BS")) c->spmv_bs = (atoi(e) == 64) ? 64 : 256;
   if (const char *e = getenv("FX_SPMV_SPATIAL")) c->spmv_spatial = atoi(e) != 0;
   if (const char *e = getenv("FX_GRAPH")) c->graph_mode = atoi(e);
@@ -313,6 +314,7 @@ static void free_precond(fx_context *c) {
   dev_free(c->ssor.lu_D); dev_free(c->ssor.lu_AL); dev_free(c->ssor.lu_AU);
   c->ssor = SsorDev();
   c->precond_valid = false;
+  c->precond_valid_sweeps = false;
   c->precond_kind = 0;
 }
 
@@ -712,6 +714,8 @@ static int ensure_work(fx_context *c) {
       if (dev_alloc(&w, (size_t)len)) return FX_ERROR_RUNTIME;
       HIP_TRY(hipMemsetAsync(w, 0, (size_t)len * 8, c->stream));
     }
+    for (int k = 0; k < 10; k++) c->W0[k] = c->W[k];  // allocation order (placement experiments)
+    c->w_tuned = false;
     if (dev_alloc(&c->Bs, (size_t)len) || dev_alloc(&c->Xs, (size_t)len)) return FX_ERROR_RUNTIME;
     HIP_TRY(hipMemsetAsync(c->Bs, 0, (size_t)len * 8, c->stream));
     HIP_TRY(hipMemsetAsync(c->Xs, 0, (size_t)len * 8, c->stream));
@@ -1399,6 +1403,67 @@ static int ilu_setup_numeric(fx_context *c, double sigma_diag) {
   return 0;
 }
 
+// Which physical buffer plays which work vector.  In the first context of a process the first two or three work vectors
+// can sit in a slow spot: the same CG + SSOR iteration ran at 2.92 ms with r, z/q, p on buffers 0, 1, 2 and at 2.66 ms on
+// 3, 4, 5 (or 5, 6, 7, or 7, 8, 9), while later contexts of that process showed no spread at all
+// (scripts/experiments/ab_wperm.py) -- the run-to-run spread of the bench line.  The ten buffers are interchangeable, so
+// each is timed as the sweep vector of the preconditioner, as the output and as the gathered input of the SpMV, and the
+// fastest take the roles the loops hammer: z/q, p, r of CG; p~, s~, v, t of BiCGSTAB.  Large systems, once per allocation.
+static int tune_work_vectors(fx_context *c) {
+  if (c->w_tuned || c->tune_tries <= 1 || c->M.nslices < c->tune_min_slices || !c->have_values || !c->bell_valid) return 0;
+  c->w_tuned = true;
+  const int nwg = spmv_nparts(c);
+  KrylovState st0;
+  memset(&st0, 0, sizeof st0);
+  HIP_TRY(hipMemcpyAsync(c->st, &st0, sizeof st0, hipMemcpyHostToDevice, c->stream));  // status 0: the gated sweeps run
+  for (int k = 0; k < 10; k++) HIP_TRY(hipMemcpyAsync(c->W[k], c->Bs, (size_t)c->wlen * 8, hipMemcpyDeviceToDevice, c->stream));
+  auto timed = [&](auto &&launch, float *ms) -> int {
+    if (launch()) return FX_ERROR_RUNTIME;  // untimed
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    for (int i = 0; i < 2; i++)
+      if (launch()) return FX_ERROR_RUNTIME;
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return 0;
+  };
+  const bool sweeps = (c->precond_kind == 1 && c->precond_valid_sweeps);
+  std::vector<std::pair<float, int>> score;
+  float stream_ms[10];
+  for (int k = 0; k < 10; k++) {
+    double *b = c->W[k], *other = c->W[(k + 5) % 10];
+    float t = 0.f, acc = 0.f;
+    int np;
+    if (timed([&]() { return spmv_launch(c, 0, 1, other, nullptr, b, nullptr, 0, nullptr, nwg); }, &t)) return FX_ERROR_RUNTIME;  // written
+    acc += t;
+    if (timed([&]() { return spmv_launch(c, 0, 1, b, nullptr, other, nullptr, 0, nullptr, nwg); }, &t)) return FX_ERROR_RUNTIME;  // gathered
+    acc += t;
+    if (sweeps) {
+      if (timed([&]() { return precond_apply_once(c, other, b, false, &np); }, &t)) return FX_ERROR_RUNTIME;  // swept
+      acc += t;
+    }
+    if (timed([&]() {  // streamed: what the vector updates of the loop do to it (read + write, contiguous)
+          hipLaunchKernelGGL(k_axpy_plain, dim3(grid_for((int64_t)c->wlen)), dim3(256), 0, c->stream, (int64_t)c->wlen, 0.0, other, b);
+          return 0;
+        }, &t)) return FX_ERROR_RUNTIME;
+    acc += 4.f * t;  // an iteration streams each hot vector 3-5 times
+    stream_ms[k] = t;
+    score.push_back({acc, k});
+  }
+  std::stable_sort(score.begin(), score.end());
+  const int priority[10] = {1, 2, 0, 3, 6, 5, 4, 7, 8, 9};  // z/q, p, r (CG); p~ (BiCGSTAB), v, t, s, ...
+  double *old[10];
+  for (int k = 0; k < 10; k++) old[k] = c->W[k];
+  for (int q = 0; q < 10; q++) c->W[priority[q]] = old[score[q].second];
+  for (int k = 0; k < 10; k++) HIP_TRY(hipMemsetAsync(c->W[k], 0, (size_t)c->wlen * 8, c->stream));
+  if (getenv("FX_TIMING") && atoi(getenv("FX_TIMING"))) {
+    fprintf(stderr, "[fx timing] work vectors (written + gathered%s + 4 x streamed, 2 launches each, ms; [streamed alone]):", sweeps ? " + swept" : "");
+    for (auto &sc : score) fprintf(stderr, " %d:%.3f[%.3f]", sc.second, sc.first, stream_ms[sc.second]);
+    fprintf(stderr, "\n");
+  }
+  return 0;
+}
+
 extern "C" int fx_precond_setup(fx_context *c, const int32_t *Iarray, const double *Rarray) {
   HIP_TRY(hipSetDevice(c->device));
   if (!c->have_values) { g_fx_error = "fx_precond_setup: no matrix values resident"; return FX_ERROR_RUNTIME; }
@@ -1440,7 +1505,9 @@ extern "C" int fx_precond_setup(fx_context *c, const int32_t *Iarray, const doub
     if (ensure_solver(c)) return FX_ERROR_RUNTIME;
     if (ssor_setup_numeric(c, sigma_diag)) return FX_ERROR_RUNTIME;
     if (tune_sweep_placement(c, nullptr, nullptr, nullptr)) return FX_ERROR_RUNTIME;
+    c->precond_valid_sweeps = true;
   }
+  if (tune_work_vectors(c)) return FX_ERROR_RUNTIME;
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->precond_valid = true;
   return 0;
@@ -1463,7 +1530,7 @@ static int precond_apply_once(fx_context *c, const double *r, double *z, bool wa
       int64_t tot = 0;
       for (int col = 0; col < S.ncolor; col++) {
         const int nsl = S.color_slice[col + 1] - S.color_slice[col];
-        tot += (nsl <= c->split_max_slices) ? nsl : nsl / (c->ssor_bs / 64) + 1;
+        tot += (nsl <= c->split_max_slices) ? nsl : nsl / ((c->ssor_bs / 64) * c->ssor_spw) + 1;
       }
       if (tot > c->max_partials) want_dot = false;
     }
@@ -1503,15 +1570,15 @@ static int precond_apply_once(fx_context *c, const double *r, double *z, bool wa
     // Workgroup size per colour: 64-thread groups (one slice each) spread a colour evenly over the 256 CUs
     // (a 150^3 colour has 5276 slices = 5.2 four-slice groups per CU: a 6-vs-5 imbalance); FX_SSOR_BS overrides.
     const int bs = c->ssor_bs;
-    const int spb = bs / 64;
+    const int spb = (bs / 64) * c->ssor_spw;  // slices per workgroup
 #define SSOR_LAUNCH(FWD, B, g, s0, s1, part)                                                                          \
   do {                                                                                                                \
     if (c->pipe_ssor && (s1 - s0) <= c->pipe_max_slices)                                                              \
       hipLaunchKernelGGL((k_ssor_color<FWD, true, B>), dim3(g), dim3(B), 0, c->stream, s0, s1, BL.pair_ptr, BL.val2,  \
-                         BL.col2, sn, S.alu, r, zsweep, znat, part, gate_status(c));                                  \
+                         BL.col2, sn, S.alu, r, zsweep, znat, part, gate_status(c), c->ssor_spw);                     \
     else                                                                                                              \
       hipLaunchKernelGGL((k_ssor_color<FWD, false, B>), dim3(g), dim3(B), 0, c->stream, s0, s1, BL.pair_ptr, BL.val2, \
-                         BL.col2, sn, S.alu, r, zsweep, znat, part, gate_status(c));                                  \
+                         BL.col2, sn, S.alu, r, zsweep, znat, part, gate_status(c), c->ssor_spw);                     \
   } while (0)
 #define SPLIT_LAUNCH(FWD, s0, s1, part)                                                                                  \
   do {                                                                                                                  \
@@ -1644,10 +1711,10 @@ static int eis_sweep_backward(fx_context *c, const double *rhs, double *out, con
                          (const int32_t *)nullptr, S.alu, rhs, out, (double *)nullptr, (double *)nullptr, gate);
     else if (c->ssor_bs == 64)
       hipLaunchKernelGGL((k_ssor_color<true, true, 64>), dim3((s1 - s0 + spb - 1) / spb), dim3(64), 0, c->stream, s0, s1, S.U.pair_ptr,
-                         S.U.val2, S.U.col2, (const int32_t *)nullptr, S.alu, rhs, out, (double *)nullptr, (double *)nullptr, gate);
+                         S.U.val2, S.U.col2, (const int32_t *)nullptr, S.alu, rhs, out, (double *)nullptr, (double *)nullptr, gate, 1);
     else
       hipLaunchKernelGGL((k_ssor_color<true, true, 256>), dim3((s1 - s0 + spb - 1) / spb), dim3(256), 0, c->stream, s0, s1, S.U.pair_ptr,
-                         S.U.val2, S.U.col2, (const int32_t *)nullptr, S.alu, rhs, out, (double *)nullptr, (double *)nullptr, gate);
+                         S.U.val2, S.U.col2, (const int32_t *)nullptr, S.alu, rhs, out, (double *)nullptr, (double *)nullptr, gate, 1);
   }
   HIP_TRY(hipGetLastError());
   return 0;
@@ -1664,10 +1731,10 @@ static int eis_sweep_forward_solve(fx_context *c, const double *rhs, double *out
                          (const int32_t *)nullptr, S.alu, rhs, out, (double *)nullptr, (double *)nullptr, gate);
     else if (c->ssor_bs == 64)
       hipLaunchKernelGGL((k_ssor_color<true, true, 64>), dim3((s1 - s0 + spb - 1) / spb), dim3(64), 0, c->stream, s0, s1, S.L.pair_ptr,
-                         S.L.val2, S.L.col2, (const int32_t *)nullptr, S.alu, rhs, out, (double *)nullptr, (double *)nullptr, gate);
+                         S.L.val2, S.L.col2, (const int32_t *)nullptr, S.alu, rhs, out, (double *)nullptr, (double *)nullptr, gate, 1);
     else
       hipLaunchKernelGGL((k_ssor_color<true, true, 256>), dim3((s1 - s0 + spb - 1) / spb), dim3(256), 0, c->stream, s0, s1, S.L.pair_ptr,
-                         S.L.val2, S.L.col2, (const int32_t *)nullptr, S.alu, rhs, out, (double *)nullptr, (double *)nullptr, gate);
+                         S.L.val2, S.L.col2, (const int32_t *)nullptr, S.alu, rhs, out, (double *)nullptr, (double *)nullptr, gate, 1);
   }
   HIP_TRY(hipGetLastError());
   return 0;
@@ -1764,6 +1831,17 @@ static int krylov_begin(fx_context *c, int method, int maxit, double tol) {
   double *X = c->Xs, *B = c->Bs, *R = c->W[0];
   int np;
   if (ensure_solver(c)) return FX_ERROR_RUNTIME;
+  if (const char *e = getenv("FX_W_PERM")) {  // placement experiments: which physical buffers play W[0], W[1], W[2] (read at every begin)
+    int a = -1, b = -1, d = -1;
+    if (sscanf(e, "%d,%d,%d", &a, &b, &d) == 3 && a >= 0 && b >= 0 && d >= 0 && a < 10 && b < 10 && d < 10 && a != b && b != d && a != d) {
+      const int want[3] = {a, b, d};
+      for (int r = 0; r < 3; r++) {
+        int where = -1;
+        for (int k = 0; k < 10; k++) if (c->W[k] == c->W0[want[r]]) where = k;
+        if (where >= 0) std::swap(c->W[r], c->W[where]);
+      }
+    }
+  }
   if (to_slots(c, c->A.B, c->Bs) || to_slots(c, c->A.X, c->Xs)) return FX_ERROR_RUNTIME;
   c->k_method = method; c->k_maxit = maxit; c->k_it = 1;
   graphs_destroy(c);  // buffers / grids may have changed since the last solve: re-capture

@@ -214,6 +214,7 @@ struct fx_context {
   // Same-process A/B at 10.1M DOF with the tuned kernels: mode 0 336 it/s (SpMV 1.11 ms, SSOR 1.61 ms),
   // mode 1 351 it/s (SpMV 1.15 ms, SSOR 1.46 ms).
   int ssor_mode = 1;
+  int ssor_spw = 1;            // consecutive slices per wave in the big-colour sweeps (FX_SSOR_SPW)
   int ssor_bs = 64;            // workgroup size of the colour sweeps: 64 (default) or 256. Measured 10M DOF: 1.78 -> 1.61 ms per apply
   int pipe_max_slices = 1 << 30;  // colours with more slices use the plain row loop (with 64-thread groups: pipelined everywhere wins, 1.61 vs 1.64/1.69 ms)
   int spmv_bs = 256;              // workgroup size of the SpMV (FX_SPMV_BS)
@@ -265,6 +266,9 @@ struct fx_context {
   int32_t tune_min_slices = 8192;
   // work vectors (3*NP each)
   double *W[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  double *W0[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // the work vectors in allocation order
+  bool w_tuned = false;               // the roles of the work vectors went through tune_work_vectors
+  bool precond_valid_sweeps = false;  // multicolour SSOR layouts filled (tune_work_vectors may time a sweep)
   int iterpremax = 1;  // additive-Schwarz sweeps of hecmw_precond_33_apply
   int32_t wlen = 0;
   double *scale_vec = nullptr;  // SCALING=YES: 1/sqrt|diag|, reference numbering, 3*NP (+ slack)

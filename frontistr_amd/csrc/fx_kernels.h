@@ -323,13 +323,14 @@ __global__ __launch_bounds__(BS) void k_ssor_color(int32_t slice0, int32_t slice
                                                          const double *__restrict__ alu,
                                                          const double *__restrict__ r, double *__restrict__ zs,
                                                          double *__restrict__ z, double *__restrict__ partials,
-                                                         const int32_t *__restrict__ gate) {
+                                                         const int32_t *__restrict__ gate, int32_t spw) {
   if (gate && *gate != 0) return;
+  // spw consecutive slices per wave (1 by default; FX_SSOR_SPW): a wave that walks several slices pays its start-up once
   const int vb = xcd_block(blockIdx.x, gridDim.x);
-  const int slice = slice0 + vb * (BS / 64) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   double d[1] = {0.0};
-  if (slice < slice1) {
+  const int first = slice0 + (vb * (BS / 64) + (threadIdx.x >> 6)) * spw;
+  for (int slice = first; slice < first + spw && slice < slice1; slice++) {
     const int slot = slice * 64 + lane;
     const int node = slot_node ? slot_node[slot] : slot;  // null: r and z already live in slot numbering
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(BS) void k_ssor_color(int32_t slice0, int32_t slice
           double *zn = z + (size_t)3 * node;
           zn[0] = x1; zn[1] = x2; zn[2] = x3;
         }
-        if (partials) d[0] = ri[0] * x1 + ri[1] * x2 + ri[2] * x3;
+        if (partials) d[0] += ri[0] * x1 + ri[1] * x2 + ri[2] * x3;
       }
     }
   }
