@@ -10,7 +10,8 @@
 //
 // Layout: the same sliced block-ELL idea as the 3x3 path -- one thread per block row, 64 rows per slice, slice width =
 // longest row of the slice -- with the NDOF*NDOF entries of a block stored entry-major across the 64 lanes
-// (val[((slice_base + k) * NDOF^2 + e) * 64 + lane]), so every load of the inner loop is one coalesced 512-byte line.
+// (val[((slice_base + k) * NDOF^2 + e) * 64 + lane]), so every load of the inner loop is one coalesced 512-byte line
+// (NDOF = 1 packs entry pairs into 16-byte words instead, see nn1_pos).
 // Vectors stay in the caller's numbering (NDOF * NP doubles); the SSOR sweeps address rows through a slot -> row map in
 // colour order.  The Krylov scalars of this path are host-driven (one small D2H per dot product): it is the functional
 // first version of the row, measured in DESIGN.md §7, not yet the tuned one.  No CPU arithmetic on vectors or matrices.
@@ -134,6 +135,15 @@ __global__ void k_nn_diag_apply(int32_t N, const double *__restrict__ alu, doubl
   for (int d = 0; d < ND; d++) z[(size_t)ND * i + d] = X[d];
 }
 
+// Scalar systems (NDOF = 1) store the entries of a slice PAIR-PACKED -- entries k, k+1 of lane l in one 16-byte word, their
+// two column ids in one 8-byte word, an odd last entry alone -- exactly as the 3x3 path packs its blocks: an 8-byte load per
+// lane runs at 0.54-0.70x the rate of a 16-byte one on MI355X (MI355X_MICROARCH.md), and at one value per entry the value
+// stream of the entry-major layout was nothing but 8-byte loads.  Wider blocks keep the entry-major layout.
+__host__ __device__ __forceinline__ size_t nn1_pos(int64_t base, int w, int k, int lane) {  // position of entry k of `lane` (values and column ids alike)
+  const int wp = w & ~1;
+  return k < wp ? (size_t)(base + (k & ~1)) * 64 + (size_t)lane * 2 + (k & 1) : (size_t)(base + k) * 64 + lane;
+}
+
 // One thread per block row of a slice.  MODE 0: y = A x; 1: y = b - A x; 2: forward SSOR sweep  z_i <- LU^-1 (z_i - sum L z);
 // 3: backward sweep  z_i <- z_i - LU^-1 (sum U z).  Slices [s0, s1) of one launch are mutually independent.
 template <int ND, int MODE>
@@ -152,6 +162,30 @@ __global__ __launch_bounds__(256) void k_nn_rows(int32_t s0, int32_t s1, const i
   double acc[ND];
 #pragma unroll
   for (int d = 0; d < ND; d++) acc[d] = 0.0;
+  if (ND == 1) {  // pair-packed scalar entries: one 16-byte value word + one 8-byte id word per two entries, streamed past the caches
+    const int np = w >> 1;
+    const fx_d2 *v2 = (const fx_d2 *)(val + (size_t)base * 64) + lane;
+    const fx_i2 *c2 = (const fx_i2 *)(col + (size_t)base * 64) + lane;
+    double a0 = 0.0;
+    int j = 0;
+    for (; j + 1 < np; j += 2) {  // two pairs in flight
+      const fx_i2 ca = __builtin_nontemporal_load(c2 + (size_t)j * 64), cb = __builtin_nontemporal_load(c2 + (size_t)(j + 1) * 64);
+      const fx_d2 va = __builtin_nontemporal_load(v2 + (size_t)j * 64), vb = __builtin_nontemporal_load(v2 + (size_t)(j + 1) * 64);
+      const double xa = x[ca.x], xb = x[ca.y], xc = x[cb.x], xd = x[cb.y];
+      a0 = a0 + va.x * xa; a0 = a0 + va.y * xb;
+      a0 = a0 + vb.x * xc; a0 = a0 + vb.y * xd;
+    }
+    if (j < np) {
+      const fx_i2 ca = __builtin_nontemporal_load(c2 + (size_t)j * 64);
+      const fx_d2 va = __builtin_nontemporal_load(v2 + (size_t)j * 64);
+      a0 = a0 + va.x * x[ca.x]; a0 = a0 + va.y * x[ca.y];
+    }
+    if (w & 1) {
+      const size_t o = (size_t)(base + w - 1) * 64 + lane;
+      a0 = a0 + val[o] * x[col[o]];
+    }
+    acc[0] = a0;
+  } else
   for (int k = 0; k < w; k++) {
     const int32_t cidx = col[(base + k) * 64 + lane];
     const double *v = val + (size_t)(base + k) * (ND * ND) * 64 + lane;
@@ -266,6 +300,12 @@ __global__ void k_nn_scale_bell(int32_t nslices, const int64_t *__restrict__ sli
   const int64_t base = slice_ptr[s];
   const int w = (int)(slice_ptr[s + 1] - base);
   for (int k = 0; k < w; k++) {
+    if (ND == 1) {  // pair-packed layout
+      const size_t o = nn1_pos(base, w, k, lane);
+      const double si = scale[row], sj = scale[col[o]];
+      val[o] = back ? val[o] / (si * sj) : (val[o] * si) * sj;
+      continue;
+    }
     const int32_t cidx = col[(base + k) * 64 + lane];
     double *v = val + (size_t)(base + k) * (ND * ND) * 64 + lane;
 #pragma unroll
@@ -331,7 +371,14 @@ static int nn_bell_build(fx_context *c, NnBell &b, int nd, const std::vector<int
       for (int l = 0; l < 64; l++) {
         tmp.clear();
         if (rows[(size_t)s * 64 + l] >= 0) fill((int64_t)s * 64 + l, tmp);
+        const int w = (int)(sp[s + 1] - sp[s]);
         for (size_t k = 0; k < tmp.size(); k++) {
+          if (nd == 1) {  // pair-packed scalar entries (nn1_pos)
+            const size_t o = nn1_pos(sp[s], w, (int)k, l);
+            col[o] = tmp[k].col;
+            val[o] = tmp[k].src[0];
+            continue;
+          }
           col[(size_t)(sp[s] + k) * 64 + l] = tmp[k].col;
           for (int q = 0; q < nd2; q++) val[((size_t)(sp[s] + k) * nd2 + q) * 64 + l] = tmp[k].src[q];
         }
