@@ -11,10 +11,10 @@
 // Layout: the same sliced block-ELL idea as the 3x3 path -- one thread per block row, 64 rows per slice, slice width =
 // longest row of the slice -- with the NDOF*NDOF entries of a block stored entry-major across the 64 lanes
 // (val[((slice_base + k) * NDOF^2 + e) * 64 + lane]), so every load of the inner loop is one coalesced 512-byte line
-// (NDOF = 1 packs entry pairs into 16-byte words instead, see nn1_pos).
+// Inside that line-per-value frame the values are paired into 16-byte words per lane (nn_pos; NDOF = 1 pairs entries: nn1_pos).
 // Vectors stay in the caller's numbering (NDOF * NP doubles); the SSOR sweeps address rows through a slot -> row map in
-// colour order.  The Krylov scalars of this path are host-driven (one small D2H per dot product): it is the functional
-// first version of the row, measured in DESIGN.md §7, not yet the tuned one.  No CPU arithmetic on vectors or matrices.
+// colour order.  CG and BiCGSTAB keep their scalars on the device (the k_scalar<OP> state machine of the 3x3 path); GMRES and
+// GPBiCG are host-driven (fx_krylov2_host.h).  Measured in DESIGN.md §7.  No CPU arithmetic on vectors or matrices.
 #pragma once
 
 struct NnBell {
@@ -143,6 +143,11 @@ __host__ __device__ __forceinline__ size_t nn1_pos(int64_t base, int w, int k, i
   const int wp = w & ~1;
   return k < wp ? (size_t)(base + (k & ~1)) * 64 + (size_t)lane * 2 + (k & 1) : (size_t)(base + k) * 64 + lane;
 }
+// Wider blocks pair the values INSIDE an entry: values q, q+1 of lane l share a 16-byte word, an odd last value (NDOF = 5) alone.
+__host__ __device__ __forceinline__ size_t nn_pos(int nd2, int64_t entry, int q, int lane) {
+  const int qp = nd2 & ~1;
+  return q < qp ? ((size_t)entry * nd2 + (q & ~1)) * 64 + (size_t)lane * 2 + (q & 1) : ((size_t)entry * nd2 + q) * 64 + lane;
+}
 
 // One thread per block row of a slice.  MODE 0: y = A x; 1: y = b - A x; 2: forward SSOR sweep  z_i <- LU^-1 (z_i - sum L z);
 // 3: backward sweep  z_i <- z_i - LU^-1 (sum U z).  Slices [s0, s1) of one launch are mutually independent.
@@ -188,14 +193,21 @@ __global__ __launch_bounds__(256) void k_nn_rows(int32_t s0, int32_t s1, const i
   } else
   for (int k = 0; k < w; k++) {
     const int32_t cidx = col[(base + k) * 64 + lane];
-    const double *v = val + (size_t)(base + k) * (ND * ND) * 64 + lane;
-    double xv[ND];
+    const double *v = val + (size_t)(base + k) * (ND * ND) * 64;
+    double a[ND * ND], xv[ND];
+#pragma unroll
+    for (int j = 0; j < (ND * ND) / 2; j++) {  // value pairs as 16-byte words, streamed past the caches
+      const fx_d2 wd = __builtin_nontemporal_load((const fx_d2 *)(v + (size_t)2 * j * 64) + lane);
+      a[2 * j] = wd.x;
+      a[2 * j + 1] = wd.y;
+    }
+    if ((ND * ND) & 1) a[ND * ND - 1] = __builtin_nontemporal_load(v + (size_t)(ND * ND - 1) * 64 + lane);
 #pragma unroll
     for (int e = 0; e < ND; e++) xv[e] = x[(size_t)ND * cidx + e];
 #pragma unroll
     for (int d = 0; d < ND; d++)
 #pragma unroll
-      for (int e = 0; e < ND; e++) acc[d] = acc[d] + v[(size_t)(d * ND + e) * 64] * xv[e];
+      for (int e = 0; e < ND; e++) acc[d] = acc[d] + a[d * ND + e] * xv[e];
   }
   if (row < 0) return;
   if (MODE == 0) {
@@ -307,13 +319,12 @@ __global__ void k_nn_scale_bell(int32_t nslices, const int64_t *__restrict__ sli
       continue;
     }
     const int32_t cidx = col[(base + k) * 64 + lane];
-    double *v = val + (size_t)(base + k) * (ND * ND) * 64 + lane;
 #pragma unroll
     for (int d = 0; d < ND; d++)
 #pragma unroll
       for (int e = 0; e < ND; e++) {
         const double si = scale[(size_t)ND * row + d], sj = scale[(size_t)ND * cidx + e];
-        double &x = v[(size_t)(d * ND + e) * 64];
+        double &x = val[nn_pos(ND * ND, base + k, d * ND + e, lane)];
         x = back ? x / (si * sj) : (x * si) * sj;
       }
   }
@@ -380,7 +391,7 @@ static int nn_bell_build(fx_context *c, NnBell &b, int nd, const std::vector<int
             continue;
           }
           col[(size_t)(sp[s] + k) * 64 + l] = tmp[k].col;
-          for (int q = 0; q < nd2; q++) val[((size_t)(sp[s] + k) * nd2 + q) * 64 + l] = tmp[k].src[q];
+          for (int q = 0; q < nd2; q++) val[nn_pos(nd2, sp[s] + (int64_t)k, q, l)] = tmp[k].src[q];
         }
       }
   });
