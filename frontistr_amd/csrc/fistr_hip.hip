@@ -25,6 +25,7 @@ Graph build_graph(int32_t N, const int32_t *indexL, const int32_t *itemL, const 
                   const int32_t *itemU);
 std::vector<int32_t> rcm_sequence(const Graph &g);
 std::vector<int32_t> rcm_starts(const Graph &g);
+std::vector<int32_t> rcm_starts_deg(int32_t n, const int32_t *deg);
 int32_t level_order_host(const Graph &g, int32_t start, std::vector<int32_t> &seq);
 void multicolor(const Graph &g, const std::vector<int32_t> &seq, int ncolor_in, std::vector<int32_t> &perm,
                 std::vector<int32_t> &colorindex);
@@ -255,6 +256,8 @@ extern "C" int fx_create(int device, fx_context **out) {
   }
   if (const char *e = getenv("FX_TUNE_PLACEMENT")) c->tune_tries = std::max(0, atoi(e));
   if (const char *e = getenv("FX_BFS_DEVICE_MIN")) c->bfs_device_min = atoi(e);
+  if (const char *e = getenv("FX_MC_DEVICE_MIN")) c->mc_device_min = atoi(e);
+  if (const char *e = getenv("FX_MC_BATCH")) c->mc_batch = std::max(1, atoi(e));
   if (const char *e = getenv("FX_LAYOUT_DEVICE")) c->layout_device = atoi(e) != 0;
   if (const char *e = getenv("FX_PIPE_SPMV")) c->pipe_spmv = atoi(e) != 0;
   if (const char *e = getenv("FX_PIPE_SSOR")) c->pipe_ssor = atoi(e) != 0;
@@ -628,13 +631,16 @@ static int tune_placement(fx_context *c, Bell &B, const char *what, double strea
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + (bytes >> 1) + ((size_t)4 << 30)) break;  // keep headroom
     char *base = nullptr;
+    const double w0 = now_s();
     if (hipMalloc((void **)&base, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+    const double w1 = now_s();
     B.val2_base = base;
     B.val2 = (double *)base;
     cand.push_back(base);
     t.push_back(1e30f);
     err = fill();
     if (!err) err = time_ms(&t.back());
+    if (getenv("FX_PLACEMENT_DEBUG")) fprintf(stderr, "[fx placement] try %d: hipMalloc %.1f ms, fill + time %.1f ms\n", k, 1e3 * (w1 - w0), 1e3 * (now_s() - w1));
   }
   if (err) {  // keep the first allocation (it is filled), release everything tried after it
     for (size_t k = 1; k < cand.size(); k++) (void)hipFree(cand[k]);
@@ -648,8 +654,10 @@ static int tune_placement(fx_context *c, Bell &B, const char *what, double strea
     for (size_t k = 0; k < t.size(); k++) fprintf(stderr, " %.3f ms%s", t[k], (int)k == best ? "*" : "");
     fprintf(stderr, "\n");
   }
+  const double wf = now_s();
   for (size_t k = 0; k < cand.size(); k++)
     if ((int)k != best) (void)hipFree(cand[k]);
+  if (getenv("FX_PLACEMENT_DEBUG")) fprintf(stderr, "[fx placement] %zu x hipFree %.1f ms\n", cand.size() - 1, 1e3 * (now_s() - wf));
   B.val2_base = cand[best];  // every candidate was filled from the same values
   B.val2 = (double *)cand[best];
   return 0;
@@ -1057,9 +1065,11 @@ static int diag_setup(fx_context *c, double sigma_diag) {
 // reverse_ordering, hecmw_matrix_ordering_CM.f90:16-55, :169-178) with the breadth-first levels on the DEVICE (kernels
 // k_bfs_*: 150 levels x 5 starts at 150^3 nodes, ~3 k small launches instead of five 0.3 s host walks).  Any start whose
 // graph is disconnected (the reference then jumps to the lowest unvisited node) falls back to the host walk for that start.
-static int rcm_sequence_device(fx_context *c, const fxo::Graph &g, std::vector<int32_t> &seq_out) {
+template <class GetGraph>
+static int rcm_sequence_device(fx_context *c, const std::vector<int32_t> &starts, GetGraph graph, std::vector<int32_t> &seq_out,
+                               int32_t *max_width) {
   const int32_t N = c->A.N;
-  const std::vector<int32_t> starts = fxo::rcm_starts(g);
+  *max_width = 1;
   DevScratch tmp;
   uint8_t *seen = nullptr;
   uint32_t *claim = nullptr;
@@ -1092,6 +1102,7 @@ static int rcm_sequence_device(fx_context *c, const fxo::Graph &g, std::vector<i
       HIP_TRY(hipStreamSynchronize(c->stream));
       const int32_t nnew = *h_total;
       if (nnew <= 0 || hi + nnew > N) { ok = false; break; }  // disconnected graph (or nonsense): the host walk handles it
+      *max_width = std::max(*max_width, nnew);
       hipLaunchKernelGGL(k_bfs_mark, dim3((nnew + 255) / 256), blk, 0, c->stream, nnew, seq + hi, seen);
       lo = hi;
       hi += nnew;
@@ -1099,7 +1110,7 @@ static int rcm_sequence_device(fx_context *c, const fxo::Graph &g, std::vector<i
     }
     HIP_TRY(hipGetLastError());
     if (!ok) {
-      nlevel = fxo::level_order_host(g, start, cur);
+      nlevel = fxo::level_order_host(graph(), start, cur);
       if (nlevel > best_levels) { best_levels = nlevel; seq_out = cur; }
       continue;
     }
@@ -1113,6 +1124,68 @@ static int rcm_sequence_device(fx_context *c, const fxo::Graph &g, std::vector<i
   return 0;
 }
 
+// hecmw_matrix_ordering_MC (hecmw_matrix_ordering_MC.f90:15-72) on the device: kernels k_mc_* (fx_kernels.h).  Every
+// `mc_batch` rounds the host looks at the length of the next IN queue; an empty one ends the colour.  perm: new -> old
+// (0-based), colour by colour.  Returns 1 (nothing changed, the caller takes the host walk) when a colour needs more
+// rounds than the queue-length table holds: a graph whose decisions form one long chain.
+static int multicolor_device(fx_context *c, const std::vector<int32_t> &seq_h, int ncolor_in, std::vector<int32_t> &perm,
+                             std::vector<int32_t> &colorindex) {
+  const int32_t N = c->A.N, cap = N / ncolor_in;
+  const DevCSR &A = c->A;
+  DevScratch tmp;
+  const int32_t nb16 = (int32_t)(((int64_t)N + 4095) / 4096);
+  const int max_rounds = 1 << 16;
+  int32_t *seq = nullptr, *info = nullptr, *cnt = nullptr, *inq = nullptr, *outq = nullptr, *n_in = nullptr, *n_out = nullptr,
+          *tot = nullptr, *bsum = nullptr, *boff = nullptr, *d_perm = nullptr;
+  if (tmp.alloc(&seq, (size_t)N) || tmp.alloc(&info, (size_t)N) || tmp.alloc(&cnt, (size_t)N) || tmp.alloc(&inq, (size_t)N) ||
+      tmp.alloc(&outq, (size_t)N) || tmp.alloc(&n_in, (size_t)max_rounds + 1) || tmp.alloc(&n_out, (size_t)max_rounds) ||
+      tmp.alloc(&tot, 4) || tmp.alloc(&bsum, (size_t)nb16) || tmp.alloc(&boff, (size_t)nb16 + 1) || tmp.alloc(&d_perm, (size_t)N))
+    return FX_ERROR_RUNTIME;
+  int32_t *h = (int32_t *)(c->st_host + 3) + 4;  // pinned
+  HIP_TRY(hipMemcpyAsync(seq, seq_h.data(), (size_t)N * 4, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_mc_pos, dim3((N + 255) / 256), dim3(256), 0, c->stream, N, seq, info);
+  const int batch = std::max(1, c->mc_batch);
+  const dim3 qgrid(std::max(1, std::min(16 * c->n_cu, (N + 7) / 8))), blk(256);
+  colorindex.assign(1, 0);
+  int32_t done = 0;
+  int64_t rounds_total = 0;
+  const double t_begin = now_s();
+  while (done < N) {
+    HIP_TRY(hipMemsetAsync(n_in, 0, ((size_t)max_rounds + 1) * 4, c->stream));
+    HIP_TRY(hipMemsetAsync(n_out, 0, (size_t)max_rounds * 4, c->stream));
+    hipLaunchKernelGGL(k_mc_init, dim3((N + 7) / 8), blk, 0, c->stream, N, A.indexL, A.itemL, A.indexU, A.itemU, info, cnt, inq, n_in);
+    int r = 0;
+    for (;;) {
+      if (r + batch > max_rounds) return 1;
+      for (int i = 0; i < batch; i++, r++) {
+        hipLaunchKernelGGL(k_mc_in, qgrid, blk, 0, c->stream, N, A.indexL, A.itemL, A.indexU, A.itemU, info, inq, n_in + r, outq, n_out + r);
+        hipLaunchKernelGGL(k_mc_out, qgrid, blk, 0, c->stream, N, A.indexL, A.itemL, A.indexU, A.itemU, info, cnt, outq, n_out + r, inq,
+                           n_in + r + 1);
+      }
+      HIP_TRY(hipMemcpyAsync(h, n_in + r, 4, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      if (h[0] == 0) break;  // no new pick: no new block either, every node of the pool is decided
+    }
+    hipLaunchKernelGGL(k_mc_blockcount, dim3(nb16), blk, 0, c->stream, N, seq, info, bsum);
+    hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, c->stream, nb16, bsum, boff, tot);
+    hipLaunchKernelGGL(k_mc_assign, dim3(nb16), blk, 0, c->stream, N, cap > 0 ? cap : N, done, seq, boff, info, d_perm);
+    HIP_TRY(hipMemcpyAsync(h, tot, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int32_t picked = cap > 0 ? std::min(h[0], cap) : h[0];
+    if (picked <= 0) { g_fx_error = "multicolouring on the device picked nothing"; return FX_ERROR_RUNTIME; }
+    done += picked;
+    colorindex.push_back(done);
+    rounds_total += r;
+  }
+  HIP_TRY(hipGetLastError());
+  if (getenv("FX_TIMING") && atoi(getenv("FX_TIMING")))
+    fprintf(stderr, "[fx timing] multicolour on the device: %zu colours, %lld rounds, %.3f s\n", colorindex.size() - 1,
+            (long long)rounds_total, now_s() - t_begin);
+  perm.resize((size_t)N);
+  HIP_TRY(hipMemcpy(perm.data(), d_perm, (size_t)N * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 // hecmw_precond_SSOR_33_setup (hecmw_precond_SSOR_33.f90:55-223), always on the
 // multicolour path (the reference's nthreads > 1 branch :102-111): ordering on the
 // host, values gathered on the device.  Within a colour the slots are sorted by the
@@ -1123,14 +1196,35 @@ static int ssor_setup_symbolic(fx_context *c, int ncolor_in) {
   SsorDev &S = c->ssor;
   const int32_t *iL = c->h_indexL.data(), *jL = c->h_itemL.data(), *iU = c->h_indexU.data(), *jU = c->h_itemU.data();
   PhaseTimer pt("ssor symbolic");
-  fxo::Graph g = fxo::build_graph(N, iL, jL, iU, jU);
-  pt.lap("graph");
+  // node degrees inside the subdomain (halo columns -- ids > N, last in the ascending itemU -- are not part of the graph)
+  std::vector<int32_t> deg((size_t)N);
+  parallel_for(N, [&](int64_t a, int64_t b) {
+    for (int64_t r = a; r < b; r++) {
+      int32_t e = iU[r + 1];
+      while (e > iU[r] && jU[e - 1] > N) e--;
+      deg[r] = (iL[r + 1] - iL[r]) + (e - iU[r]);
+    }
+  });
+  fxo::Graph g_store;  // the host adjacency is only built when a host walk needs it (small systems, disconnected graphs)
+  bool g_built = false;
+  auto graph = [&]() -> const fxo::Graph & {
+    if (!g_built) { g_store = fxo::build_graph(N, iL, jL, iU, jU); g_built = true; }
+    return g_store;
+  };
+  pt.lap("degrees");
   std::vector<int32_t> seq;
-  if (N >= c->bfs_device_min) { if (rcm_sequence_device(c, g, seq)) return FX_ERROR_RUNTIME; }
-  else seq = fxo::rcm_sequence(g);
+  int32_t max_width = 0;
+  if (N >= c->bfs_device_min) {
+    if (rcm_sequence_device(c, fxo::rcm_starts_deg(N, deg.data()), graph, seq, &max_width)) return FX_ERROR_RUNTIME;
+  } else seq = fxo::rcm_sequence(graph());
   pt.lap("level ordering");
   std::vector<int32_t> perm0, cidx;
-  fxo::multicolor(g, seq, ncolor_in, perm0, cidx);
+  int mc = 1;
+  if (N >= c->mc_device_min && ncolor_in > 0 && N / ncolor_in > 0) {
+    mc = multicolor_device(c, seq, ncolor_in, perm0, cidx);
+    if (mc < 0) return FX_ERROR_RUNTIME;
+  }
+  if (mc > 0) fxo::multicolor(graph(), seq, ncolor_in, perm0, cidx);
   pt.lap("multicolour");
   S.ncolor = (int32_t)cidx.size() - 1;
   S.colorindex = cidx;
@@ -1142,7 +1236,8 @@ static int ssor_setup_symbolic(fx_context *c, int ncolor_in) {
   parallel_for(N, [&](int64_t a, int64_t b) {
     for (int64_t r = a; r < b; r++) {
       int32_t k = 0;
-      for (int64_t e = g.ptr[r]; e < g.ptr[r + 1]; e++) k += (newpos[g.adj[e]] < newpos[r]);
+      for (int32_t e = iL[r]; e < iL[r + 1]; e++) k += (newpos[jL[e] - 1] < newpos[r]);
+      for (int32_t e = iU[r]; e < iU[r + 1] && jU[e] <= N; e++) k += (newpos[jU[e] - 1] < newpos[r]);
       nlow[r] = k;
     }
   });
@@ -1220,7 +1315,7 @@ static int ssor_setup_symbolic(fx_context *c, int ncolor_in) {
   auto countL = [&](int32_t slot) { const int32_t r = slot_row[slot]; return r < 0 ? 0 : nlow[r]; };
   auto countU = [&](int32_t slot) {
     const int32_t r = slot_row[slot];
-    return r < 0 ? 0 : (int32_t)(g.ptr[r + 1] - g.ptr[r]) - nlow[r];
+    return r < 0 ? 0 : deg[r] - nlow[r];
   };
   auto fillL = [&](int32_t slot, std::vector<BellEntry> &e) { collect(slot, e, true); };
   auto fillU = [&](int32_t slot, std::vector<BellEntry> &e) { collect(slot, e, false); };
@@ -1498,16 +1593,26 @@ extern "C" int fx_precond_setup(fx_context *c, const int32_t *Iarray, const doub
     if (ensure_solver(c)) return FX_ERROR_RUNTIME;
     if (ilu_setup_numeric(c, sigma_diag)) return FX_ERROR_RUNTIME;
   } else {
+    PhaseTimer pt("precond setup");
     if (symbolic) {
       c->ssor_ncolor_in = ncolor_in;
       if (ssor_setup_symbolic(c, ncolor_in)) return FX_ERROR_RUNTIME;
     }
+    pt.lap("symbolic");
     if (ensure_solver(c)) return FX_ERROR_RUNTIME;
+    pt.lap("solver layout values + SpMV placement");
     if (ssor_setup_numeric(c, sigma_diag)) return FX_ERROR_RUNTIME;
+    if (pt.on) HIP_TRY(hipStreamSynchronize(c->stream));
+    pt.lap("numeric");
     if (tune_sweep_placement(c, nullptr, nullptr, nullptr)) return FX_ERROR_RUNTIME;
+    pt.lap("sweep placement");
     c->precond_valid_sweeps = true;
   }
-  if (tune_work_vectors(c)) return FX_ERROR_RUNTIME;
+  {
+    PhaseTimer pt("precond setup");
+    if (tune_work_vectors(c)) return FX_ERROR_RUNTIME;
+    pt.lap("work vectors");
+  }
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->precond_valid = true;
   return 0;

@@ -1469,6 +1469,170 @@ __global__ void k_bfs_mark(int32_t n, const int32_t *__restrict__ nodes, uint8_t
 }
 
 // ------------------------------------------------------------------------
+// Greedy capped multicolouring on the device (hecmw_matrix_ordering_MC, hecmw_matrix_ordering_MC.f90:15-72).  The reference
+// walks the level sequence once per colour: a node joins the colour unless a neighbour EARLIER in the walk joined it, and
+// the colour closes after N / ncolor_in picks.  A colour is therefore the lexicographically first independent set of the
+// nodes still uncoloured, cut off at the cap, and the fate of a node depends on earlier positions only:
+//   OUT as soon as one earlier neighbour is IN;  IN as soon as all earlier (uncoloured) neighbours are OUT.
+// Event-driven, one edge visit per decision instead of one scan per round: cnt[v] = earlier uncoloured neighbours not yet
+// OUT.  Nodes with cnt = 0 start as IN; a round lets the new IN nodes mark their later undecided neighbours OUT
+// (k_mc_in, compare-and-swap so that each is queued once), then the new OUT nodes decrement their later neighbours'
+// counters and whatever reaches zero is IN for the next round (k_mc_out).  A node with an earlier IN neighbour never
+// reaches zero (that neighbour does not decrement), so the two transitions cannot collide.  ~260 rounds per colour at
+// 150^3 nodes.  The cap is applied afterwards (k_mc_assign): the picks are ranked in walk order, the first `cap` keep the
+// colour, everything else returns to the pool -- the sequential walk never visited those.  Same colours and the same order
+// inside a colour as the reference's walk (tests: device against host ordering).
+//   info[node] = position in the walk << 2 | state;  queues hold node ids;  n_in[r] / n_out[r]: queue lengths of round r.
+// ------------------------------------------------------------------------
+enum { MC_UNDECIDED = 0, MC_IN = 1, MC_OUT = 2, MC_DONE = 3 };
+__global__ void k_mc_pos(int32_t n, const int32_t *__restrict__ seq, int32_t *__restrict__ info) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) info[seq[i]] = i << 2;
+}
+// Queue append aggregated per wave: ONE atomic on the queue length per wave instruction instead of one per node (3.4 M
+// appends to one address per colour otherwise).  Must be reached by the lanes of a wave together.
+__device__ __forceinline__ void mc_push(bool pred, int32_t value, int32_t *__restrict__ q, int32_t *__restrict__ counter) {
+  const uint64_t m = __ballot(pred);
+  if (!m) return;
+  const int lane = __lane_id(), leader = __ffsll((unsigned long long)m) - 1;
+  int32_t base = 0;
+  if (lane == leader) base = atomicAdd(counter, __popcll(m));
+  base = __shfl(base, leader);
+  if (pred) q[base + __popcll(m & ((1ull << lane) - 1))] = value;
+}
+// k-th neighbour of v: lower items, then upper items; -1 for a halo column (not part of the graph) or k past the row
+__device__ __forceinline__ int32_t mc_neighbour(int32_t k, int32_t l0, int32_t nl, int32_t u0, int32_t nu, int32_t N,
+                                                const int32_t *__restrict__ itemL, const int32_t *__restrict__ itemU) {
+  if (k < nl) return itemL[l0 + k] - 1;
+  if (k < nl + nu) {
+    const int32_t w = itemU[u0 + k - nl] - 1;
+    return w < N ? w : -1;
+  }
+  return -1;
+}
+// The three event kernels give every node HALF A WAVE (32 lanes, one neighbour each per step): the gathers and atomics of a
+// node are one instruction in flight instead of a chain of dependent round trips -- a round is latency-, not work-bound.
+__global__ __launch_bounds__(256) void k_mc_init(int32_t N, const int32_t *__restrict__ indexL, const int32_t *__restrict__ itemL,
+                                                 const int32_t *__restrict__ indexU, const int32_t *__restrict__ itemU, int32_t *info,
+                                                 int32_t *__restrict__ cnt, int32_t *__restrict__ inq, int32_t *__restrict__ n_in) {
+  const int sub = threadIdx.x & 31, half = (threadIdx.x >> 5) & 1;
+  const int32_t v = blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int32_t iv = v < N ? info[v] : MC_DONE;
+  const bool pool = (iv & 3) != MC_DONE;
+  int32_t l0 = 0, nl = 0, u0 = 0, nu = 0;
+  if (pool) { l0 = indexL[v]; nl = indexL[v + 1] - l0; u0 = indexU[v]; nu = indexU[v + 1] - u0; }
+  int32_t k = 0;
+  for (int32_t kb = 0; __any(kb < nl + nu); kb += 32) {
+    const int32_t w = mc_neighbour(kb + sub, l0, nl, u0, nu, N, itemL, itemU);
+    bool earlier = false;
+    if (w >= 0) {
+      const int32_t iw = info[w];
+      earlier = (iw >> 2) < (iv >> 2) && (iw & 3) != MC_DONE;
+    }
+    k += __popc((uint32_t)(__ballot(earlier) >> (32 * half)));
+  }
+  const bool first = pool && sub == 0;
+  if (first) {
+    cnt[v] = k;
+    if (k == 0) info[v] = iv | MC_IN;
+  }
+  mc_push(first && k == 0, v, inq, n_in);
+}
+__global__ __launch_bounds__(256) void k_mc_in(int32_t N, const int32_t *__restrict__ indexL, const int32_t *__restrict__ itemL,
+                                               const int32_t *__restrict__ indexU, const int32_t *__restrict__ itemU, int32_t *info,
+                                               const int32_t *__restrict__ inq, const int32_t *__restrict__ n_in,
+                                               int32_t *__restrict__ outq, int32_t *__restrict__ n_out) {
+  const int32_t n = *n_in;
+  const int sub = threadIdx.x & 31;
+  for (int32_t i0 = blockIdx.x * 8; i0 < n; i0 += gridDim.x * 8) {  // wave-uniform trip counts (mc_push)
+    const int32_t i = i0 + (threadIdx.x >> 5);
+    const int32_t v = i < n ? inq[i] : -1;
+    int32_t pv = 0, l0 = 0, nl = 0, u0 = 0, nu = 0;
+    if (v >= 0) { pv = info[v] >> 2; l0 = indexL[v]; nl = indexL[v + 1] - l0; u0 = indexU[v]; nu = indexU[v + 1] - u0; }
+    for (int32_t kb = 0; __any(kb < nl + nu); kb += 32) {
+      const int32_t w = mc_neighbour(kb + sub, l0, nl, u0, nu, N, itemL, itemU);
+      bool won = false;
+      if (w >= 0) {
+        const int32_t iw = info[w];
+        won = (iw >> 2) > pv && (iw & 3) == MC_UNDECIDED && atomicCAS(&info[w], iw, iw | MC_OUT) == iw;
+      }
+      mc_push(won, w, outq, n_out);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_mc_out(int32_t N, const int32_t *__restrict__ indexL, const int32_t *__restrict__ itemL,
+                                                const int32_t *__restrict__ indexU, const int32_t *__restrict__ itemU, int32_t *info,
+                                                int32_t *cnt, const int32_t *__restrict__ outq, const int32_t *__restrict__ n_out,
+                                                int32_t *__restrict__ inq, int32_t *__restrict__ n_in_next) {
+  const int32_t n = *n_out;
+  const int sub = threadIdx.x & 31;
+  for (int32_t i0 = blockIdx.x * 8; i0 < n; i0 += gridDim.x * 8) {
+    const int32_t i = i0 + (threadIdx.x >> 5);
+    const int32_t v = i < n ? outq[i] : -1;
+    int32_t pv = 0, l0 = 0, nl = 0, u0 = 0, nu = 0;
+    if (v >= 0) { pv = info[v] >> 2; l0 = indexL[v]; nl = indexL[v + 1] - l0; u0 = indexU[v]; nu = indexU[v + 1] - u0; }
+    for (int32_t kb = 0; __any(kb < nl + nu); kb += 32) {
+      const int32_t w = mc_neighbour(kb + sub, l0, nl, u0, nu, N, itemL, itemU);
+      bool freed = false;
+      if (w >= 0) {
+        const int32_t iw = info[w];
+        freed = (iw >> 2) > pv && (iw & 3) != MC_DONE && atomicSub(&cnt[w], 1) == 1;
+        if (freed) info[w] = (iw & ~3) | MC_IN;  // its last earlier neighbour went OUT: none of them is IN, so nobody marks w OUT
+      }
+      mc_push(freed, w, inq, n_in_next);
+    }
+  }
+}
+// picks of 4096 consecutive positions of the walk (16 per thread): bsum[block]
+__global__ __launch_bounds__(256) void k_mc_blockcount(int32_t N, const int32_t *__restrict__ seq, const int32_t *__restrict__ info,
+                                                       int32_t *__restrict__ bsum) {
+  __shared__ int32_t sh;
+  if (threadIdx.x == 0) sh = 0;
+  __syncthreads();
+  const int64_t p0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+  int32_t k = 0;
+  for (int i = 0; i < 16; i++)
+    if (p0 + i < N) k += (info[seq[p0 + i]] & 3) == MC_IN;
+  if (k) atomicAdd(&sh, k);
+  __syncthreads();
+  if (threadIdx.x == 0) bsum[blockIdx.x] = sh;
+}
+// rank the picks in walk order; the first `cap` of them become the colour (perm[coloff + rank] = node), the rest and the
+// blocked nodes go back to the pool
+__global__ __launch_bounds__(256) void k_mc_assign(int32_t N, int32_t cap, int32_t coloff, const int32_t *__restrict__ seq,
+                                                   const int32_t *__restrict__ boff, int32_t *__restrict__ info,
+                                                   int32_t *__restrict__ perm) {
+  __shared__ int32_t sh[256];
+  const int t = threadIdx.x;
+  const int64_t p0 = ((int64_t)blockIdx.x * 256 + t) * 16;
+  int32_t st[16], node[16];
+  int32_t k = 0;
+  for (int i = 0; i < 16; i++) {
+    node[i] = p0 + i < N ? seq[p0 + i] : -1;
+    st[i] = node[i] >= 0 ? info[node[i]] & 3 : MC_DONE;
+    k += st[i] == MC_IN;
+  }
+  sh[t] = k;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    const int32_t v = t >= d ? sh[t - d] : 0;
+    __syncthreads();
+    sh[t] += v;
+    __syncthreads();
+  }
+  int32_t run = boff[blockIdx.x] + sh[t] - k;
+  for (int i = 0; i < 16; i++) {
+    if (st[i] != MC_IN && st[i] != MC_OUT) continue;
+    int32_t ns = MC_UNDECIDED;
+    if (st[i] == MC_IN) {
+      if (run < cap) { perm[coloff + run] = node[i]; ns = MC_DONE; }
+      run++;
+    }
+    info[node[i]] = (int32_t)(p0 + i) << 2 | ns;
+  }
+}
+
+// ------------------------------------------------------------------------
 // BELL source maps built on the DEVICE (set-up): which block goes where is a pure function of the resident CRS profile, the
 // slot order and -- for the SSOR sweeps -- the new numbering, so it needs neither the host threads nor a 720 MB upload.
 // One thread per slot generates its row's entries in the order the sweep consumes them:

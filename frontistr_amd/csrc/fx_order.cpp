@@ -101,19 +101,23 @@ static int32_t level_order(const Graph &g, int32_t start, std::vector<int32_t> &
 // followed by reverse_ordering, which maps node id k -> N-1-k (0-based) instead of
 // reversing the sequence.  Returns the visiting sequence (new -> old, 0-based).
 // the up-to-5 minimum-degree start candidates (find_minimum_degrees, hecmw_matrix_ordering_CM.f90:138-167)
-std::vector<int32_t> rcm_starts(const Graph &g) {
-  const int32_t n = g.n;
+std::vector<int32_t> rcm_starts_deg(int32_t n, const int32_t *deg_of) {
   int64_t degmin = n;
   std::vector<int32_t> starts;
   int32_t nties = 0;
   for (int32_t i = 0; i < n; i++) {
-    const int64_t deg = g.ptr[i + 1] - g.ptr[i];
+    const int64_t deg = deg_of[i];
     if (deg == 0) continue;
     if (deg < degmin) { degmin = deg; starts.assign(1, i); nties = 1; }
     else if (deg == degmin) { if (++nties <= 5) starts.push_back(i); }
   }
   if (starts.empty()) starts.push_back(0);
   return starts;
+}
+std::vector<int32_t> rcm_starts(const Graph &g) {
+  std::vector<int32_t> deg((size_t)g.n);
+  for (int32_t i = 0; i < g.n; i++) deg[i] = (int32_t)(g.ptr[i + 1] - g.ptr[i]);
+  return rcm_starts_deg(g.n, deg.data());
 }
 int32_t level_order_host(const Graph &g, int32_t start, std::vector<int32_t> &seq) { return level_order(g, start, seq); }
 

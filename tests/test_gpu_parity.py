@@ -799,12 +799,18 @@ def test_eisenstat_form_of_cg_ssor(hip, oracle, deck, sigma, monkeypatch):
         assert np.all(np.abs(h[:n] - h0[:n]) <= 0.25 * h0[:n])
 
 
-@pytest.mark.parametrize("n,skew", [(4, 0.0), (12, 0.05), (47, 0.0)])
-def test_device_level_ordering_equals_host_ordering(hip, n, skew, monkeypatch):
+@pytest.mark.parametrize("n,skew,batch", [(4, 0.0, 0), (12, 0.05, 0), (12, 0.05, 1), (20, 0.0, 3), (47, 0.0, 0), (47, 0.0, 7)])
+def test_device_level_ordering_equals_host_ordering(hip, n, skew, batch, monkeypatch):
     """The breadth-first level ordering of the SSOR set-up on the device (k_bfs_*: claim by the smallest parent position, count,
-    scan, write) must give the host walk's sequence node for node, hence the same colours: perm and COLORindex of the resident
-    preconditioner against the host-only fx_ssor_ordering, with the device path forced on small meshes and taken by default on
-    the 110k-node one."""
+    scan, write) must give the host walk's sequence node for node, and the capped greedy multicolouring on the device (k_mc_*:
+    the lexicographically first independent set driven by events -- picks block their later neighbours, blocked nodes release
+    theirs -- with the cap applied by rank afterwards) the host walk's colours: perm and COLORindex of the resident
+    preconditioner against the host-only fx_ssor_ordering, with the device paths forced on small meshes and taken by default on
+    the 110k-node one; several host look-in intervals."""
+    if batch:
+        monkeypatch.setenv("FX_MC_BATCH", str(batch))
+    if n < 47:
+        monkeypatch.setenv("FX_MC_DEVICE_MIN", "0")
     import ctypes as C
     from frontistr_amd.mesh import CubeMesh
     from test_abi import _lib_ordering
