@@ -257,6 +257,7 @@ extern "C" int fx_create(int device, fx_context **out) {
   if (const char *e = getenv("FX_TUNE_PLACEMENT")) c->tune_tries = std::max(0, atoi(e));
   if (const char *e = getenv("FX_BFS_DEVICE_MIN")) c->bfs_device_min = atoi(e);
   if (const char *e = getenv("FX_MC_DEVICE_MIN")) c->mc_device_min = atoi(e);
+  if (const char *e = getenv("FX_BFS_BATCH")) c->bfs_batch = std::max(1, atoi(e));
   if (const char *e = getenv("FX_MC_BATCH")) c->mc_batch = std::max(1, atoi(e));
   if (const char *e = getenv("FX_LAYOUT_DEVICE")) c->layout_device = atoi(e) != 0;
   if (const char *e = getenv("FX_PIPE_SPMV")) c->pipe_spmv = atoi(e) != 0;
@@ -1062,63 +1063,71 @@ static int diag_setup(fx_context *c, double sigma_diag) {
 }
 
 // hecmw_matrix_ordering_CM's "RCM" (level ordering from the best of <= 5 minimum-degree starts + the id mirror of
-// reverse_ordering, hecmw_matrix_ordering_CM.f90:16-55, :169-178) with the breadth-first levels on the DEVICE (kernels
-// k_bfs_*: 150 levels x 5 starts at 150^3 nodes, ~3 k small launches instead of five 0.3 s host walks).  Any start whose
-// graph is disconnected (the reference then jumps to the lowest unvisited node) falls back to the host walk for that start.
+// reverse_ordering, hecmw_matrix_ordering_CM.f90:16-55, :169-178) with the breadth-first levels on the DEVICE: kernels
+// k_bfsb_* walk all candidate starts at once with the level state resident (five launches per level for all starts, the
+// host looks at the state every `bfs_batch` levels; 150 levels at 150^3 nodes).  A start whose graph is disconnected (the
+// reference then jumps to the lowest unvisited node) falls back to the host walk for that start.
 template <class GetGraph>
-static int rcm_sequence_device(fx_context *c, const std::vector<int32_t> &starts, GetGraph graph, std::vector<int32_t> &seq_out,
-                               int32_t *max_width) {
+static int rcm_sequence_device(fx_context *c, const std::vector<int32_t> &starts, GetGraph graph, std::vector<int32_t> &seq_out) {
   const int32_t N = c->A.N;
-  *max_width = 1;
+  const int S = (int)starts.size();
+  const int32_t nvb_max = (N + 255) / 256 + 1;
   DevScratch tmp;
   uint8_t *seen = nullptr;
   uint32_t *claim = nullptr;
-  int32_t *seq = nullptr, *cnt = nullptr, *off = nullptr, *total = nullptr;
-  if (tmp.alloc(&seen, (size_t)N) || tmp.alloc(&claim, (size_t)N) || tmp.alloc(&seq, (size_t)N) || tmp.alloc(&cnt, (size_t)N) ||
-      tmp.alloc(&off, (size_t)N) || tmp.alloc(&total, 4))
+  int32_t *seq = nullptr, *cnt = nullptr, *bsum = nullptr, *boff = nullptr;
+  BfsState *st = nullptr;  // [2][S]
+  if (tmp.alloc(&seen, (size_t)N * S) || tmp.alloc(&claim, (size_t)N * S) || tmp.alloc(&seq, (size_t)N * S) ||
+      tmp.alloc(&cnt, (size_t)N * S) || tmp.alloc(&bsum, (size_t)nvb_max * S) || tmp.alloc(&boff, (size_t)nvb_max * S) ||
+      tmp.alloc(&st, (size_t)2 * S))
     return FX_ERROR_RUNTIME;
-  int32_t *h_total = (int32_t *)(c->st_host + 3) + 4;  // pinned
   const DevCSR &A = c->A;
+  HIP_TRY(hipMemsetAsync(seen, 0, (size_t)N * S, c->stream));
+  HIP_TRY(hipMemsetAsync(claim, 0xFF, (size_t)N * S * 4, c->stream));
+  std::vector<BfsState> h_st((size_t)2 * S);
+  const uint8_t one = 1;
+  for (int s = 0; s < S; s++) {
+    h_st[s] = h_st[S + s] = BfsState{0, 1, 1, 0};
+    HIP_TRY(hipMemcpyAsync(seq + (size_t)s * N, &starts[s], 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(seen + (size_t)s * N + starts[s], &one, 1, hipMemcpyHostToDevice, c->stream));
+  }
+  HIP_TRY(hipMemcpyAsync(st, h_st.data(), h_st.size() * sizeof(BfsState), hipMemcpyHostToDevice, c->stream));
+  const dim3 grid(std::max(1, std::min(2 * c->n_cu, (N + 255) / 256)), S), blk(256);
+  int par = 0;
+  for (int64_t level = 0;; ) {
+    for (int i = 0; i < c->bfs_batch; i++, level++, par ^= 1) {
+      const BfsState *cur = st + (size_t)par * S;
+      BfsState *nxt = st + (size_t)(par ^ 1) * S;
+      hipLaunchKernelGGL(k_bfsb_claim, grid, blk, 0, c->stream, N, cur, A.indexL, A.itemL, A.indexU, A.itemU, seq, seen, claim);
+      hipLaunchKernelGGL(k_bfsb_count, grid, blk, 0, c->stream, N, nvb_max, cur, A.indexL, A.itemL, A.indexU, A.itemU, seq, seen, claim, cnt, bsum);
+      hipLaunchKernelGGL(k_bfsb_scan, dim3(S), dim3(1024), 0, c->stream, N, nvb_max, cur, nxt, bsum, boff);
+      hipLaunchKernelGGL(k_bfsb_write, grid, blk, 0, c->stream, N, nvb_max, cur, A.indexL, A.itemL, A.indexU, A.itemU, seq, seen, claim, cnt, boff);
+      hipLaunchKernelGGL(k_bfsb_mark, grid, blk, 0, c->stream, N, cur, nxt, seq, seen);
+    }
+    HIP_TRY(hipMemcpyAsync(h_st.data(), st + (size_t)par * S, (size_t)S * sizeof(BfsState), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    bool all = true;
+    for (int s = 0; s < S; s++) all = all && (h_st[s].hi >= N || h_st[s].stuck);
+    if (all) break;
+    if (level > (int64_t)N + c->bfs_batch) { g_fx_error = "level ordering on the device made no progress"; return FX_ERROR_RUNTIME; }
+  }
+  HIP_TRY(hipGetLastError());
   int32_t best_levels = -1;
+  int best = -1;  // >= 0: a device sequence; -2: seq_out already holds a host walk
   std::vector<int32_t> cur;
-  for (size_t si = 0; si < starts.size(); si++) {
-    const int32_t start = starts[si];
-    HIP_TRY(hipMemsetAsync(seen, 0, (size_t)N, c->stream));
-    HIP_TRY(hipMemsetAsync(claim, 0xFF, (size_t)N * 4, c->stream));
-    HIP_TRY(hipMemcpyAsync(seq, &start, 4, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_bfs_mark, dim3(1), dim3(64), 0, c->stream, 1, seq, seen);
-    int32_t lo = 0, hi = 1, nlevel = 1;
-    bool ok = true;
-    while (hi < N) {
-      const int32_t nf = hi - lo;
-      const dim3 grid((nf + 255) / 256), blk(256);
-      hipLaunchKernelGGL(k_bfs_claim, grid, blk, 0, c->stream, nf, seq + lo, (uint32_t)lo, N, A.indexL, A.itemL, A.indexU, A.itemU, seen, claim);
-      hipLaunchKernelGGL((k_bfs_children<false>), grid, blk, 0, c->stream, nf, seq + lo, (uint32_t)lo, N, A.indexL, A.itemL, A.indexU,
-                         A.itemU, seen, claim, cnt, (const int32_t *)nullptr, (int32_t *)nullptr);
-      hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, c->stream, nf, cnt, off, total);
-      hipLaunchKernelGGL((k_bfs_children<true>), grid, blk, 0, c->stream, nf, seq + lo, (uint32_t)lo, N, A.indexL, A.itemL, A.indexU,
-                         A.itemU, seen, claim, cnt, off, seq + hi);
-      HIP_TRY(hipMemcpyAsync(h_total, total, 4, hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(hipStreamSynchronize(c->stream));
-      const int32_t nnew = *h_total;
-      if (nnew <= 0 || hi + nnew > N) { ok = false; break; }  // disconnected graph (or nonsense): the host walk handles it
-      *max_width = std::max(*max_width, nnew);
-      hipLaunchKernelGGL(k_bfs_mark, dim3((nnew + 255) / 256), blk, 0, c->stream, nnew, seq + hi, seen);
-      lo = hi;
-      hi += nnew;
-      nlevel++;
-    }
-    HIP_TRY(hipGetLastError());
-    if (!ok) {
-      nlevel = fxo::level_order_host(graph(), start, cur);
-      if (nlevel > best_levels) { best_levels = nlevel; seq_out = cur; }
-      continue;
-    }
-    if (nlevel > best_levels) {  // strictly more levels wins: the first of equals stays (hecmw_matrix_ordering_CM.f90:41-47)
+  for (int s = 0; s < S; s++) {  // strictly more levels wins: the first of equals stays (hecmw_matrix_ordering_CM.f90:41-47)
+    int32_t nlevel = h_st[s].nlevel;
+    const bool on_device = h_st[s].hi == N && !h_st[s].stuck;
+    if (!on_device) nlevel = fxo::level_order_host(graph(), starts[s], cur);
+    if (nlevel > best_levels) {
       best_levels = nlevel;
-      seq_out.resize((size_t)N);
-      HIP_TRY(hipMemcpy(seq_out.data(), seq, (size_t)N * 4, hipMemcpyDeviceToHost));
+      if (on_device) best = s;
+      else { best = -2; seq_out = cur; }
     }
+  }
+  if (best >= 0) {
+    seq_out.resize((size_t)N);
+    HIP_TRY(hipMemcpy(seq_out.data(), seq + (size_t)best * N, (size_t)N * 4, hipMemcpyDeviceToHost));
   }
   for (auto &v : seq_out) v = N - 1 - v;  // reverse_ordering: id mirror
   return 0;
@@ -1213,9 +1222,8 @@ static int ssor_setup_symbolic(fx_context *c, int ncolor_in) {
   };
   pt.lap("degrees");
   std::vector<int32_t> seq;
-  int32_t max_width = 0;
   if (N >= c->bfs_device_min) {
-    if (rcm_sequence_device(c, fxo::rcm_starts_deg(N, deg.data()), graph, seq, &max_width)) return FX_ERROR_RUNTIME;
+    if (rcm_sequence_device(c, fxo::rcm_starts_deg(N, deg.data()), graph, seq)) return FX_ERROR_RUNTIME;
   } else seq = fxo::rcm_sequence(graph());
   pt.lap("level ordering");
   std::vector<int32_t> perm0, cidx;
@@ -1512,11 +1520,9 @@ static int tune_work_vectors(fx_context *c) {
   memset(&st0, 0, sizeof st0);
   HIP_TRY(hipMemcpyAsync(c->st, &st0, sizeof st0, hipMemcpyHostToDevice, c->stream));  // status 0: the gated sweeps run
   for (int k = 0; k < 10; k++) HIP_TRY(hipMemcpyAsync(c->W[k], c->Bs, (size_t)c->wlen * 8, hipMemcpyDeviceToDevice, c->stream));
-  auto timed = [&](auto &&launch, float *ms) -> int {
-    if (launch()) return FX_ERROR_RUNTIME;  // untimed
+  auto timed = [&](auto &&launch, float *ms) -> int {  // one launch each: the effect looked for is 5-10 %, the noise of one launch 1 %
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    for (int i = 0; i < 2; i++)
-      if (launch()) return FX_ERROR_RUNTIME;
+    if (launch()) return FX_ERROR_RUNTIME;
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(hipEventSynchronize(c->ev1));
     HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
@@ -1552,7 +1558,7 @@ static int tune_work_vectors(fx_context *c) {
   for (int q = 0; q < 10; q++) c->W[priority[q]] = old[score[q].second];
   for (int k = 0; k < 10; k++) HIP_TRY(hipMemsetAsync(c->W[k], 0, (size_t)c->wlen * 8, c->stream));
   if (getenv("FX_TIMING") && atoi(getenv("FX_TIMING"))) {
-    fprintf(stderr, "[fx timing] work vectors (written + gathered%s + 4 x streamed, 2 launches each, ms; [streamed alone]):", sweeps ? " + swept" : "");
+    fprintf(stderr, "[fx timing] work vectors (written + gathered%s + 4 x streamed, ms; [streamed alone]):", sweeps ? " + swept" : "");
     for (auto &sc : score) fprintf(stderr, " %d:%.3f[%.3f]", sc.second, sc.first, stream_ms[sc.second]);
     fprintf(stderr, "\n");
   }

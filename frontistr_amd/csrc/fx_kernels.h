@@ -1415,34 +1415,7 @@ __device__ __forceinline__ void bfs_for_neighbours(int32_t u, int32_t N, const i
     if (v < N) f(v);  // halo columns are not part of the graph
   }
 }
-__global__ void k_bfs_claim(int32_t nf, const int32_t *__restrict__ frontier, uint32_t f0, int32_t N, const int32_t *__restrict__ indexL,
-                            const int32_t *__restrict__ itemL, const int32_t *__restrict__ indexU, const int32_t *__restrict__ itemU,
-                            const uint8_t *__restrict__ seen, uint32_t *__restrict__ claim) {
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= nf) return;
-  bfs_for_neighbours(frontier[q], N, indexL, itemL, indexU, itemU, [&](int32_t v) {
-    if (!seen[v]) atomicMin(&claim[v], f0 + (uint32_t)q);
-  });
-}
-template <bool WRITE>
-__global__ void k_bfs_children(int32_t nf, const int32_t *__restrict__ frontier, uint32_t f0, int32_t N,
-                               const int32_t *__restrict__ indexL, const int32_t *__restrict__ itemL,
-                               const int32_t *__restrict__ indexU, const int32_t *__restrict__ itemU,
-                               const uint8_t *__restrict__ seen, const uint32_t *__restrict__ claim, int32_t *__restrict__ cnt,
-                               const int32_t *__restrict__ off, int32_t *__restrict__ out) {
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= nf) return;
-  int32_t k = 0;
-  const int32_t o = WRITE ? off[q] : 0;
-  bfs_for_neighbours(frontier[q], N, indexL, itemL, indexU, itemU, [&](int32_t v) {
-    if (!seen[v] && claim[v] == f0 + (uint32_t)q) {
-      if (WRITE) out[o + k] = v;
-      k++;
-    }
-  });
-  if (!WRITE) cnt[q] = k;
-}
-// exclusive scan of n ints by ONE workgroup (n <= a few hundred thousand: a frontier), total -> *total
+// exclusive scan of n ints by ONE workgroup (n up to a few hundred thousand: slice widths, block sums), total -> *total
 __global__ __launch_bounds__(1024) void k_scan_excl(int32_t n, const int32_t *__restrict__ in, int32_t *__restrict__ out,
                                                     int32_t *__restrict__ total) {
   __shared__ int32_t sh[1024];
@@ -1463,9 +1436,132 @@ __global__ __launch_bounds__(1024) void k_scan_excl(int32_t n, const int32_t *__
   for (int i = a; i < b; i++) { const int32_t v = in[i]; out[i] = run; run += v; }
   if (t == 1023) *total = sh[1023];
 }
-__global__ void k_bfs_mark(int32_t n, const int32_t *__restrict__ nodes, uint8_t *__restrict__ seen) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) seen[nodes[i]] = 1;
+// The walk runs for ALL candidate starts at once and without a host round trip per level (blockIdx.y = start): the level
+// state {lo, hi, nlevel, stuck} lives on the device, double-buffered by level parity -- the scan kernel (one workgroup per
+// start) writes the next level's state while the write and mark kernels still read the current one.  Frontier entries are
+// grouped in virtual blocks of 256 (grid-stride): k_bfsb_count leaves per-parent counts and per-block sums, k_bfsb_scan
+// turns the sums into offsets, k_bfsb_write rebuilds the in-block prefix in LDS and appends the children in parent order,
+// adjacency order -- the sequential sequence, node for node.  A finished start (hi = N) or a stuck one (nothing discovered
+// with nodes left: a disconnected graph, the host walk takes over) turns further levels into no-ops.
+struct BfsState { int32_t lo, hi, nlevel, stuck; };
+__global__ __launch_bounds__(256) void k_bfsb_claim(int32_t N, const BfsState *__restrict__ st, const int32_t *__restrict__ indexL,
+                                                    const int32_t *__restrict__ itemL, const int32_t *__restrict__ indexU,
+                                                    const int32_t *__restrict__ itemU, const int32_t *__restrict__ seq_all,
+                                                    const uint8_t *__restrict__ seen_all, uint32_t *__restrict__ claim_all) {
+  const int s = blockIdx.y;
+  const BfsState S = st[s];
+  const int32_t nf = S.hi - S.lo;
+  const int32_t *seq = seq_all + (size_t)s * N + S.lo;
+  const uint8_t *seen = seen_all + (size_t)s * N;
+  uint32_t *claim = claim_all + (size_t)s * N;
+  for (int32_t q = blockIdx.x * 256 + threadIdx.x; q < nf; q += gridDim.x * 256)
+    bfs_for_neighbours(seq[q], N, indexL, itemL, indexU, itemU, [&](int32_t v) {
+      if (!seen[v]) atomicMin(&claim[v], (uint32_t)(S.lo + q));
+    });
+}
+__global__ __launch_bounds__(256) void k_bfsb_count(int32_t N, int32_t nvb_max, const BfsState *__restrict__ st,
+                                                    const int32_t *__restrict__ indexL, const int32_t *__restrict__ itemL,
+                                                    const int32_t *__restrict__ indexU, const int32_t *__restrict__ itemU,
+                                                    const int32_t *__restrict__ seq_all, const uint8_t *__restrict__ seen_all,
+                                                    const uint32_t *__restrict__ claim_all, int32_t *__restrict__ cnt_all,
+                                                    int32_t *__restrict__ bsum_all) {
+  __shared__ int32_t sh;
+  const int s = blockIdx.y;
+  const BfsState S = st[s];
+  const int32_t nf = S.hi - S.lo;
+  const int32_t *seq = seq_all + (size_t)s * N + S.lo;
+  const uint8_t *seen = seen_all + (size_t)s * N;
+  const uint32_t *claim = claim_all + (size_t)s * N;
+  int32_t *cnt = cnt_all + (size_t)s * N, *bsum = bsum_all + (size_t)s * nvb_max;
+  for (int32_t vb = blockIdx.x; (int64_t)vb * 256 < nf; vb += gridDim.x) {
+    if (threadIdx.x == 0) sh = 0;
+    __syncthreads();
+    const int32_t q = vb * 256 + threadIdx.x;
+    int32_t k = 0;
+    if (q < nf) {
+      bfs_for_neighbours(seq[q], N, indexL, itemL, indexU, itemU, [&](int32_t v) { k += !seen[v] && claim[v] == (uint32_t)(S.lo + q); });
+      cnt[q] = k;
+    }
+    if (k) atomicAdd(&sh, k);
+    __syncthreads();
+    if (threadIdx.x == 0) bsum[vb] = sh;
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(1024) void k_bfsb_scan(int32_t N, int32_t nvb_max, const BfsState *__restrict__ st,
+                                                    BfsState *__restrict__ st_next, const int32_t *__restrict__ bsum_all,
+                                                    int32_t *__restrict__ boff_all) {
+  __shared__ int32_t sh[1024];
+  const int s = blockIdx.x, t = threadIdx.x;
+  const BfsState S = st[s];
+  const int32_t nf = S.hi - S.lo, n = (nf + 255) / 256;
+  const int32_t *in = bsum_all + (size_t)s * nvb_max;
+  int32_t *out = boff_all + (size_t)s * nvb_max;
+  const int chunk = (n + 1023) / 1024;
+  const int a = min(n, t * chunk), b = min(n, a + chunk);
+  int32_t sum = 0;
+  for (int i = a; i < b; i++) sum += in[i];
+  sh[t] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int32_t v = (t >= d) ? sh[t - d] : 0;
+    __syncthreads();
+    sh[t] += v;
+    __syncthreads();
+  }
+  int32_t run = sh[t] - sum;
+  for (int i = a; i < b; i++) { const int32_t v = in[i]; out[i] = run; run += v; }
+  if (t == 1023) {
+    const int32_t nnew = sh[1023];
+    BfsState nx = S;
+    if (nf > 0) {
+      nx.lo = S.hi;
+      nx.hi = S.hi + nnew;
+      if (nnew > 0) nx.nlevel = S.nlevel + 1;
+      else nx.stuck = S.hi < N;
+    }
+    st_next[s] = nx;
+  }
+}
+__global__ __launch_bounds__(256) void k_bfsb_write(int32_t N, int32_t nvb_max, const BfsState *__restrict__ st,
+                                                    const int32_t *__restrict__ indexL, const int32_t *__restrict__ itemL,
+                                                    const int32_t *__restrict__ indexU, const int32_t *__restrict__ itemU,
+                                                    int32_t *seq_all, const uint8_t *__restrict__ seen_all,
+                                                    const uint32_t *__restrict__ claim_all, const int32_t *__restrict__ cnt_all,
+                                                    const int32_t *__restrict__ boff_all) {
+  __shared__ int32_t sh[256];
+  const int s = blockIdx.y, t = threadIdx.x;
+  const BfsState S = st[s];
+  const int32_t nf = S.hi - S.lo;
+  int32_t *seq0 = seq_all + (size_t)s * N;
+  const uint8_t *seen = seen_all + (size_t)s * N;
+  const uint32_t *claim = claim_all + (size_t)s * N;
+  const int32_t *cnt = cnt_all + (size_t)s * N, *boff = boff_all + (size_t)s * nvb_max;
+  for (int32_t vb = blockIdx.x; (int64_t)vb * 256 < nf; vb += gridDim.x) {
+    const int32_t q = vb * 256 + t;
+    const int32_t k = q < nf ? cnt[q] : 0;
+    sh[t] = k;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+      const int32_t v = t >= d ? sh[t - d] : 0;
+      __syncthreads();
+      sh[t] += v;
+      __syncthreads();
+    }
+    int32_t o = S.hi + boff[vb] + sh[t] - k;
+    if (k) bfs_for_neighbours(seq0[S.lo + q], N, indexL, itemL, indexU, itemU, [&](int32_t v) {
+      if (!seen[v] && claim[v] == (uint32_t)(S.lo + q)) seq0[o++] = v;
+    });
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void k_bfsb_mark(int32_t N, const BfsState *__restrict__ st, const BfsState *__restrict__ st_next,
+                                                   const int32_t *__restrict__ seq_all, uint8_t *__restrict__ seen_all) {
+  const int s = blockIdx.y;
+  const int32_t hi = st[s].hi, nnew = st_next[s].hi - hi;
+  const int32_t *seq = seq_all + (size_t)s * N + hi;
+  uint8_t *seen = seen_all + (size_t)s * N;
+  for (int32_t i = blockIdx.x * 256 + threadIdx.x; i < nnew; i += gridDim.x * 256) seen[seq[i]] = 1;
 }
 
 // ------------------------------------------------------------------------

@@ -832,6 +832,36 @@ def test_device_level_ordering_equals_host_ordering(hip, n, skew, batch, monkeyp
     ctx.close()
 
 
+def test_device_level_ordering_disconnected_graph_takes_host_walk(hip, monkeypatch):
+    """Two cubes that share no node: the level walk on the device discovers nothing after the first component (state `stuck`),
+    the host walk -- which jumps to the lowest unvisited node like the reference -- takes over for that start, and the device
+    multicolouring runs on its sequence: same perm / COLORindex as the host-only ordering."""
+    import ctypes as C
+    from frontistr_amd.mesh import CubeMesh
+    from test_abi import _lib_ordering
+    a, b = CubeMesh(5), CubeMesh(3, skew=0.05)
+    conn = np.vstack([a.conn, b.conn + a.n_node])
+    coord = np.vstack([a.coord.reshape(-1, 3), b.coord.reshape(-1, 3) + np.array([20.0, 0.0, 0.0])])
+    hm = hip.hecmwST_local_mesh(n_node=a.n_node + b.n_node)
+    hm.elem_node_item = conn.ravel()
+    m = hip.hecmw_mat_con(hm, hip.hecmwST_matrix())
+    monkeypatch.setenv("FX_BFS_DEVICE_MIN", "0")
+    monkeypatch.setenv("FX_MC_DEVICE_MIN", "0")
+    monkeypatch.setenv("FX_BFS_BATCH", "3")
+    ctx = hip.SolverContext()
+    ctx.upload(m, what=hip.FX_UP_PROFILE)
+    (an, ad, av), (bn, bd, bv) = a.dirichlet(), b.dirichlet()
+    bc = (np.concatenate([an, bn + a.n_node]), np.concatenate([ad, bd]), np.concatenate([av, bv]))
+    ctx.assemble_c3d8(coord, conn, 210000.0, 0.3, elemopt=1, load=np.zeros(3 * (a.n_node + b.n_node)), bc=bc)
+    m.Iarray[2] = 1
+    ctx.precond_setup(m)
+    perm = np.zeros(m.N, dtype=np.int32); cidx = np.zeros(m.N + 2, dtype=np.int32); nc = C.c_int32(0)
+    assert hip.lib().fx_get_ssor_ordering(ctx.h, perm.ctypes.data_as(C.c_void_p), cidx.ctypes.data_as(C.c_void_p), cidx.size, C.byref(nc)) == 0
+    hperm, hcidx = _lib_ordering(m, 10)
+    assert np.array_equal(cidx[:nc.value + 1], hcidx) and np.array_equal(perm, hperm)
+    ctx.close()
+
+
 @pytest.mark.parametrize("deck", DECKS + ["cube12"])
 @pytest.mark.parametrize("pc", [3, 1, 10])
 def test_device_built_layouts_equal_host_built(hip, oracle, deck, pc, monkeypatch):
