@@ -2,16 +2,29 @@
 #pragma once
 
 // hecmw_mat_con (hecmw_mat_con.f90:23-268): CRS block profile from element connectivity.
-// Node -> element incidence by counting sort, then per node the sorted unique set of the
-// nodes of its elements, split into lower / upper; rows are independent => host threads.
-// The two-call protocol (count, then fill) would build the node -> element incidence and every row's neighbour list twice;
-// the first call keeps the lists (one flat array, ~ (NPL + NPU + NP) ints) for the second, which then only splits them.
+// Node -> element incidence by counting sort (host threads, relaxed atomic counters: the order of a node's elements does
+// not matter, its neighbour set is sorted afterwards), then per node the sorted unique set of the nodes of its elements,
+// split into lower / upper; rows are independent => one contiguous chunk of nodes per host thread, each keeping the lists
+// of its rows back to back.  The two-call protocol (count, then fill) would build all of that twice; the first call keeps
+// the chunks (~ (NPL + NPU + NP) ints) for the second, which then only splits them.
 struct MatConCache {
   const int32_t *conn = nullptr;
   int32_t NP = 0, n_elem = 0, nn = 0;
-  std::vector<int64_t> rptr;
-  std::vector<int32_t> rows;  // per node: sorted unique neighbour ids (1-based), itself included
-  void clear() { conn = nullptr; std::vector<int64_t>().swap(rptr); std::vector<int32_t>().swap(rows); }
+  std::vector<int64_t> cstart;             // chunk c holds the rows of nodes cstart[c] + 1 .. cstart[c + 1] (1-based)
+  std::vector<std::vector<int32_t>> rows;  // per chunk: sorted unique neighbour ids (1-based, itself included) of its nodes, back to back
+  std::vector<int32_t> rlen;               // per node (index 1..NP): length of its list
+  void clear() {
+    conn = nullptr;
+    std::vector<int64_t>().swap(cstart);
+    std::vector<std::vector<int32_t>>().swap(rows);
+    std::vector<int32_t>().swap(rlen);
+  }
+  template <class F>
+  void for_chunks(F f) const {  // f(chunk) on one host thread per chunk
+    std::vector<std::thread> th;
+    for (size_t c = 0; c + 1 < cstart.size(); c++) th.emplace_back([=] { f((int)c); });
+    for (auto &t : th) t.join();
+  }
 };
 static thread_local MatConCache g_matcon;  // per calling thread: the count and the fill call of one profile come from the same thread; concurrent callers (one thread per subdomain) do not share it
 
@@ -19,52 +32,69 @@ extern "C" int fx_mat_con(int32_t NP, int32_t n_elem, int32_t nn, const int32_t 
                           int32_t *itemL, int32_t *itemU) {
   MatConCache &mc = g_matcon;
   const bool fill = itemL && itemU;
-  if (!(fill && mc.conn == conn && mc.NP == NP && mc.n_elem == n_elem && mc.nn == nn && !mc.rptr.empty())) {
+  if (!(fill && mc.conn == conn && mc.NP == NP && mc.n_elem == n_elem && mc.nn == nn && !mc.rlen.empty())) {
     mc.clear();
-    std::vector<int64_t> ptr((size_t)NP + 2, 0);
+    PhaseTimer pt("mat_con");
     const int64_t tot = (int64_t)n_elem * nn;
-    for (int64_t k = 0; k < tot; k++) {
-      const int32_t v = conn[k];
-      if (v < 1 || v > NP) { g_fx_error = "fx_mat_con: node id out of range"; return FX_ERROR_RUNTIME; }
-      ptr[v + 1]++;
+    std::vector<int64_t> ptr((size_t)NP + 2, 0);
+    {
+      std::vector<int32_t> deg((size_t)NP + 2, 0);
+      int bad = 0;
+      parallel_for(tot, [&](int64_t a, int64_t b) {
+        for (int64_t k = a; k < b; k++) {
+          const int32_t v = conn[k];
+          if (v < 1 || v > NP) { __atomic_store_n(&bad, 1, __ATOMIC_RELAXED); return; }
+          __atomic_fetch_add(&deg[v + 1], 1, __ATOMIC_RELAXED);
+        }
+      });
+      if (bad) { g_fx_error = "fx_mat_con: node id out of range"; return FX_ERROR_RUNTIME; }
+      for (int32_t i = 1; i <= NP + 1; i++) ptr[i] = ptr[i - 1] + deg[i];
     }
-    for (int32_t i = 1; i <= NP + 1; i++) ptr[i] += ptr[i - 1];
+    pt.lap("count");
     std::vector<int32_t> inc((size_t)tot);
     {
       std::vector<int64_t> pos(ptr.begin(), ptr.end());
-      for (int32_t e = 0; e < n_elem; e++)
-        for (int j = 0; j < nn; j++) inc[pos[conn[(size_t)e * nn + j]]++] = e;
+      parallel_for(n_elem, [&](int64_t a, int64_t b) {
+        for (int64_t e = a; e < b; e++)
+          for (int j = 0; j < nn; j++) inc[__atomic_fetch_add(&pos[conn[(size_t)e * nn + j]], 1, __ATOMIC_RELAXED)] = (int32_t)e;
+      });
     }
-    auto row_nodes = [&](int32_t i, std::vector<int32_t> &buf) {
-      buf.clear();
-      for (int64_t a = ptr[i]; a < ptr[i + 1]; a++) {
-        const int32_t *en = conn + (size_t)inc[a] * nn;
-        buf.insert(buf.end(), en, en + nn);
+    pt.lap("incidence");
+    const int nt = (int)std::min<int64_t>(nthreads_host(), std::max<int64_t>(1, NP / 4096));
+    mc.cstart.resize((size_t)nt + 1);
+    for (int c = 0; c <= nt; c++) mc.cstart[c] = (int64_t)NP * c / nt;
+    mc.rows.assign((size_t)nt, std::vector<int32_t>());
+    mc.rlen.assign((size_t)NP + 1, 0);
+    mc.for_chunks([&](int c) {
+      std::vector<int32_t> &out = mc.rows[c];
+      const int64_t a = mc.cstart[c], b = mc.cstart[c + 1];
+      out.reserve((size_t)((ptr[b + 1] - ptr[a + 1]) * 7 / 2 + 64));  // a hex8 node: 8 elements x 8 nodes -> 27 neighbours
+      std::vector<int32_t> buf;
+      for (int64_t i = a + 1; i <= b; i++) {
+        buf.clear();
+        for (int64_t q = ptr[i]; q < ptr[i + 1]; q++) {
+          const int32_t *en = conn + (size_t)inc[q] * nn;
+          buf.insert(buf.end(), en, en + nn);
+        }
+        std::sort(buf.begin(), buf.end());
+        buf.erase(std::unique(buf.begin(), buf.end()), buf.end());
+        mc.rlen[i] = (int32_t)buf.size();
+        out.insert(out.end(), buf.begin(), buf.end());
       }
-      std::sort(buf.begin(), buf.end());
-      buf.erase(std::unique(buf.begin(), buf.end()), buf.end());
-    };
-    // pass 1: sizes (parallel), pass 2: lists into one flat array (parallel)
-    mc.rptr.assign((size_t)NP + 1, 0);
-    parallel_for(NP, [&](int64_t a, int64_t b) {
-      std::vector<int32_t> buf;
-      for (int64_t i = a + 1; i <= b; i++) { row_nodes((int32_t)i, buf); mc.rptr[i] = (int64_t)buf.size(); }
-    });
-    for (int32_t i = 1; i <= NP; i++) mc.rptr[i] += mc.rptr[i - 1];
-    mc.rows.resize((size_t)mc.rptr[NP]);
-    parallel_for(NP, [&](int64_t a, int64_t b) {
-      std::vector<int32_t> buf;
-      for (int64_t i = a + 1; i <= b; i++) { row_nodes((int32_t)i, buf); std::copy(buf.begin(), buf.end(), mc.rows.begin() + mc.rptr[i - 1]); }
     });
     mc.conn = conn; mc.NP = NP; mc.n_elem = n_elem; mc.nn = nn;
+    pt.lap("row lists");
   }
+  PhaseTimer pt2(fill ? "mat_con fill" : "mat_con index");
   if (!fill) {
     std::vector<int32_t> nl((size_t)NP + 1, 0), nu((size_t)NP + 1, 0);
-    parallel_for(NP, [&](int64_t a, int64_t b) {
-      for (int64_t i = a + 1; i <= b; i++) {
+    mc.for_chunks([&](int c) {
+      const int32_t *r = mc.rows[c].data();
+      for (int64_t i = mc.cstart[c] + 1; i <= mc.cstart[c + 1]; i++) {
         int32_t l = 0, u = 0;
-        for (int64_t k = mc.rptr[i - 1]; k < mc.rptr[i]; k++) { l += (mc.rows[k] < i); u += (mc.rows[k] > i); }
+        for (int32_t k = 0; k < mc.rlen[i]; k++) { l += (r[k] < i); u += (r[k] > i); }
         nl[i] = l; nu[i] = u;
+        r += mc.rlen[i];
       }
     });
     indexL[0] = 0; indexU[0] = 0;
@@ -74,18 +104,22 @@ extern "C" int fx_mat_con(int32_t NP, int32_t n_elem, int32_t nn, const int32_t 
       if (cl > INT32_MAX || cu > INT32_MAX) { g_fx_error = "fx_mat_con: profile exceeds int32 (kint=4)"; mc.clear(); return FX_ERROR_RUNTIME; }
       indexL[i] = (int32_t)cl; indexU[i] = (int32_t)cu;
     }
+    pt2.lap("indexL / indexU");
     return 0;  // the lists stay for the fill call
   }
-  parallel_for(NP, [&](int64_t a, int64_t b) {
-    for (int64_t i = a + 1; i <= b; i++) {
+  mc.for_chunks([&](int c) {
+    const int32_t *r = mc.rows[c].data();
+    for (int64_t i = mc.cstart[c] + 1; i <= mc.cstart[c + 1]; i++) {
       int32_t *pl = itemL + indexL[i - 1], *pu = itemU + indexU[i - 1];
-      for (int64_t k = mc.rptr[i - 1]; k < mc.rptr[i]; k++) {
-        const int32_t v = mc.rows[k];
+      for (int32_t k = 0; k < mc.rlen[i]; k++) {
+        const int32_t v = r[k];
         if (v < i) *pl++ = v;
         else if (v > i) *pu++ = v;
       }
+      r += mc.rlen[i];
     }
   });
+  pt2.lap("itemL / itemU");
   mc.clear();
   return 0;
 }
