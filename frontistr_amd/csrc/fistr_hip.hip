@@ -258,6 +258,7 @@ extern "C" int fx_create(int device, fx_context **out) {
   if (const char *e = getenv("FX_BFS_DEVICE_MIN")) c->bfs_device_min = atoi(e);
   if (const char *e = getenv("FX_MC_DEVICE_MIN")) c->mc_device_min = atoi(e);
   if (const char *e = getenv("FX_BFS_BATCH")) c->bfs_batch = std::max(1, atoi(e));
+  if (const char *e = getenv("FX_TUNE_BUDGET_MS")) c->tune_budget_s = 1e-3 * atof(e);
   if (const char *e = getenv("FX_MC_BATCH")) c->mc_batch = std::max(1, atoi(e));
   if (const char *e = getenv("FX_LAYOUT_DEVICE")) c->layout_device = atoi(e) != 0;
   if (const char *e = getenv("FX_PIPE_SPMV")) c->pipe_spmv = atoi(e) != 0;
@@ -629,6 +630,7 @@ static int tune_placement(fx_context *c, Bell &B, const char *what, double strea
   int err = time_ms(&t[0]);
   for (int k = 1; k < tries && !err; k++) {
     if (stream_bytes / (1e-3 * *std::min_element(t.begin(), t.end())) / 1e9 >= good_gbs) break;
+    if (c->tune_spent_s >= c->tune_budget_s) break;  // a candidate costs 7-10 ms when hipMalloc hands out recycled memory, 60-350 ms when the driver has to clear fresh VRAM
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + (bytes >> 1) + ((size_t)4 << 30)) break;  // keep headroom
     char *base = nullptr;
@@ -641,6 +643,7 @@ static int tune_placement(fx_context *c, Bell &B, const char *what, double strea
     t.push_back(1e30f);
     err = fill();
     if (!err) err = time_ms(&t.back());
+    c->tune_spent_s += now_s() - w0;
     if (getenv("FX_PLACEMENT_DEBUG")) fprintf(stderr, "[fx placement] try %d: hipMalloc %.1f ms, fill + time %.1f ms\n", k, 1e3 * (w1 - w0), 1e3 * (now_s() - w1));
   }
   if (err) {  // keep the first allocation (it is filled), release everything tried after it
