@@ -144,6 +144,58 @@ print('self halo ok', len(res[(1, 'rccl')][0]), res[(1, 'rccl')][0][-1])
     assert p.returncode == 0 and "self halo ok" in p.stdout, p.stdout[-3000:]
 
 
+def test_host_callback_halo_buffers_follow_a_larger_profile():
+    """one context, the host-callback transport, two profiles in a row -- a 4^3 subdomain, then a 9^3 one whose
+    import / export tables are five times longer.  The pinned staging pair of the callback path is sized by the tables, so it
+    has to be re-allocated with them (setup_halo); hecmw_matvec of both profiles against numpy, the big one last and first."""
+    import ctypes as C
+    from frontistr_amd import hecmw as hip
+    from frontistr_amd.partition import cube_subdomain
+    HALO = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
+    ARED = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int, C.c_void_p)
+    state = {"n": 0}
+    def _halo(send, recv, _u):
+        C.memmove(recv, send, 8 * 3 * state["n"])
+    cbs = (HALO(_halo), ARED(lambda v, n, u: None))
+
+    def case(n, seed):
+        sub = cube_subdomain(n, (2, 1, 1), 0)
+        hm = sub.hecmesh(hip)
+        hm.elem_node_item = sub.conn.ravel()
+        m = hip.hecmw_mat_con(hm, hip.hecmwST_matrix())
+        N, NP = m.N, m.NP
+        rng = np.random.default_rng(seed)
+        m.D = rng.standard_normal(9 * NP); m.AL = 0.1 * rng.standard_normal(9 * m.NPL); m.AU = 0.1 * rng.standard_normal(9 * m.NPU)
+        n_imp = NP - N
+        exp_item = (1 + rng.permutation(N)[:n_imp]).astype(np.int32)
+        hm.my_rank, hm.PETOT, hm.n_neighbor_pe = 0, 1, 1
+        hm.neighbor_pe = np.zeros(1, dtype=np.int32)
+        hm.import_index = np.array([0, n_imp], dtype=np.int32); hm.export_index = hm.import_index.copy()
+        hm.export_item = exp_item
+        X = rng.standard_normal(3 * NP)
+        xf = X.copy().reshape(NP, 3)
+        xf[hm.import_item - 1] = xf[exp_item - 1]
+        y = np.einsum('nij,nj->ni', m.D.reshape(NP, 3, 3)[:N], xf[:N])
+        for i in range(N):
+            for j in range(m.indexL[i], m.indexL[i + 1]):
+                y[i] += m.AL[9 * j:9 * j + 9].reshape(3, 3) @ xf[m.itemL[j] - 1]
+            for j in range(m.indexU[i], m.indexU[i + 1]):
+                y[i] += m.AU[9 * j:9 * j + 9].reshape(3, 3) @ xf[m.itemU[j] - 1]
+        return hm, m, X, y.ravel(), n_imp
+
+    small, big = case(4, 1), case(9, 2)
+    assert big[4] >= 4 * small[4]
+    for order in ((small, big), (big, small, big)):
+        ctx = hip.SolverContext()
+        assert hip.lib().fx_comm_set_host_callbacks(ctx.h, 0, 1, cbs[0], cbs[1], None) == 0
+        for hm, m, X, ref, n_imp in order:
+            state["n"] = n_imp
+            Y = np.zeros(3 * m.NP)
+            hip.hecmw_matvec(hm, m, X.copy(), Y, ctx=ctx)
+            assert np.abs(Y[:3 * m.N] - ref).max() < 1e-12 * np.abs(ref).max(), n_imp
+        ctx.close()
+
+
 def test_rccl_self_neighbour_halo_exchange_generic_blocks(tmp_path):
     """The same self-neighbour drive for the NDOF != 3 path (nn_halo: NDOF doubles per node): hecmw_matvec against numpy and a
     CG + DIAG solve over RCCL against the host-callback transport, NDOF = 2 and 6."""
