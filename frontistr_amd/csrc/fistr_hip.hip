@@ -274,6 +274,16 @@ extern "C" int fx_create(int device, fx_context **out) {
   if (const char *e = getenv("FX_EISENSTAT")) c->eisenstat = atoi(e) != 0;
   if (const char *e = getenv("FX_SPLIT_MAX_SLICES")) c->split_max_slices = atoi(e);
   if (const char *e = getenv("FX_DATAFLOW")) c->df_mode = atoi(e);
+  if (const char *e = getenv("FX_CH_HOP")) c->ch_hop = std::max(0, atoi(e));
+  if (const char *e = getenv("FX_CH_GRID")) c->ch_grid = atoi(e);
+  if (const char *e = getenv("FX_CH_AHEAD")) c->ch_ahead = atoi(e);
+  if (const char *e = getenv("FX_CH_W")) c->ch_w = atoi(e);
+  if (const char *e = getenv("FX_CH_MAXLEN")) c->ch_maxlen = std::max(1, atoi(e));
+  {  // chain sweeps: every workgroup of the launch must be resident at once
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tri_chain<8>, 256, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
+    c->ch_grid_auto = std::max(1, c->n_cu * std::min(per_cu, 8));
+  }
   if (const char *e = getenv("FX_DF_GRID")) c->df_grid = atoi(e);
   if (const char *e = getenv("FX_DF_POLL")) c->df_poll = atoi(e);
   if (const char *e = getenv("FX_DF_SLEEP")) c->df_sleep = std::max(0, atoi(e));
@@ -317,6 +327,8 @@ static void free_precond(fx_context *c) {
   bell_free(c->ssor.L); bell_free(c->ssor.U); bell_free(c->ssor.H);
   dev_free(c->ssor.alu); dev_free(c->ssor.dblk); dev_free(c->ssor.slot_node); dev_free(c->ssor.zs); dev_free(c->ssor.zb);
   dev_free(c->ssor.lu_D); dev_free(c->ssor.lu_AL); dev_free(c->ssor.lu_AU);
+  dev_free(c->ssor.ch_ordF); dev_free(c->ssor.ch_ordB); dev_free(c->ssor.ch_startF); dev_free(c->ssor.ch_startB);
+  dev_free(c->ssor.ch_zf); dev_free(c->ssor.ch_zb);
   c->ssor = SsorDev();
   c->precond_valid = false;
   c->precond_valid_sweeps = false;
@@ -1407,6 +1419,7 @@ static int ssor_setup_numeric(fx_context *c, double sigma_diag) {
 // levels.  The level structure reuses the SSOR machinery: "colours" = levels, a private level-major
 // sweep vector, BELL copies of the strictly lower / upper FACTOR blocks; the apply (:90-157) is then the
 // same pair of sweeps as SSOR's, forward over ascending levels, backward over descending ones.
+static int ilu_setup_chain(fx_context *c);
 static int ilu_setup_symbolic(fx_context *c) {
   const int32_t N = c->A.N;
   SsorDev &S = c->ssor;
@@ -1476,6 +1489,116 @@ static int ilu_setup_symbolic(fx_context *c) {
   }
   dev_free(S.alu);
   if (dev_alloc(&S.alu, (size_t)(nslots / 64) * 576)) return FX_ERROR_RUNTIME;
+  if (ilu_setup_chain(c)) return FX_ERROR_RUNTIME;
+  pt.lap("chain schedule");
+  return 0;
+}
+
+// Units and visiting orders of the chain sweeps (k_tri_chain).  A unit is a CHAIN: a maximal run of consecutive rows in which
+// every row depends on the one before it in the sweep's direction (a pencil of a structured mesh), cut at `maxlen` rows.
+// A unit that started in the middle of such a run could not begin before its predecessor had finished -- with fixed-length
+// units the whole sweep degenerates into one serial chain.  Units are sorted by an estimate of when they can start: a row
+// costs one step, a value from another unit arrives `hop` steps after its row is done; a unit can start when, for every row,
+// its outside dependencies will have arrived by the time the walk reaches that row.  The key is also kept above the keys of
+// all units it depends on, so the order is topological: a wave that takes the entries k, k + G, ... in order only ever waits
+// for entries before its own.  Returns the estimated makespans (steps) of the two sweeps.
+struct ChainPlan {
+  std::vector<int32_t> startF, ordF, startB, ordB;
+  int64_t spanF = 0, spanB = 0;
+};
+static void chain_schedule(int32_t N, int hop, int maxlen, const int32_t *iL, const int32_t *jL, const int32_t *iU, const int32_t *jU,
+                           ChainPlan &P) {
+  std::vector<int64_t> done((size_t)N);
+  std::vector<int32_t> unit_of((size_t)N);
+  auto sorted = [&](const std::vector<int64_t> &key, std::vector<int32_t> &ord) {
+    ord.resize(key.size());
+    for (size_t k = 0; k < key.size(); k++) ord[k] = (int32_t)k;
+    std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return key[x] < key[y]; });
+  };
+  {  // forward: row i continues the chain of row i - 1 when i - 1 is among its lower columns (ascending: the last one)
+    P.startF.assign(1, 0);
+    for (int32_t i = 1; i < N; i++) {
+      const bool cont = iL[i + 1] > iL[i] && jL[iL[i + 1] - 1] == i;  // 1-based id of row i - 1
+      if (!cont || i - P.startF.back() >= maxlen) P.startF.push_back(i);
+    }
+    P.startF.push_back(N);
+    const int32_t nu = (int32_t)P.startF.size() - 1;
+    std::vector<int64_t> key((size_t)nu);
+    for (int32_t u = 0; u < nu; u++) {
+      const int32_t a = P.startF[u], b = P.startF[u + 1];
+      int64_t start = 0, kdep = -1;
+      for (int32_t i = a; i < b; i++) {
+        unit_of[i] = u;
+        for (int32_t j = iL[i]; j < iL[i + 1]; j++) {
+          const int32_t cidx = jL[j] - 1;
+          if (cidx >= a) continue;
+          start = std::max(start, done[cidx] + hop - (i - a));
+          kdep = std::max(kdep, key[unit_of[cidx]]);
+        }
+      }
+      start = std::max(start, kdep + 1);
+      key[u] = start;
+      for (int32_t i = a; i < b; i++) done[i] = start + (i - a) + 1;
+      P.spanF = std::max(P.spanF, start + (b - a));
+    }
+    sorted(key, P.ordF);
+  }
+  {  // backward: rows descending; row i continues the chain of row i + 1 when i + 1 is its first upper column
+    std::vector<int32_t> cuts(1, N);  // descending boundaries
+    for (int32_t i = N - 2; i >= 0; i--) {
+      const bool cont = iU[i + 1] > iU[i] && jU[iU[i]] == i + 2;  // 1-based id of row i + 1
+      if (!cont || cuts.back() - (i + 1) >= maxlen) cuts.push_back(i + 1);
+    }
+    cuts.push_back(0);
+    P.startB.assign(cuts.rbegin(), cuts.rend());  // ascending starts, unit u = rows [startB[u], startB[u + 1])
+    const int32_t nu = (int32_t)P.startB.size() - 1;
+    std::vector<int64_t> key((size_t)nu);
+    for (int32_t u = nu - 1; u >= 0; u--) {
+      const int32_t a = P.startB[u], b = P.startB[u + 1];
+      int64_t start = 0, kdep = -1;
+      for (int32_t i = b - 1; i >= a; i--) {
+        unit_of[i] = u;
+        for (int32_t j = iU[i]; j < iU[i + 1]; j++) {
+          const int32_t cidx = jU[j] - 1;
+          if (cidx >= N || cidx < b) continue;
+          start = std::max(start, done[cidx] + hop - (b - 1 - i));
+          kdep = std::max(kdep, key[unit_of[cidx]]);
+        }
+      }
+      start = std::max(start, kdep + 1);
+      key[u] = start;
+      for (int32_t i = b - 1; i >= a; i--) done[i] = start + (b - 1 - i) + 1;
+      P.spanB = std::max(P.spanB, start + (b - a));
+    }
+    sorted(key, P.ordB);
+  }
+}
+
+static int ilu_setup_chain(fx_context *c) {
+  SsorDev &S = c->ssor;
+  const int32_t N = c->A.N;
+  const int32_t *iL = c->h_indexL.data(), *jL = c->h_itemL.data(), *iU = c->h_indexU.data(), *jU = c->h_itemU.data();
+  S.chain = false;
+  if (c->df_mode != 3 || N < 1) return 0;
+  for (int32_t i = 0; i < N; i++)
+    if (iL[i + 1] - iL[i] > FX_CH_MAXB || iU[i + 1] - iU[i] > FX_CH_MAXB) return 0;  // the lane mapping holds 16 blocks per row: level sweeps instead
+  ChainPlan P;
+  chain_schedule(N, c->ch_hop, c->ch_maxlen, iL, jL, iU, jU, P);
+  if (getenv("FX_TIMING") && atoi(getenv("FX_TIMING")))
+    fprintf(stderr, "[fx timing] chain sweeps: %zu forward / %zu backward chains, estimated makespan %lld / %lld steps (%d levels)\n",
+            P.ordF.size(), P.ordB.size(), (long long)P.spanF, (long long)P.spanB, S.ncolor);
+  S.ch_nF = (int32_t)P.ordF.size();
+  S.ch_nB = (int32_t)P.ordB.size();
+  const size_t nz = ((size_t)3 * N + 1) / 2 * 2;  // the tag fill writes 16-byte words
+  dev_free(S.ch_ordF); dev_free(S.ch_ordB); dev_free(S.ch_startF); dev_free(S.ch_startB); dev_free(S.ch_zf); dev_free(S.ch_zb);
+  if (dev_alloc(&S.ch_ordF, P.ordF.size()) || dev_alloc(&S.ch_ordB, P.ordB.size()) || dev_alloc(&S.ch_startF, P.startF.size()) ||
+      dev_alloc(&S.ch_startB, P.startB.size()) || dev_alloc(&S.ch_zf, nz) || dev_alloc(&S.ch_zb, nz))
+    return FX_ERROR_RUNTIME;
+  HIP_TRY(hipMemcpy(S.ch_ordF, P.ordF.data(), P.ordF.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(S.ch_ordB, P.ordB.data(), P.ordB.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(S.ch_startF, P.startF.data(), P.startF.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(S.ch_startB, P.startB.data(), P.startB.size() * 4, hipMemcpyHostToDevice));
+  S.chain = true;
   return 0;
 }
 
@@ -1505,7 +1628,7 @@ static int ilu_setup_numeric(fx_context *c, double sigma_diag) {
                      S.alu);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(c->stream));
-  dev_free(S.lu_D); dev_free(S.lu_AL); dev_free(S.lu_AU);  // the sweeps only stream the BELL copies
+  if (!S.chain) { dev_free(S.lu_D); dev_free(S.lu_AL); dev_free(S.lu_AU); }  // the level sweeps only stream the BELL copies; the chain sweeps read the factors where they are
   return 0;
 }
 
@@ -1651,6 +1774,33 @@ static int precond_apply_once(fx_context *c, const double *r, double *z, bool wa
     const bool full = (c->ord.kind == 1);  // Krylov vectors already colour-major: sweep in place on z
     const int32_t *sn = full ? (const int32_t *)nullptr : S.slot_node;
     double *zsweep = full ? z : S.zs, *znat = full ? (double *)nullptr : z;
+    if (c->precond_kind == 10 && S.chain) {
+      // chain sweeps: one persistent launch, natural numbering throughout (r and z are the caller's vectors)
+      const int32_t N0 = c->A.N;
+      const size_t n16 = ((size_t)3 * N0 + 1) / 2;
+      hipLaunchKernelGGL(k_df_fill, dim3(grid_for((int64_t)n16, 256, 2048)), dim3(256), 0, c->stream, (int64_t)n16, (fx_u4 *)S.ch_zf,
+                         (fx_u4 *)S.ch_zb);
+      if (want_dot && S.ch_nB > c->max_partials) want_dot = false;
+      int grid = c->ch_grid > 0 ? c->ch_grid : c->ch_grid_auto;
+      grid = std::max(1, std::min(grid, (int)std::max(S.ch_nF, S.ch_nB)));
+#define CH_LAUNCH(W)                                                                                                               \
+  hipLaunchKernelGGL(k_tri_chain<W>, dim3(grid), dim3(256), 0, c->stream, N0, S.ch_nF, S.ch_startF, S.ch_ordF, S.ch_nB, S.ch_startB, \
+                     S.ch_ordB, c->A.indexL, c->A.itemL, S.lu_AL, c->A.indexU, c->A.itemU, S.lu_AU, S.lu_D, r, S.ch_zf, S.ch_zb, z,  \
+                     want_dot ? c->partials : (double *)nullptr, gate_status(c), c->df_err, c->ch_ahead)
+      if (c->ch_w <= 4) CH_LAUNCH(4);
+      else if (c->ch_w <= 6) CH_LAUNCH(6);
+      else CH_LAUNCH(8);
+#undef CH_LAUNCH
+      if (getenv("FX_CH_PROFILE")) {  // clocks of workgroup 0 (100 MHz constant clock), accumulated over the launches so far
+        unsigned long long h[8];
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_chain_dbg), sizeof h));
+        fprintf(stderr, "[fx chain] wg0: set-up %llu, wait ready %llu, compute %llu ticks over %llu rows; operand wave: wait %llu, loop %llu\n", h[0], h[1], h[2], h[3], h[4], h[5]);
+      }
+      HIP_TRY(hipGetLastError());
+      *nparts = want_dot ? S.ch_nB : 0;
+      return 0;
+    }
     if ((c->precond_kind == 10 && c->df_mode >= 1) || (c->precond_kind == 1 && c->df_mode >= 2)) {
       // one persistent launch: forward values in S.zs, backward values in z itself (colour-major Krylov vectors) or in
       // S.zb (+ z in the caller's numbering); both start as the sentinel pattern (0xFF bytes)
@@ -2563,7 +2713,7 @@ extern "C" int fx_get_stats(fx_context *c, int64_t out[16]) {
   out[8] = c->ssor.L.npairs; out[9] = c->ssor.L.nblocks; out[10] = c->ssor.U.npairs; out[11] = c->ssor.U.nblocks;
   out[12] = c->ssor.L.nslices;
   out[13] = c->M.n_wg_interior; out[14] = c->M.n_wg_boundary;  // SpMV workgroups overlapped with / ordered after the halo exchange
-  out[15] = c->eis_active ? 1 : 0;                              // the last Krylov loop ran in Eisenstat's form
+  out[15] = (c->eis_active ? 1 : 0) | (c->ssor.chain ? 2 : 0);   // bit 0: the last Krylov loop ran in Eisenstat's form; bit 1: the ILU(0) sweeps are chain sweeps
   return 0;
 }
 

@@ -97,6 +97,12 @@ struct SsorDev {
   double *zs = nullptr;              // private sweep vector, 3*nslots, colour-major
   double *zb = nullptr;              // dataflow sweeps: the backward sweep's vector (zs holds the forward one), 3*nslots
   double *lu_D = nullptr, *lu_AL = nullptr, *lu_AU = nullptr;  // ILU(0): factor values in the reference CSR layout
+  // ILU(0) chain sweeps (FX_DATAFLOW=3, k_tri_chain): chains of consecutive natural rows, two visiting orders, natural-order sweep vectors
+  bool chain = false;
+  int32_t ch_nF = 0, ch_nB = 0;                                  // chains (units) of the forward / backward sweep
+  int32_t *ch_startF = nullptr, *ch_startB = nullptr;            // unit u covers rows [start[u], start[u + 1])
+  int32_t *ch_ordF = nullptr, *ch_ordB = nullptr;                // visiting orders (unit ids)
+  double *ch_zf = nullptr, *ch_zb = nullptr;
   std::vector<int32_t> slot_start;   // ILU(0): first slot of each level (ncolor+1)
   int32_t max_row_blocks = 0;        // ILU(0): largest number of off-diagonal blocks in a row (<= 32: lane-per-block factorisation)
   std::vector<int32_t> perm;         // new -> old (1-based), as the reference's perm(:)
@@ -261,6 +267,12 @@ struct fx_context {
   // candidate allocations are filled and timed (3 SpMV launches each), the fastest is kept, the others are released.
   // Large systems only (>= tune_min_slices), once per symbolic build, bounded by free device memory.  FX_TUNE_PLACEMENT=0 off.
   bool layout_device = true;        // BELL source maps built by k_bell_count / k_bell_map (FX_LAYOUT_DEVICE=0: host threads)
+  int32_t ch_hop = 12;              // chain sweeps: memory hand-off priced in row steps by the set-up's start-time estimate (FX_CH_HOP)
+  int32_t ch_maxlen = 512;          // chain sweeps: longest chain handled as one unit (FX_CH_MAXLEN)
+  int32_t ch_w = 8;                 // chain sweeps: rows between the issue of a row's loads and its step (4, 6 or 8; FX_CH_W)
+  int32_t ch_ahead = 10;            // chain sweeps: a segment starts when the row this many steps in has its outside operands (FX_CH_AHEAD, 0: at once)
+  int32_t ch_grid_auto = 256;       // n_cu x resident workgroups of k_tri_chain per CU
+  int32_t ch_grid = 0;              // chain sweeps: workgroups (0: as many as are co-resident, FX_CH_GRID)
   int32_t mc_batch = 32;            // rounds of the device multicolouring between two looks at the queue length by the host (FX_MC_BATCH)
   int32_t mc_device_min = 100000;   // block rows from which the multicolouring of the SSOR set-up runs on the device (FX_MC_DEVICE_MIN)
   double tune_budget_s = 0.2;       // wall time the placement searches of one context may spend on extra candidates (FX_TUNE_BUDGET_MS)

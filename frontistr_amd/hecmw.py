@@ -249,7 +249,10 @@ class SolverContext:
         _chk(lib().fx_get_stats(self.h, out))
         keys = ("N", "NP", "NPL", "NPU", "M_pairs", "M_blocks", "M_slices", "ncolor", "L_pairs", "L_blocks",
                 "U_pairs", "U_blocks", "ssor_slices", "wg_interior", "wg_boundary", "eisenstat")
-        return {k: int(out[i]) for i, k in enumerate(keys)}
+        st = {k: int(out[i]) for i, k in enumerate(keys)}
+        st["chain_sweeps"] = (st["eisenstat"] >> 1) & 1
+        st["eisenstat"] &= 1
+        return st
 
     def krylov_begin(self, hecMAT):
         _chk(lib().fx_krylov_begin(self.h, _ptr(hecMAT.Iarray), _ptr(hecMAT.Rarray)))

@@ -140,8 +140,8 @@ int fx_nn_matvec_resident(fx_context *ctx, int nrepeat, float *ms_per_call, int6
 int fx_precond_apply_resident(fx_context *ctx, int nrepeat, float *ms_per_call); /* z = M^-1 b, timed */
 int fx_precond_apply_host(fx_context *ctx, const double *r, double *z);   /* z = M^-1 r, 3*NP doubles */
 /* out[0..14]: N NP NPL NPU | M pairs, blocks, slices | ncolor | L pairs, blocks | U pairs, blocks | slices |
- * SpMV workgroups overlapped with the halo exchange (interior), ordered after it (boundary) | [15] 1 if the last Krylov
- * loop ran in Eisenstat's form (FX_EISENSTAT=1) */
+ * SpMV workgroups overlapped with the halo exchange (interior), ordered after it (boundary) | [15] bit 0: the last Krylov
+ * loop ran in Eisenstat's form (FX_EISENSTAT=1); bit 1: the ILU(0) sweeps are chain sweeps (FX_DATAFLOW=3) */
 int fx_get_stats(fx_context *ctx, int64_t out[16]);
 /* measured read-streaming rate (GB/s) of this device over the resident matrix values: the on-box
  * ceiling reported beside the 8 TB/s vendor peak */

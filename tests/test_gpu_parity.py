@@ -728,6 +728,54 @@ def test_dataflow_sweeps_equal_launch_per_level_sweeps_bitwise(hip, deck, pc, mo
     assert relerr(ref[2], ref[4]) < 1e-13 and relerr(ref[8], ref[4]) < 1e-13
 
 
+@pytest.mark.parametrize("deck", DECKS + ["cube20"])
+def test_chain_sweeps_equal_level_sweeps(hip, oracle, deck, monkeypatch):
+    """k_tri_chain (FX_DATAFLOW=3, opt-in: a workgroup walks a chain of consecutive rows in the reference's sequential order -- one
+    wave substitutes, two prepare operands ahead of it, one publishes; dependencies inside the chain through registers / LDS,
+    the others through sentinel-tagged memory; chains dealt in the order of the set-up's start-time estimate) against the
+    launch-per-level sweeps on the same ILU(0) factors: z = M^-1 r equal to rounding (the sum over a row's blocks is a
+    butterfly instead of the sequential loop), repeatable bit for bit, with one workgroup, with a few and with as many as fit,
+    chains cut short and chunked, several pipeline depths, with and without the start-up probe."""
+    if deck == "cube20":
+        from frontistr_amd.mesh import CubeMesh
+        mesh = CubeMesh(20, skew=0.03)
+        A = oracle.assemble(1, mesh.coord, mesh.conn, 210000.0, 0.3, bc=mesh.dirichlet(), load=mesh.load())
+    else:
+        A = golden_matrix(load_golden(deck))
+    r = np.cos(0.11 * np.arange(3 * A.NP) + 0.3)
+    keys = ("FX_DATAFLOW", "FX_CH_GRID", "FX_CH_HOP", "FX_CH_MAXLEN", "FX_CH_W", "FX_CH_AHEAD")
+
+    def apply(env):
+        for k in keys:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = to_hecmat(hip, A)
+        m.Iarray[2] = 10
+        ctx = hip.SolverContext()
+        ctx.upload(m)
+        ctx.precond_setup(m)
+        z = ctx.precond_apply(r)
+        ctx.precond_apply(np.sin(1.7 * r) + 0.5)
+        z2 = ctx.precond_apply(r)
+        assert ctx.stats()["chain_sweeps"] == (1 if env.get("FX_DATAFLOW") == "3" else 0)   # rows of up to 16 blocks: all decks here
+        ctx.close()
+        assert np.array_equal(z, z2)
+        return z[:3 * A.N]
+
+    lev = apply(dict(FX_DATAFLOW="0"))
+    assert np.all(np.isfinite(lev))
+    first = {}
+    for grid, hop, extra in (("1", "12", {}), ("3", "0", dict(FX_CH_MAXLEN="7", FX_CH_W="4")), ("7", "40", dict(FX_CH_MAXLEN="100", FX_CH_W="6")),
+                             ("2", "5", dict(FX_CH_MAXLEN="7")), ("0", "12", dict(FX_CH_AHEAD="0")), ("0", "12", {})):
+        ch = apply(dict(FX_DATAFLOW="3", FX_CH_GRID=grid, FX_CH_HOP=hop, **extra))
+        assert relerr(ch, lev) < 1e-12, (grid, hop, extra)
+        # who waits for whom and how deep the pipeline is never changes an operand; where a chain is cut does change how the
+        # block on the previous row enters the sum (registers of the chain wave, or the butterfly): rounding
+        ref = first.setdefault(extra.get("FX_CH_MAXLEN", ""), ch)
+        assert np.array_equal(ch, ref), (grid, hop, extra)
+
+
 @pytest.mark.parametrize("k", [0, 1, 3, 4, 5, 7, 8])
 def test_divergence_retries_against_reference_golden(hip, oracle, k):
     """The retry loop of hecmw_solve_iterative on the GPU against real reference runs (tests/golden/retry.npz): same outcome
