@@ -16,7 +16,9 @@ timeout -k 10 300 python scripts/bench_nonlinear.py 149 1 1 3 2>/dev/null | tail
 timeout -k 10 300 python scripts/bench_nonlinear.py 149 2 10 3 2>/dev/null | tail -1 > $OUT/nonlinear_newton_10m_bicgstab_ilu0.json && echo "nl ilu ok" && \
 timeout -k 10 200 python scripts/bench_assembly.py 149 > $OUT/assembly_10m.json 2>/dev/null && echo "asm ok" && \
 timeout -k 10 300 python scripts/bench_nn.py 1 150 2>/dev/null | tail -1 > $OUT/nn_ndof1_3p4m.json && \
-timeout -k 10 300 python scripts/bench_nn.py 6 70 2>/dev/null | tail -1 > $OUT/nn_ndof6_2m.json && echo "nn ok" && \
+timeout -k 10 300 python scripts/bench_nn.py 6 70 2>/dev/null | tail -1 > $OUT/nn_ndof6_2m.json && \
+timeout -k 10 300 python scripts/bench_nn.py 2 120 2>/dev/null | tail -1 > $OUT/nn_ndof2_3p5m.json && \
+timeout -k 10 300 python scripts/bench_nn.py 5 70 2>/dev/null | tail -1 > $OUT/nn_ndof5_1p7m.json && echo "nn ok" && \
 timeout -k 10 1100 python bench.py --steps 20 --warmup 5 --cpu-full > $OUT/bench_10m_cg_ssor_cpu_full.json 2> $OUT/bench_cpu_full.err && echo "cpu-full ok"
 python3 - <<PY
 import json, glob, os
