@@ -110,6 +110,44 @@ __global__ void k_scatter_map(int32_t n_elem, const int32_t *__restrict__ conn, 
   pos[t] = k;
 }
 
+// Global derivatives of node b's shape function at a Gauss point from the stored inverse Jacobian: the expression of
+// hex8_global_deriv for one node (hex8n.f90:24-53, element.f90:693-744).
+__device__ __forceinline__ void hex8_node_deriv(int b, double xi, double et, double ze, const double *inv, double *g) {
+  const double sx = ((b & 3) == 1 || (b & 3) == 2) ? 1.0 : -1.0, sy = (b & 2) ? 1.0 : -1.0, sz = (b & 4) ? 1.0 : -1.0;
+  const double fx = 1.0 + sx * xi, fy = 1.0 + sy * et, fz = 1.0 + sz * ze;
+  const double d0 = sx * 0.125 * fy * fz, d1 = sy * 0.125 * fx * fz, d2 = sz * 0.125 * fx * fy;
+#pragma unroll
+  for (int j = 0; j < 3; j++) g[j] = d0 * inv[j] + d1 * inv[3 + j] + d2 * inv[6 + j];
+}
+// K += B_a^T D B_b * wg for one Gauss point (static_LIB_3d.f90:138-176; D of calElasticMatrix, ElasticLinear.f90:43-55)
+__device__ __forceinline__ void btdb_accumulate(const double (&Ba)[6][3], const double (&Bb)[6][3], double D11, double D12, double D44,
+                                                double wg, double *K) {
+  double DB[6][3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    DB[0][j] = D11 * Bb[0][j] + D12 * Bb[1][j] + D12 * Bb[2][j];
+    DB[1][j] = D12 * Bb[0][j] + D11 * Bb[1][j] + D12 * Bb[2][j];
+    DB[2][j] = D12 * Bb[0][j] + D12 * Bb[1][j] + D11 * Bb[2][j];
+    DB[3][j] = D44 * Bb[3][j]; DB[4][j] = D44 * Bb[4][j]; DB[5][j] = D44 * Bb[5][j];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      double s = 0.0;
+#pragma unroll
+      for (int q = 0; q < 6; q++) s += Ba[q][i] * DB[q][j];
+      K[3 * i + j] += s * wg;
+    }
+}
+
+// Round 2: column strips.  Lane a still owns the 3-row block of node a, but it builds ONE 3x3 block at a time (9 accumulators
+// over the 8 Gauss points) and scatters it before the next -- round 1 kept all 8 (11 for the IC element) column blocks live:
+// 310-512 VGPRs plus scratch, one wave per SIMD.  What the strips share is small: lane g computes the Jacobian of Gauss point g
+// once and leaves its inverse and determinant in LDS (80 doubles per element); a node's global derivatives are three FMAs away
+// from that.  The IC element goes in two passes: the mode columns first (27 accumulators, kept for the condensation), the 9x9
+// mode block factored in LDS as before, then the node columns, each condensed and scattered as it is finished.  Every entry
+// is accumulated over the Gauss points in the same order with the same expressions as before: bit-identical element matrices.
 template <int ELEMOPT>
 __global__ __launch_bounds__(FXA_BS(ELEMOPT)) void k_assemble_c3d8(int32_t n_elem, const double *__restrict__ coord,
                                                              const int32_t *__restrict__ conn, double D11, double D12,
@@ -125,31 +163,25 @@ __global__ __launch_bounds__(FXA_BS(ELEMOPT)) void k_assemble_c3d8(int32_t n_ele
                                                              const int32_t *__restrict__ pos_map) {
   // elem_list != nullptr: positions [e0, n_elem) of elem_list are the elements of ONE colour (no shared nodes), scattered
   // without atomics; nullptr: elements e0..n_elem-1 in their own order with hardware fp64 atomics
-  constexpr int NJ = (ELEMOPT == 1) ? 11 : 8;
-  __shared__ double Ksh[(ELEMOPT == 1) ? FXA_EPB(1) : 1][9][34];
-  __shared__ double Xinv[(ELEMOPT == 1) ? FXA_EPB(1) : 1][9][10];
+  constexpr int EPB = FXA_EPB(ELEMOPT);
+  constexpr bool IC = (ELEMOPT == 1);
+  __shared__ double Jsh[EPB][8][10];                 // per Gauss point: inverse Jacobian (row-major), determinant
+  __shared__ double Ksh[IC ? EPB : 1][9][25];        // IC: mode rows against the node columns
+  __shared__ double Xinv[IC ? EPB : 1][9][10];       // IC: the 9x9 mode block, then its Cholesky factor (1 / L_ii in column 9)
   constexpr int LPE = FXA_LPE(ELEMOPT);
   const int el = threadIdx.x / LPE, a = threadIdx.x % LPE;
-  const int32_t epos = e0 + blockIdx.x * FXA_EPB(ELEMOPT) + el;
-  const bool active = (epos < n_elem) && (a < NJ);
-  const int32_t elem = (elem_list && epos < n_elem) ? elem_list[epos] : epos;
-  double K[NJ][9];
-#pragma unroll
-  for (int b = 0; b < NJ; b++)
-#pragma unroll
-    for (int e = 0; e < 9; e++) K[b][e] = 0.0;
-  // IC: rows 24..32 (the three incompatible modes) against the mode columns; lanes 0..2 own mode row block a.  Their entries
-  // against the node columns are the transposes of what the node lanes hold in K[8..10] (the element matrix is symmetric).
-  double Kmm[(ELEMOPT == 1) ? 3 : 1][9];
-#pragma unroll
-  for (int b = 0; b < ((ELEMOPT == 1) ? 3 : 1); b++)
-#pragma unroll
-    for (int e = 0; e < 9; e++) Kmm[b][e] = 0.0;
-  int32_t nod[8];
+  const int32_t epos = e0 + blockIdx.x * EPB + el;
+  const bool active = epos < n_elem;
+  const int32_t elem = (elem_list && active) ? elem_list[epos] : epos;
+  const double GP = 0.577350269189626;  // quadrature.f90:83-91, unit weights (:221)
   if (active && elem_mat) {  // several sections: (D11, D12, D44) of this element's material (hecMESH%section_ID)
     const int32_t mid = elem_mat[elem] - 1;
     D11 = mat_tab[3 * mid]; D12 = mat_tab[3 * mid + 1]; D44 = mat_tab[3 * mid + 2];
   }
+  int32_t nod[8];
+  double c0[10];  // IC: inverse Jacobian at the element centre times its determinant (3dIC.f90:79-81); B-bar: the centroid's inverse (C3D8.f90:72-73)
+#pragma unroll
+  for (int e = 0; e < 10; e++) c0[e] = 0.0;
   if (active) {
     double ec[8][3];
 #pragma unroll
@@ -159,136 +191,124 @@ __global__ __launch_bounds__(FXA_BS(ELEMOPT)) void k_assemble_c3d8(int32_t n_ele
       for (int d = 0; d < 3; d++) ec[j][d] = coord[(size_t)3 * (nod[j] - 1) + d];
     }
     double det, inv[3][3], gd[11][3];
-    double inv0[3][3], det0 = 0.0, bbar[8][3];
-    if (ELEMOPT == 1) {  // Jacobian at the element centre, scaled by its determinant (3dIC.f90:79-81)
-      hex8_global_deriv(ec, 0.0, 0.0, 0.0, det0, inv0, gd);
-    } else if (ELEMOPT == 2) {  // dilatation at the centroid (C3D8.f90:72-73)
+    if (ELEMOPT == 1 || ELEMOPT == 2) {
       hex8_global_deriv(ec, 0.0, 0.0, 0.0, det, inv, gd);
 #pragma unroll
-      for (int j = 0; j < 8; j++)
+      for (int i = 0; i < 3; i++)
 #pragma unroll
-        for (int d = 0; d < 3; d++) bbar[j][d] = gd[j][d];
+        for (int j = 0; j < 3; j++) c0[3 * i + j] = IC ? inv[i][j] * det : inv[i][j];
     }
-    const double GP = 0.577350269189626;  // quadrature.f90:83-91, unit weights (:221)
-    for (int LX = 0; LX < 8; LX++) {
-      const double xi = (LX & 1) ? GP : -GP, et = (LX & 2) ? GP : -GP, ze = (LX & 4) ? GP : -GP;
-      hex8_global_deriv(ec, xi, et, ze, det, inv, gd);
-      if (ELEMOPT == 1) {  // incompatible-mode derivatives (3dIC.f90:120-122)
+    const double xi = (a & 1) ? GP : -GP, et = (a & 2) ? GP : -GP, ze = (a & 4) ? GP : -GP;
+    hex8_global_deriv(ec, xi, et, ze, det, inv, gd);  // this lane's Gauss point
 #pragma unroll
-        for (int d = 0; d < 3; d++) {
-          gd[8][d] = -2.0 * xi * (inv0[0][d] * det0) / det;
-          gd[9][d] = -2.0 * et * (inv0[1][d] * det0) / det;
-          gd[10][d] = -2.0 * ze * (inv0[2][d] * det0) / det;
-        }
-      }
-      const double wg = det;
-      double Ba[6][3], h[3] = {0.0, 0.0, 0.0};
-      // own row block: B_a
-      {
-        double ga[3] = {0.0, 0.0, 0.0};
+    for (int i = 0; i < 3; i++)
 #pragma unroll
-        for (int b = 0; b < NJ; b++)
-          if (b == a) { ga[0] = gd[b][0]; ga[1] = gd[b][1]; ga[2] = gd[b][2]; }
-        if (ELEMOPT == 2) {
+      for (int j = 0; j < 3; j++) Jsh[el][a][3 * i + j] = inv[i][j];
+    Jsh[el][a][9] = det;
+  }
+  __syncthreads();
+  // B of node b at Gauss point LX (h: the B-bar correction)
+  auto node_B_at = [&](int b, int LX, double (&B)[6][3]) {
+    const double xi = (LX & 1) ? GP : -GP, et = (LX & 2) ? GP : -GP, ze = (LX & 4) ? GP : -GP;
+    double g[3], h[3] = {0.0, 0.0, 0.0};
+    hex8_node_deriv(b, xi, et, ze, Jsh[el][LX], g);
+    if (ELEMOPT == 2) {
+      double bb[3];
+      hex8_node_deriv(b, 0.0, 0.0, 0.0, c0, bb);
+      h[0] = (bb[0] - g[0]) / 3.0; h[1] = (bb[1] - g[1]) / 3.0; h[2] = (bb[2] - g[2]) / 3.0;
+    }
+    node_B(g, h, B);
+  };
+  auto mode_B_at = [&](int m, int LX, double (&B)[6][3]) {  // incompatible-mode derivatives (3dIC.f90:120-122)
+    const double xi = (LX & 1) ? GP : -GP, et = (LX & 2) ? GP : -GP, ze = (LX & 4) ? GP : -GP;
+    const double x = (m == 0) ? xi : ((m == 1) ? et : ze), det = Jsh[el][LX][9];
+    double g[3], h0[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-          for (int b = 0; b < 8; b++)
-            if (b == a) { h[0] = (bbar[b][0] - ga[0]) / 3.0; h[1] = (bbar[b][1] - ga[1]) / 3.0; h[2] = (bbar[b][2] - ga[2]) / 3.0; }
-        }
-        node_B(ga, h, Ba);
-      }
-      double Bm[6][3];
-      if (ELEMOPT == 1) {  // B of this lane's mode (lanes 0..2)
-        double gm[3], h0[3] = {0.0, 0.0, 0.0};
+    for (int d = 0; d < 3; d++) g[d] = -2.0 * x * c0[3 * m + d] / det;
+    node_B(g, h0, B);
+  };
+  double tk[IC ? 3 : 1][9];  // IC: row i of K_a,alpha (K_alpha,alpha)^-1
+  if (IC) {
+    if (active) {
+      {  // node row block a against the three mode columns
+        double Kam[3][9];
 #pragma unroll
-        for (int d = 0; d < 3; d++) gm[d] = (a == 0) ? gd[8][d] : ((a == 1) ? gd[9][d] : gd[10][d]);
-        node_B(gm, h0, Bm);
-      }
+        for (int m = 0; m < 3; m++)
 #pragma unroll
-      for (int b = 0; b < NJ; b++) {
-        double Bb[6][3], hb[3] = {0.0, 0.0, 0.0};
-        if (ELEMOPT == 2) {
-          hb[0] = (bbar[b][0] - gd[b][0]) / 3.0; hb[1] = (bbar[b][1] - gd[b][1]) / 3.0; hb[2] = (bbar[b][2] - gd[b][2]) / 3.0;
-        }
-        node_B(gd[b], hb, Bb);
-        // DB = D * B_b with the isotropic D of calElasticMatrix (ElasticLinear.f90:43-55)
-        double DB[6][3];
+          for (int e = 0; e < 9; e++) Kam[m][e] = 0.0;
+#pragma unroll 1
+        for (int LX = 0; LX < 8; LX++) {
+          const double wg = Jsh[el][LX][9];
+          double Ba[6][3];
+          node_B_at(a, LX, Ba);
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
-          DB[0][j] = D11 * Bb[0][j] + D12 * Bb[1][j] + D12 * Bb[2][j];
-          DB[1][j] = D12 * Bb[0][j] + D11 * Bb[1][j] + D12 * Bb[2][j];
-          DB[2][j] = D12 * Bb[0][j] + D12 * Bb[1][j] + D11 * Bb[2][j];
-          DB[3][j] = D44 * Bb[3][j]; DB[4][j] = D44 * Bb[4][j]; DB[5][j] = D44 * Bb[5][j];
-        }
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-#pragma unroll
-          for (int j = 0; j < 3; j++) {
-            double s = 0.0;
-#pragma unroll
-            for (int q = 0; q < 6; q++) s += Ba[q][i] * DB[q][j];
-            K[b][3 * i + j] += s * wg;
+          for (int m = 0; m < 3; m++) {
+            double Bb[6][3];
+            mode_B_at(m, LX, Bb);
+            btdb_accumulate(Ba, Bb, D11, D12, D44, wg, Kam[m]);
           }
-        if (ELEMOPT == 1 && b >= 8 && a < 3) {
+        }
+        // rows 24..32 against the node columns: the transposes of what the node lanes hold (the element matrix is symmetric)
+#pragma unroll
+        for (int al = 0; al < 3; al++)
 #pragma unroll
           for (int i = 0; i < 3; i++)
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
-              double s = 0.0;
-#pragma unroll
-              for (int q = 0; q < 6; q++) s += Bm[q][i] * DB[q][j];
-              Kmm[(ELEMOPT == 1) ? b - 8 : 0][3 * i + j] += s * wg;
-            }
-        }
+            for (int j = 0; j < 3; j++) Ksh[el][3 * al + i][3 * a + j] = Kam[al][3 * j + i];
       }
-    }
-  }
-  if (ELEMOPT == 1) {
-    // publish rows 24..32 (node columns: transposed from the node lanes; mode columns: lanes 0..2), invert the 9x9 mode
-    // block, condense (3dIC.f90:206-209)
-    if (active) {
+      if (a < 3) {  // lanes 0..2 also own mode row block a against the mode columns
+        double Kmm[3][9];
 #pragma unroll
-      for (int al = 0; al < 3; al++)
+        for (int m = 0; m < 3; m++)
 #pragma unroll
-        for (int i = 0; i < 3; i++)
+          for (int e = 0; e < 9; e++) Kmm[m][e] = 0.0;
+#pragma unroll 1
+        for (int LX = 0; LX < 8; LX++) {
+          const double wg = Jsh[el][LX][9];
+          double Bm[6][3];
+          mode_B_at(a, LX, Bm);
 #pragma unroll
-          for (int j = 0; j < 3; j++) Ksh[el][3 * al + i][3 * a + j] = K[(ELEMOPT == 1) ? 8 + al : 0][3 * j + i];
-      if (a < 3) {
+          for (int m = 0; m < 3; m++) {
+            double Bb[6][3];
+            mode_B_at(m, LX, Bb);
+            btdb_accumulate(Bm, Bb, D11, D12, D44, wg, Kmm[m]);
+          }
+        }
 #pragma unroll
         for (int be = 0; be < 3; be++)
 #pragma unroll
           for (int i = 0; i < 3; i++)
 #pragma unroll
-            for (int j = 0; j < 3; j++) Ksh[el][3 * a + i][24 + 3 * be + j] = Kmm[be][3 * i + j];
+            for (int j = 0; j < 3; j++) Xinv[el][3 * a + i][3 * be + j] = Kmm[be][3 * i + j];
       }
     }
     __syncthreads();
     if (active && a == 0) {
-      // Cholesky factor of the 9x9 mode block (symmetric positive definite for a valid element) instead of the explicit
-      // inverse of calInverse (utilities.f90:247-316): K_cond = K - K_a,alpha (K_alpha,alpha)^-1 K_alpha,b is the same
-      // to rounding, the serial part shrinks from ~1500 to ~250 flops.  L in Xinv[el][i][j] (j <= i), 1/L_ii in column 9.
+      // Cholesky factor of the 9x9 mode block (symmetric positive definite for a valid element), in place, instead of the
+      // explicit inverse of calInverse (utilities.f90:247-316): K_cond = K - K_a,alpha (K_alpha,alpha)^-1 K_alpha,b is the
+      // same to rounding, the serial part shrinks from ~1500 to ~250 flops.  L in Xinv[el][i][j] (j <= i), 1/L_ii in column 9.
       double (*L)[10] = Xinv[el];
       for (int k = 0; k < 9; k++) {
-        double d = Ksh[el][k][24 + k];
+        double d = L[k][k];
         for (int j = 0; j < k; j++) d -= L[k][j] * L[k][j];
         if (!(d > 1.0e-35)) { if (err) atomicExch(err, 1); d = 1.0; }  // the reference's PIVOT ERROR threshold
         const double lkk = sqrt(d), inv = 1.0 / lkk;
         L[k][k] = lkk;
         L[k][9] = inv;
         for (int i = k + 1; i < 9; i++) {
-          double v = Ksh[el][i][24 + k];
+          double v = L[i][k];
           for (int j = 0; j < k; j++) v -= L[i][j] * L[k][j];
           L[i][k] = v * inv;
         }
       }
     }
     __syncthreads();
-    if (active && a < 8) {
-      double tk[3][9];  // row i of K_a,alpha (K_alpha,alpha)^-1: two triangular solves with the factor
+    if (active) {
 #pragma unroll
       for (int i = 0; i < 3; i++) {
         double y[9];
 #pragma unroll
-        for (int q = 0; q < 9; q++) y[q] = K[(ELEMOPT == 1) ? 8 + q / 3 : 0][3 * i + (q % 3)];
+        for (int q = 0; q < 9; q++) y[q] = Ksh[el][q][3 * a + i];  // K_a,alpha row i (= the published transpose)
 #pragma unroll
         for (int q = 0; q < 9; q++) {  // L y' = y
 #pragma unroll
@@ -304,37 +324,40 @@ __global__ __launch_bounds__(FXA_BS(ELEMOPT)) void k_assemble_c3d8(int32_t n_ele
 #pragma unroll
         for (int q = 0; q < 9; q++) tk[i][q] = y[q];
       }
-#pragma unroll
-      for (int b = 0; b < 8; b++)
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-#pragma unroll
-          for (int j = 0; j < 3; j++) {
-            double s = 0.0;
-#pragma unroll
-            for (int q = 0; q < 9; q++) s += tk[i][q] * Ksh[el][q][3 * b + j];
-            K[b][3 * i + j] -= s;
-          }
     }
   }
-  if (!active || a >= 8) return;
-  if (Kout) {
-#pragma unroll
-    for (int b = 0; b < 8; b++)
+  if (!active) return;
+  const int32_t inod = conn[(size_t)8 * elem + a];
+#pragma unroll 1
+  for (int b = 0; b < 8; b++) {
+    double K[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+    for (int LX = 0; LX < 8; LX++) {
+      double Ba[6][3], Bb[6][3];
+      node_B_at(a, LX, Ba);
+      node_B_at(b, LX, Bb);
+      btdb_accumulate(Ba, Bb, D11, D12, D44, Jsh[el][LX][9], K);
+    }
+    if (IC) {  // condense (3dIC.f90:206-209)
 #pragma unroll
       for (int i = 0; i < 3; i++)
 #pragma unroll
-        for (int j = 0; j < 3; j++) Kout[(size_t)elem * 576 + (size_t)(3 * a + i) * 24 + 3 * b + j] = K[b][3 * i + j];
-    return;
-  }
-  // scatter (hecmw_mat_add_node, hecmw_mat_ass.f90:72-134)
-  int32_t inod = 0;
+        for (int j = 0; j < 3; j++) {
+          double s = 0.0;
 #pragma unroll
-  for (int b = 0; b < 8; b++)
-    if (b == a) inod = nod[b];
+          for (int q = 0; q < 9; q++) s += tk[i][q] * Ksh[el][q][3 * b + j];
+          K[3 * i + j] -= s;
+        }
+    }
+    if (Kout) {
 #pragma unroll
-  for (int b = 0; b < 8; b++) {
-    const int32_t jnod = nod[b];
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) Kout[(size_t)elem * 576 + (size_t)(3 * a + i) * 24 + 3 * b + j] = K[3 * i + j];
+      continue;
+    }
+    // scatter (hecmw_mat_add_node, hecmw_mat_ass.f90:72-134)
+    const int32_t jnod = conn[(size_t)8 * elem + b];
     double *dst;
     if (inod == jnod) dst = D + (size_t)9 * (inod - 1);
     else if (jnod < inod) {
@@ -348,10 +371,10 @@ __global__ __launch_bounds__(FXA_BS(ELEMOPT)) void k_assemble_c3d8(int32_t n_ele
     }
     if (elem_list) {
 #pragma unroll
-      for (int e = 0; e < 9; e++) dst[e] += K[b][e];
+      for (int e = 0; e < 9; e++) dst[e] += K[e];
     } else {
 #pragma unroll
-      for (int e = 0; e < 9; e++) unsafeAtomicAdd(dst + e, K[b][e]);
+      for (int e = 0; e < 9; e++) unsafeAtomicAdd(dst + e, K[e]);
     }
   }
 }
