@@ -259,6 +259,7 @@ extern "C" int fx_create(int device, fx_context **out) {
   if (const char *e = getenv("FX_MC_DEVICE_MIN")) c->mc_device_min = atoi(e);
   if (const char *e = getenv("FX_BFS_BATCH")) c->bfs_batch = std::max(1, atoi(e));
   if (const char *e = getenv("FX_TUNE_BUDGET_MS")) c->tune_budget_s = 1e-3 * atof(e);
+  if (const char *e = getenv("FX_VAL2_POW2")) c->val2_pow2 = atoi(e) != 0;
   if (const char *e = getenv("FX_MC_BATCH")) c->mc_batch = std::max(1, atoi(e));
   if (const char *e = getenv("FX_LAYOUT_DEVICE")) c->layout_device = atoi(e) != 0;
   if (const char *e = getenv("FX_PIPE_SPMV")) c->pipe_spmv = atoi(e) != 0;
@@ -374,6 +375,28 @@ extern "C" int fx_device_synchronize(fx_context *c) {
 // ---------------------------------------------------------------------------
 struct BellEntry { int32_t src, col; };
 
+// Bytes to ask hipMalloc for when a BELL value array needs `bytes`.  A multi-gigabyte request is served from several
+// power-of-two blocks of the driver's VRAM allocator (6.5 GB = 4 + 2 + 0.5), and where those blocks lie decides the speed class
+// of the SpMV (fx_context::tune_tries).  Measured inside one 15 GB allocation: the array runs at 1.04 ms while it lies in the
+// leading 8 GB block and slows to 1.18 ms as it moves out of it.  Rounding the request up to a power of two asks for ONE block.
+static size_t val2_alloc_bytes(const fx_context *c, size_t bytes) {
+  if (!c->val2_pow2 || bytes < ((size_t)1 << 30)) return bytes;
+  size_t p = (size_t)1 << 30;
+  while (p < bytes) p <<= 1;
+  return p;
+}
+static int val2_alloc(const fx_context *c, char **base, size_t bytes) {  // the rounded request first, the exact one when memory does not allow it
+  *base = nullptr;
+  const size_t want = val2_alloc_bytes(c, bytes);
+  if (want > bytes) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > want + ((size_t)8 << 30) && hipMalloc((void **)base, want) == hipSuccess) return 0;
+    (void)hipGetLastError();
+    *base = nullptr;
+  }
+  return dev_alloc(base, bytes);
+}
+
 template <class CountFn, class FillFn>
 static int bell_build2(fx_context *c, Bell &b, int32_t nslots, const std::vector<int32_t> *slot_row,
                        CountFn count, FillFn fill) {
@@ -434,7 +457,7 @@ static int bell_build2(fx_context *c, Bell &b, int32_t nslots, const std::vector
     size_t pad = 0;
     if (const char *e = getenv("FX_VAL2_PAD")) pad = (size_t)atoll(e);
     char *base = nullptr;
-    if (dev_alloc(&base, (size_t)tot * 576 * 8 + pad)) return FX_ERROR_RUNTIME;
+    if (val2_alloc(c, &base, (size_t)tot * 576 * 8 + pad)) return FX_ERROR_RUNTIME;
     b.val2_base = base;
     b.val2 = (double *)(base + pad);
   }
@@ -487,7 +510,7 @@ static int bell_build_device(fx_context *c, Bell &b, int variant, int32_t nslots
     size_t pad = 0;
     if (const char *e = getenv("FX_VAL2_PAD")) pad = (size_t)atoll(e);
     char *base = nullptr;
-    if (dev_alloc(&base, tot * 576 * 8 + pad)) return FX_ERROR_RUNTIME;
+    if (val2_alloc(c, &base, tot * 576 * 8 + pad)) return FX_ERROR_RUNTIME;
     b.val2_base = base;
     b.val2 = (double *)(base + pad);
   }
@@ -647,7 +670,7 @@ static int tune_placement(fx_context *c, Bell &B, const char *what, double strea
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + (bytes >> 1) + ((size_t)4 << 30)) break;  // keep headroom
     char *base = nullptr;
     const double w0 = now_s();
-    if (hipMalloc((void **)&base, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+    if (hipMalloc((void **)&base, val2_alloc_bytes(c, bytes)) != hipSuccess) { (void)hipGetLastError(); break; }
     const double w1 = now_s();
     B.val2_base = base;
     B.val2 = (double *)base;
@@ -663,6 +686,26 @@ static int tune_placement(fx_context *c, Bell &B, const char *what, double strea
     B.val2_base = cand[0];
     B.val2 = (double *)cand[0];
     return FX_ERROR_RUNTIME;
+  }
+  if (const char *ea = getenv("FX_PLACEMENT_ARENA_MB")) {  // experiment: does the OFFSET inside one large allocation change the speed class?
+    const size_t arena = (size_t)atoll(ea) << 20, step = (size_t)(getenv("FX_PLACEMENT_STEP_MB") ? atoll(getenv("FX_PLACEMENT_STEP_MB")) : 256) << 20;
+    char *big = nullptr;
+    void *keep_base = B.val2_base;
+    double *keep = B.val2;
+    if (hipMalloc((void **)&big, bytes + arena) == hipSuccess) {
+      fprintf(stderr, "[fx placement] %s offsets inside one %.1f GB allocation:", what, (bytes + arena) / 1e9);
+      for (size_t off = 0; off <= arena && !err; off += step) {
+        B.val2 = (double *)(big + off);
+        float ms = 0.f;
+        err = fill();
+        if (!err) err = time_ms(&ms);
+        fprintf(stderr, " %zuM:%.3f", off >> 20, ms);
+      }
+      fprintf(stderr, "\n");
+      B.val2 = keep; B.val2_base = keep_base;
+      (void)hipFree(big);
+      if (err) return FX_ERROR_RUNTIME;
+    } else (void)hipGetLastError();
   }
   const int best = (int)(std::min_element(t.begin(), t.end()) - t.begin());
   if (getenv("FX_TIMING") && atoi(getenv("FX_TIMING"))) {

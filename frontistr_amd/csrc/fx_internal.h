@@ -275,6 +275,7 @@ struct fx_context {
   int32_t ch_grid = 0;              // chain sweeps: workgroups (0: as many as are co-resident, FX_CH_GRID)
   int32_t mc_batch = 32;            // rounds of the device multicolouring between two looks at the queue length by the host (FX_MC_BATCH)
   int32_t mc_device_min = 100000;   // block rows from which the multicolouring of the SSOR set-up runs on the device (FX_MC_DEVICE_MIN)
+  bool val2_pow2 = true;            // BELL value arrays of a gigabyte or more: ask hipMalloc for the next power of two -- ONE block of the driver's allocator, the fast placement class (FX_VAL2_POW2=0: the exact size)
   double tune_budget_s = 0.5;       // wall time the placement searches of one context may spend on extra candidates (FX_TUNE_BUDGET_MS): 2-3 candidates when hipMalloc has to clear fresh VRAM (190 ms per 6.5 GB), all 20 when it recycles (10 ms each)
   double tune_spent_s = 0.0;
   int32_t bfs_batch = 16;           // levels of the device level ordering between two looks at the level state by the host (FX_BFS_BATCH)
