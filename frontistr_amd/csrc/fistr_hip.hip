@@ -1834,12 +1834,6 @@ static int precond_apply_once(fx_context *c, const double *r, double *z, bool wa
       else if (c->ch_w <= 6) CH_LAUNCH(6);
       else CH_LAUNCH(8);
 #undef CH_LAUNCH
-      if (getenv("FX_CH_PROFILE")) {  // clocks of workgroup 0 (100 MHz constant clock), accumulated over the launches so far
-        unsigned long long h[8];
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_chain_dbg), sizeof h));
-        fprintf(stderr, "[fx chain] wg0: set-up %llu, wait ready %llu, compute %llu ticks over %llu rows; operand wave: wait %llu, loop %llu\n", h[0], h[1], h[2], h[3], h[4], h[5]);
-      }
       HIP_TRY(hipGetLastError());
       *nparts = want_dot ? S.ch_nB : 0;
       return 0;

@@ -1055,10 +1055,6 @@ __device__ __forceinline__ bool chain_wait(ChainStage &S, int i, int a, int len,
 //               y'_i and the link block in LDS, raises ready[i]
 //   wave 3      PUBLISHER: writes finished rows out with the write-through stores of the hand-off (loads and stores of one
 //               wave retire in issue order; behind a write-through store every later load would count as outstanding)
-#ifndef FX_CH_PROFILE_BUILD
-#define FX_CH_PROFILE_BUILD 0  // 1: the clocks below are taken (perturbs what it measures: s_memrealtime is a memory instruction)
-#endif
-__device__ unsigned long long g_chain_dbg[8];  // FX_CH_PROFILE: clocks spent by workgroup 0's chain wave [0] set-up, [1] waiting for ready, [2] computing; [3] rows; operand wave 1: [4] chain_wait, [5] total loop
 struct ChainLds {
   int32_t ip[FX_CH_SEG + 1];
   fx_i2 tab[FX_CH_SEG * FX_CH_MAXB];   // [row][b] = {index of the block in the factor array (always a valid one), column or -1}
@@ -1086,8 +1082,6 @@ __device__ __forceinline__ void chain_segment(int a, int len, int ulo, int uhi, 
   // barriers -- the LDS operations of a wave execute in issue order, so that is all the ordering the hardware needs
   double *xs = L.xs, *yp = L.yp, *al = L.al, *fs = L.fs;
 #define CH_ORDER() asm volatile("" ::: "memory")
-  const bool prof = FX_CH_PROFILE_BUILD && blockIdx.x == 0 && lane == 0;
-  const unsigned long long c_begin = wall_clock64();
   // the chunk's row pointers, column ids, diagonal factors and right-hand side: coalesced sweeps into LDS
   for (int t = threadIdx.x; t <= len; t += 256) L.ip[t] = index[a + t];
   if (threadIdx.x < FX_CH_SEG) L.ready[threadIdx.x] = 0;
@@ -1122,10 +1116,8 @@ __device__ __forceinline__ void chain_segment(int a, int len, int ulo, int uhi, 
   auto row_of = [&](int step) { return FWD ? a + step : a + len - 1 - step; };
   if (wave == 0) {
     // ---- the chain ----
-    if (prof) { g_chain_dbg[0] += wall_clock64() - c_begin; g_chain_dbg[3] += len; }
     for (int step = 0; step < len; step++) {
       const int t = row_of(step) - a;
-      const unsigned long long c0 = prof ? wall_clock64() : 0;
       if (!dead) {
         unsigned long long t0 = 0;
         for (unsigned spins = 1; ready[step] == 0; spins++) {  // the operand waves run ahead: normally set long ago
@@ -1141,7 +1133,6 @@ __device__ __forceinline__ void chain_segment(int a, int len, int ulo, int uhi, 
           }
         }
       }
-      const unsigned long long c1 = prof ? wall_clock64() : 0;
       CH_ORDER();
       double y0 = yp[3 * step], y1 = yp[3 * step + 1], y2 = yp[3 * step + 2];
       double A[9], u[9];
@@ -1166,7 +1157,6 @@ __device__ __forceinline__ void chain_segment(int a, int len, int ulo, int uhi, 
       }
       CH_ORDER();
       if (lane == 0) *ndone = step + 1;  // after the row's entries: LDS operations of a wave execute in order
-      if (prof) { g_chain_dbg[1] += c1 - c0; g_chain_dbg[2] += wall_clock64() - c1; }
     }
     __syncthreads();
     return;
@@ -1221,7 +1211,6 @@ __device__ __forceinline__ void chain_segment(int a, int len, int ulo, int uhi, 
 #pragma unroll
     for (int s = 0; s < W; s++) chain_issue<FWD>(st[s], entry(first + 2 * s), row_of(min(first + 2 * s, len - 1)), blocks, zsrc, zf, qq);
   }
-  const unsigned long long c_loop = wall_clock64();
   for (int base = first; base < len; base += 2 * W) {
 #pragma unroll
     for (int s = 0; s < W; s++) {
@@ -1248,9 +1237,7 @@ __device__ __forceinline__ void chain_segment(int a, int len, int ulo, int uhi, 
         const int o = 3 * (S.col - a);
         S.x0 = xs[o]; S.x1 = xs[o + 1]; S.x2 = xs[o + 2];
       }
-      const unsigned long long cw = prof ? wall_clock64() : 0;
       if (live) chain_wait<FWD>(S, i, a, len, zsrc, zf, q, err, dead, 0, valid && !inside && !link);
-      if (prof && wave == 1) g_chain_dbg[4] += wall_clock64() - cw;
       double acc = (valid && !link) ? fma(S.a2, S.x2, fma(S.a1, S.x1, S.a0 * S.x0)) : 0.0;
       acc = row_ror_add<8>(acc);
       acc = row_ror_add<4>(acc);
@@ -1270,7 +1257,6 @@ __device__ __forceinline__ void chain_segment(int a, int len, int ulo, int uhi, 
       chain_issue<FWD>(st[s], enext, row_of(min(step + 2 * W, len - 1)), blocks, zsrc, zf, qq);
     }
   }
-  if (prof && wave == 1) g_chain_dbg[5] += wall_clock64() - c_loop;
   __syncthreads();  // LDS is reused by the next chunk
 #undef CH_ORDER
 }
