@@ -249,6 +249,7 @@ def main():
     t0 = time.time()
     ctx.precond_setup(m)
     t_pre = time.time() - t0
+    t_tune = ctx.tune_seconds()     # of which: placement searches + role timing (candidate allocations; fresh VRAM makes them slow)
     st = ctx.stats()
     N, nb = st["N"], st["M_blocks"]
 
@@ -333,7 +334,9 @@ def main():
                               "frac": prec_bytes / (ms_prec * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "iteration_GBs": (alg + prec_bytes + 480 * N) / (dt / a.steps) / 1e9,
         },
-        "setup_s": {"mat_con": t_con, "assemble_ms": ms_asm, "precond_setup": t_pre},
+        "setup_s": {"mat_con": t_con, "assemble_ms": ms_asm, "precond_setup": t_pre - t_tune, "placement_tuning": t_tune,
+                    "note": "precond_setup = ordering + colouring + layouts + factors; placement_tuning = timing candidate allocations "
+                            "of the value arrays (optional, FX_TUNE_PLACEMENT=0 off; ~0.2 s per candidate when the driver clears fresh VRAM)"},
         "resid_after_steps": resid,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

@@ -277,7 +277,10 @@ struct fx_context {
   int32_t mc_device_min = 100000;   // block rows from which the multicolouring of the SSOR set-up runs on the device (FX_MC_DEVICE_MIN)
   bool val2_pow2 = true;            // BELL value arrays of a gigabyte or more: ask hipMalloc for the next power of two -- ONE block of the driver's allocator, the fast placement class (FX_VAL2_POW2=0: the exact size)
   double tune_budget_s = 0.5;       // wall time the placement searches of one context may spend on extra candidates (FX_TUNE_BUDGET_MS): 2-3 candidates when hipMalloc has to clear fresh VRAM (190 ms per 6.5 GB), all 20 when it recycles (10 ms each)
-  double tune_spent_s = 0.0;
+  double tune_spent_s = 0.0;        // wall time of all tuning steps of this context's set-ups (placement searches, work-vector roles): fx_tune_seconds
+  double tune_cand_s = 0.0;         // of which: allocating, filling and timing extra candidates (what the budget caps)
+  std::vector<void *> held;         // losing candidates of the placement searches, released with the context
+  size_t held_bytes = 0, hold_max_bytes = (size_t)48 << 30;  // FX_TUNE_HOLD_GB
   int32_t bfs_batch = 16;           // levels of the device level ordering between two looks at the level state by the host (FX_BFS_BATCH)
   int32_t bfs_device_min = 100000;  // block rows from which the level ordering of the SSOR set-up runs on the device (FX_BFS_DEVICE_MIN)
   int tune_tries = 20;

@@ -204,6 +204,12 @@ class SolverContext:
     def precond_setup(self, hecMAT):
         _chk(lib().fx_precond_setup(self.h, _ptr(hecMAT.Iarray), _ptr(hecMAT.Rarray)))
 
+    def tune_seconds(self):
+        """Wall time of the measured tuning steps of this context's set-ups so far (placement searches, work-vector roles)."""
+        f = lib().fx_tune_seconds
+        f.restype = C.c_double
+        return float(f(self.h))
+
     def solve_resident(self, hecMAT, want_history=True):
         info = _SolveInfo()
         maxit = int(hecMAT.Iarray[0])

@@ -143,6 +143,11 @@ int fx_precond_apply_host(fx_context *ctx, const double *r, double *z);   /* z =
  * SpMV workgroups overlapped with the halo exchange (interior), ordered after it (boundary) | [15] bit 0: the last Krylov
  * loop ran in Eisenstat's form (FX_EISENSTAT=1); bit 1: the ILU(0) sweeps are chain sweeps (FX_DATAFLOW=3) */
 int fx_get_stats(fx_context *ctx, int64_t out[16]);
+/* wall time (s) this context's set-ups have spent on measured tuning so far -- the placement searches of the value arrays
+ * (candidate allocations: 10 ms each from recycled memory, ~200 ms each when the driver has to clear fresh VRAM) and the role
+ * timing of the work vectors -- as opposed to building the preconditioner (no reference counterpart: the reference has no
+ * such step; FX_TUNE_PLACEMENT=0 switches the searches off) */
+double fx_tune_seconds(fx_context *ctx);
 /* measured read-streaming rate (GB/s) of this device over the resident matrix values: the on-box
  * ceiling reported beside the 8 TB/s vendor peak */
 int fx_stream_ceiling(fx_context *ctx, int nrepeat, double *gbs);
