@@ -2632,21 +2632,22 @@ extern "C" int fx_nn_matvec_resident(fx_context *c, int nrepeat, float *ms_per_c
 extern "C" int fx_spmv_resident(fx_context *c, int variant, int nrepeat, float *ms_per_call) {
   HIP_TRY(hipSetDevice(c->device));
   if (getenv("FX_PLACEMENT_DEBUG"))
-    fprintf(stderr, "[fx placement] val2 %p col2 %p pair_ptr %p x(Bs) %p y(W7) %p partials %p slice_order %p\n", (void *)c->M.val2,
-            (void *)c->M.col2, (void *)c->M.pair_ptr, (void *)c->Bs, (void *)c->W[7], (void *)c->partials, (void *)c->M.slice_order);
+    fprintf(stderr, "[fx placement] val2 %p col2 %p pair_ptr %p x(W2) %p y(W1) %p partials %p slice_order %p\n", (void *)c->M.val2,
+            (void *)c->M.col2, (void *)c->M.pair_ptr, (void *)c->W[2], (void *)c->W[1], (void *)c->partials, (void *)c->M.slice_order);
   if (!c->have_values) { g_fx_error = "fx_spmv_resident: no matrix resident"; return FX_ERROR_RUNTIME; }
   if (variant < 0 || variant > 2) { g_fx_error = "fx_spmv_resident: variant must be 0, 1 or 2"; return FX_ERROR_RUNTIME; }
   if (ensure_solver(c)) return FX_ERROR_RUNTIME;
   if (to_slots(c, c->A.B, c->Bs)) return FX_ERROR_RUNTIME;
   const int mode = variant == 2 ? 1 : 0, dot = variant;
-  double *xin = c->Bs, *yout = c->W[7];
-  if (const char *e = getenv("FX_SPMV_XY")) {  // placement experiments: which work vectors play x and y ("2,1" = the CG loop's p and q)
+  // x and y are the vectors the CG loop multiplies (p = W[2], q = W[1]: cg_iteration) -- which buffers the product reads and
+  // writes moves its time by up to 4 % (scripts/experiments/ab_vectors.py), and the roofline figure is the loop's kernel.  The
+  // call overwrites them: not between fx_krylov_begin and the end of the iterations.  FX_SPMV_XY="a,b": other work vectors.
+  double *xin = c->W[2], *yout = c->W[1];
+  if (const char *e = getenv("FX_SPMV_XY")) {
     int a = -1, b = -1;
-    if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && a < 10 && b >= 0 && b < 10 && a != b) {
-      xin = c->W[a]; yout = c->W[b];
-      HIP_TRY(hipMemcpyAsync(xin, c->Bs, (size_t)c->wlen * 8, hipMemcpyDeviceToDevice, c->stream));
-    }
+    if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && a < 10 && b >= 0 && b < 10 && a != b) { xin = c->W[a]; yout = c->W[b]; }
   }
+  HIP_TRY(hipMemcpyAsync(xin, c->Bs, (size_t)c->wlen * 8, hipMemcpyDeviceToDevice, c->stream));
   if (spmv(c, mode, dot, xin, c->Bs, yout, nullptr, 0)) return FX_ERROR_RUNTIME;  // untimed first touch
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
   for (int i = 0; i < nrepeat; i++)

@@ -132,7 +132,9 @@ int fx_download_matrix(fx_context *ctx, double *D, double *AL, double *AU, doubl
 int fx_matvec_resident(fx_context *ctx, int nrepeat, float *ms_per_call); /* y = A x on work vectors */
 /* The same with the launch variant chosen: 0 plain (hecmw_solver_BiCGSTAB.f90:184, :210), 1 fused partial of x.y (the
  * product of every CG iteration, hecmw_solver_CG.f90:204-211), 2 r = b - A x with the partial of r.r (hecmw_matresid,
- * las/hecmw_solver_las.f90:105-122).  HIP events on the solver stream; one untimed call first. */
+ * las/hecmw_solver_las.f90:105-122).  HIP events on the solver stream; one untimed call first.  The product reads and
+ * writes the work vectors the CG loop multiplies (p and q) and overwrites them: not to be called while a Krylov loop is
+ * between fx_krylov_begin and its last step. */
 int fx_spmv_resident(fx_context *ctx, int variant, int nrepeat, float *ms_per_call);
 /* The same for the resident NDOF != 3 system of the last fx_solve / fx_matvec (hecmw_matvec_nn, las_nn.f90:135-310).
  * stats: NDOF, N, padded blocks of the layout, blocks of the matrix (N + NPL + NPU). */
