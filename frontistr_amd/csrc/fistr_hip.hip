@@ -694,6 +694,7 @@ static int tune_placement(fx_context *c, Bell &B, const char *what, double strea
     err = fill();
     if (!err) err = time_ms(&t.back());
     c->tune_cand_s += now_s() - w0;
+    if (max_tries < (1 << 30) && w1 - w0 > 0.03) { k = tries; }  // a search with little to gain (the sweeps: 1-3 %) stops at the first candidate hipMalloc had to clear fresh VRAM for
     if (getenv("FX_PLACEMENT_DEBUG")) fprintf(stderr, "[fx placement] try %d: hipMalloc %.1f ms, fill + time %.1f ms\n", k, 1e3 * (w1 - w0), 1e3 * (now_s() - w1));
   }
   if (err) {  // keep the first allocation (it is filled), release everything tried after it
