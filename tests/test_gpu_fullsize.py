@@ -215,3 +215,24 @@ def test_nonlinear_substep_bicgstab_ilu0_fullsize():
     assert np.abs(sig - sig[0]).max() < 1e-3 * np.abs(sig[0]).max()
     assert st["istat"].min() == 1                                          # every point yielded
     ctx.close()
+
+
+def test_device_ordering_equals_host_ordering_fullsize():
+    """The level ordering and the capped greedy multicolouring of the SSOR set-up run on the device from 100 k block rows on
+    (k_bfsb_*, k_mc_*); at the full 3.375 M rows of configs[2] the resident preconditioner's perm / COLORindex must be the
+    host walk's (fx_ssor_ordering: the reference's hecmw_matrix_ordering_CM / _MC, pinned against the oracle on CPU) node for
+    node -- 150 levels, 20 colours, ~2,900 colouring rounds."""
+    import ctypes as C
+    from frontistr_amd import hecmw as hip
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_abi import _lib_ordering
+    mesh, m, ctx = build(hip, 149)
+    m.Iarray[2] = 1
+    ctx.precond_setup(m)
+    perm = np.zeros(m.N, dtype=np.int32); cidx = np.zeros(m.N + 2, dtype=np.int32); nc = C.c_int32(0)
+    assert hip.lib().fx_get_ssor_ordering(ctx.h, perm.ctypes.data_as(C.c_void_p), cidx.ctypes.data_as(C.c_void_p), cidx.size, C.byref(nc)) == 0
+    ctx.close()
+    hperm, hcidx = _lib_ordering(m, 10)
+    assert nc.value == 20 and np.array_equal(cidx[:nc.value + 1], hcidx)
+    assert np.array_equal(perm, hperm)
