@@ -1148,8 +1148,9 @@ static int diag_setup(fx_context *c, double sigma_diag) {
 // host looks at the state every `bfs_batch` levels; 150 levels at 150^3 nodes).  A start whose graph is disconnected (the
 // reference then jumps to the lowest unvisited node) falls back to the host walk for that start.
 template <class GetGraph>
-static int rcm_sequence_device(fx_context *c, const std::vector<int32_t> &starts, GetGraph graph, std::vector<int32_t> &seq_out) {
-  const int32_t N = c->A.N;
+static int rcm_sequence_device(fx_context *c, const DevCSR &A, const std::vector<int32_t> &starts, GetGraph graph,
+                               std::vector<int32_t> &seq_out) {
+  const int32_t N = A.N;
   const int S = (int)starts.size();
   const int32_t nvb_max = (N + 255) / 256 + 1;
   DevScratch tmp;
@@ -1161,7 +1162,6 @@ static int rcm_sequence_device(fx_context *c, const std::vector<int32_t> &starts
       tmp.alloc(&cnt, (size_t)N * S) || tmp.alloc(&bsum, (size_t)nvb_max * S) || tmp.alloc(&boff, (size_t)nvb_max * S) ||
       tmp.alloc(&st, (size_t)2 * S))
     return FX_ERROR_RUNTIME;
-  const DevCSR &A = c->A;
   HIP_TRY(hipMemsetAsync(seen, 0, (size_t)N * S, c->stream));
   HIP_TRY(hipMemsetAsync(claim, 0xFF, (size_t)N * S * 4, c->stream));
   std::vector<BfsState> h_st((size_t)2 * S);
@@ -1217,10 +1217,9 @@ static int rcm_sequence_device(fx_context *c, const std::vector<int32_t> &starts
 // `mc_batch` rounds the host looks at the length of the next IN queue; an empty one ends the colour.  perm: new -> old
 // (0-based), colour by colour.  Returns 1 (nothing changed, the caller takes the host walk) when a colour needs more
 // rounds than the queue-length table holds: a graph whose decisions form one long chain.
-static int multicolor_device(fx_context *c, const std::vector<int32_t> &seq_h, int ncolor_in, std::vector<int32_t> &perm,
-                             std::vector<int32_t> &colorindex) {
-  const int32_t N = c->A.N, cap = N / ncolor_in;
-  const DevCSR &A = c->A;
+static int multicolor_device(fx_context *c, const DevCSR &A, const std::vector<int32_t> &seq_h, int ncolor_in,
+                             std::vector<int32_t> &perm, std::vector<int32_t> &colorindex) {
+  const int32_t N = A.N, cap = N / ncolor_in;
   DevScratch tmp;
   const int32_t nb16 = (int32_t)(((int64_t)N + 4095) / 4096);
   const int max_rounds = 1 << 16;
@@ -1275,18 +1274,16 @@ static int multicolor_device(fx_context *c, const std::vector<int32_t> &seq_h, i
   return 0;
 }
 
-// hecmw_precond_SSOR_33_setup (hecmw_precond_SSOR_33.f90:55-223), always on the
-// multicolour path (the reference's nthreads > 1 branch :102-111): ordering on the
-// host, values gathered on the device.  Within a colour the slots are sorted by the
-// number of lower blocks (rows of one colour are independent, so the order inside a
-// colour does not change the result) which keeps the BELL padding of L and U small.
-static int ssor_setup_symbolic(fx_context *c, int ncolor_in) {
-  const int32_t N = c->A.N;
-  SsorDev &S = c->ssor;
-  const int32_t *iL = c->h_indexL.data(), *jL = c->h_itemL.data(), *iU = c->h_indexU.data(), *jU = c->h_itemU.data();
-  PhaseTimer pt("ssor symbolic");
-  // node degrees inside the subdomain (halo columns -- ids > N, last in the ascending itemU -- are not part of the graph)
-  std::vector<int32_t> deg((size_t)N);
+// The reference's ordering of the multicolour SSOR (hecmw_matrix_ordering_CM + _MC): level sequence from the best of the
+// minimum-degree starts, capped greedy colouring -- on the device from bfs_device_min / mc_device_min block rows on (A: the
+// profile resident on the device; iL .. jU: the same arrays on the host), with the host walks of fx_order.cpp for small
+// systems and as the fallback.  deg: node degrees inside the subdomain; perm0: new -> old (0-based), colour by colour.
+static int ssor_ordering(fx_context *c, const DevCSR &A, const int32_t *iL, const int32_t *jL, const int32_t *iU, const int32_t *jU,
+                         int ncolor_in, std::vector<int32_t> &deg, std::vector<int32_t> &perm0, std::vector<int32_t> &cidx,
+                         PhaseTimer &pt) {
+  const int32_t N = A.N;
+  // halo columns -- ids > N, last in the ascending itemU -- are not part of the graph
+  deg.resize((size_t)N);
   parallel_for(N, [&](int64_t a, int64_t b) {
     for (int64_t r = a; r < b; r++) {
       int32_t e = iU[r + 1];
@@ -1303,17 +1300,31 @@ static int ssor_setup_symbolic(fx_context *c, int ncolor_in) {
   pt.lap("degrees");
   std::vector<int32_t> seq;
   if (N >= c->bfs_device_min) {
-    if (rcm_sequence_device(c, fxo::rcm_starts_deg(N, deg.data()), graph, seq)) return FX_ERROR_RUNTIME;
+    if (rcm_sequence_device(c, A, fxo::rcm_starts_deg(N, deg.data()), graph, seq)) return FX_ERROR_RUNTIME;
   } else seq = fxo::rcm_sequence(graph());
   pt.lap("level ordering");
-  std::vector<int32_t> perm0, cidx;
   int mc = 1;
   if (N >= c->mc_device_min && ncolor_in > 0 && N / ncolor_in > 0) {
-    mc = multicolor_device(c, seq, ncolor_in, perm0, cidx);
+    mc = multicolor_device(c, A, seq, ncolor_in, perm0, cidx);
     if (mc < 0) return FX_ERROR_RUNTIME;
   }
   if (mc > 0) fxo::multicolor(graph(), seq, ncolor_in, perm0, cidx);
   pt.lap("multicolour");
+  return 0;
+}
+
+// hecmw_precond_SSOR_33_setup (hecmw_precond_SSOR_33.f90:55-223), always on the
+// multicolour path (the reference's nthreads > 1 branch :102-111): ordering on the
+// host, values gathered on the device.  Within a colour the slots are sorted by the
+// number of lower blocks (rows of one colour are independent, so the order inside a
+// colour does not change the result) which keeps the BELL padding of L and U small.
+static int ssor_setup_symbolic(fx_context *c, int ncolor_in) {
+  const int32_t N = c->A.N;
+  SsorDev &S = c->ssor;
+  const int32_t *iL = c->h_indexL.data(), *jL = c->h_itemL.data(), *iU = c->h_indexU.data(), *jU = c->h_itemU.data();
+  PhaseTimer pt("ssor symbolic");
+  std::vector<int32_t> deg, perm0, cidx;
+  if (ssor_ordering(c, c->A, iL, jL, iU, jU, ncolor_in, deg, perm0, cidx, pt)) return FX_ERROR_RUNTIME;
   S.ncolor = (int32_t)cidx.size() - 1;
   S.colorindex = cidx;
   S.perm.resize(N);

@@ -551,9 +551,27 @@ static int nn_ssor_setup(fx_context *c, int ncolor_in) {
   NnDev *n = nn_of(c);
   const int nd = n->ndof, nd2 = nd * nd;
   const int32_t N = n->N;
-  fxo::Graph g = fxo::build_graph(N, n->h_indexL.data(), n->h_itemL.data(), n->h_indexU.data(), n->h_itemU.data());
-  std::vector<int32_t> seq = fxo::rcm_sequence(g), perm, cidx;
-  fxo::multicolor(g, seq, std::max(ncolor_in, 1), perm, cidx);
+  std::vector<int32_t> perm, cidx;
+  {  // the ordering of the 3x3 path (ssor_ordering: device walks from 100 k block rows on); the profile goes up for the walk only
+    DevScratch tmp;
+    DevCSR A;
+    A.N = N; A.NP = n->NP; A.NPL = (int32_t)n->h_itemL.size(); A.NPU = (int32_t)n->h_itemU.size();
+    if (N >= std::min(c->bfs_device_min, c->mc_device_min)) {
+      if (tmp.alloc(&A.indexL, n->h_indexL.size()) || tmp.alloc(&A.indexU, n->h_indexU.size()) || tmp.alloc(&A.itemL, n->h_itemL.size()) ||
+          tmp.alloc(&A.itemU, n->h_itemU.size()))
+        return FX_ERROR_RUNTIME;
+      HIP_TRY(hipMemcpyAsync(A.indexL, n->h_indexL.data(), n->h_indexL.size() * 4, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(hipMemcpyAsync(A.indexU, n->h_indexU.data(), n->h_indexU.size() * 4, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(hipMemcpyAsync(A.itemL, n->h_itemL.data(), n->h_itemL.size() * 4, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(hipMemcpyAsync(A.itemU, n->h_itemU.data(), n->h_itemU.size() * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    std::vector<int32_t> deg;
+    PhaseTimer pt("nn ssor symbolic");
+    if (ssor_ordering(c, A, n->h_indexL.data(), n->h_itemL.data(), n->h_indexU.data(), n->h_itemU.data(), std::max(ncolor_in, 1), deg, perm,
+                      cidx, pt))
+      return FX_ERROR_RUNTIME;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
   std::vector<int32_t> iperm((size_t)N);
   for (int32_t i = 0; i < N; i++) iperm[perm[i]] = i;
   n->ncolor = (int)cidx.size() - 1;
