@@ -120,7 +120,8 @@ def scan_driver(path):
     return us - INTRINSIC
 
 
-def build_variant(name, drivers, omp, jobs, provides, uses, overrides=None, defines=(), extra_link=(), exe_name=None, opt="-O2"):
+def build_variant(name, drivers, omp, jobs, provides, uses, overrides=None, defines=(), extra_link=(), exe_name=None, opt="-O2",
+                  c_main=None, c_main_flags=()):
     objdir = os.path.join(OUT, "obj_" + name)
     moddir = os.path.join(OUT, "mod_" + name)
     os.makedirs(objdir, exist_ok=True)
@@ -192,7 +193,12 @@ def build_variant(name, drivers, omp, jobs, provides, uses, overrides=None, defi
         exe = os.path.join(OUT, exe_name or (os.path.basename(d).replace("_driver.f90", "") + ("_omp" if omp else "")))
         dobj = objname(objdir, d)
         others = [o for o in fobjs if o != dobj and not any(o == objname(objdir, x) for x in drivers)]
-        link = [FLANG, "-o", exe, dobj] + others + [lib] + list(extra_link) + ["-lm"]
+        mains = []
+        if c_main:                         # a C `main` beside the Fortran root (fistr1/src/main/main.c calls fstr_main)
+            mo = objname(objdir, c_main)
+            run([GCC] + cflags + list(c_main_flags) + ["-c", c_main, "-o", mo])
+            mains.append(mo)
+        link = [FLANG, "-o", exe, dobj] + mains + others + [lib] + list(extra_link) + ["-lm"]
         if omp:
             link.append("-fopenmp")
         # External (non-module) Fortran procedures, e.g. the user-material
@@ -232,6 +238,38 @@ def build_variant(name, drivers, omp, jobs, provides, uses, overrides=None, defi
     return exes
 
 
+def render_config_header(outdir):
+    """FrontISTRConfig.h from the reference's template (CMakeLists.txt:98-101, :360-363 do this with configure_file):
+    version numbers from the reference's CMakeLists.txt, every WITH_* option off, HECMW_SERIAL on."""
+    os.makedirs(outdir, exist_ok=True)
+    with open(os.path.join(REF, "CMakeLists.txt")) as fh:
+        cm = fh.read()
+    vals = {k: re.search(r"set\(%s (\d+)" % k, cm).group(1) for k in ("VERSION_MAJOR", "VERSION_MINOR", "VERSION_PATCH")}
+    vals["GIT_HASH"] = '"unknown"'
+    on = {"HECMW_SERIAL", "NDEBUG"}
+    out = []
+    with open(os.path.join(REF, "FrontISTRConfig.h.in")) as fh:
+        for line in fh:
+            m = re.match(r"#cmakedefine\s+(\w+)(.*)", line)
+            if m:
+                out.append("#define %s%s\n" % (m.group(1), m.group(2)) if m.group(1) in on else "/* #undef %s */\n" % m.group(1))
+            else:
+                out.append(re.sub(r"@(\w+)@", lambda k: vals.get(k.group(1), ""), line))
+    with open(os.path.join(outdir, "FrontISTRConfig.h"), "w") as fh:
+        fh.write("".join(out))
+
+
+def fistr1_overrides(shimdir):
+    """Further reference modules a GPU build of fistr1 swaps (device assembly / stress update bindings); empty until
+    the files exist."""
+    over = {}
+    for mod, fn in (("m_fstr_stiffmatrix_hip", "fstr_stiffmatrix_hip.f90"),):
+        f = os.path.join(shimdir, fn)
+        if os.path.exists(f):
+            over[mod] = f
+    return over
+
+
 def build_partitioner(jobs):
     objdir = os.path.join(OUT, "obj_part")
     os.makedirs(objdir, exist_ok=True)
@@ -255,7 +293,7 @@ def build_partitioner(jobs):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--jobs", type=int, default=4)
-    ap.add_argument("--only", choices=["solve", "fem", "nl", "load", "shim", "part"], default=None)
+    ap.add_argument("--only", choices=["solve", "fem", "nl", "load", "shim", "part", "fistr1"], default=None)
     a = ap.parse_args()
     if not os.path.isdir(REF):
         print(f"reference not present at {REF}; oracle/_ref left as is")
@@ -294,7 +332,24 @@ def main():
     shimdir = os.path.join(os.path.dirname(HERE), "frontistr_amd", "shim")
     shim = os.path.join(shimdir, "hecmw_solver_hip.f90")
     hiplib = os.path.join(os.path.dirname(HERE), "frontistr_amd", "libfistr_hip.so")
-    if a.only in (None, "shim") and os.path.exists(shim) and os.path.exists(hiplib):
+    want_shim = a.only in (None, "shim") and os.path.exists(shim) and os.path.exists(hiplib)
+    want_f1 = a.only in (None, "fistr1")
+    # fistr1 ITSELF (VERDICT r02 "next" #1, SURVEY section 7 step 3's gate): the reference's own main program
+    # (fistr1/src/main/main.c -> fstr_main, fistr_main.f90:38-114) with every module the reference's, built twice:
+    #   oracle/_ref/fistr1_ref   the unmodified reference (OpenMP build: OMP_NUM_THREADS >= 2 gives the multicolour SSOR)
+    #   oracle/_ref/fistr1_hip   the same program with module hecmw_solver / hecmw_solver_las taken from frontistr_amd/shim/
+    #                            (what a maintainer gets by following INTEGRATION.md) -> libfistr_hip.so
+    # FrontISTRConfig.h is a CMake-generated header (version numbers + WITH_* switches for `fistr1 -v`); it is rendered
+    # here from the reference's own template FrontISTRConfig.h.in with the values of a serial build without options.
+    fmain = os.path.join(REF, "fistr1/src/main/fistr_main.f90")
+    cmain = os.path.join(REF, "fistr1/src/main/main.c")
+    gen_cfg = os.path.join(OUT, "gen_fistr1")
+    if want_f1 or want_shim:
+        render_config_header(gen_cfg)
+    if want_f1:
+        build_variant("omp", [fmain], True, a.jobs, provides, uses, exe_name="fistr1_ref",
+                      c_main=cmain, c_main_flags=("-I", gen_cfg))
+    if want_shim or (want_f1 and os.path.exists(hiplib)):
         # hecmw_matvec: the four-line patch of INTEGRATION.md section 2 applied to a SCRATCH copy of the reference's
         # hecmw_solver_las.f90 (build intermediate under oracle/_ref/, removed after the compile; never committed)
         gen = os.path.join(OUT, "gen_shim")
@@ -311,12 +366,18 @@ def main():
                                        "    endif\n" + body_anchor, 1)
         with open(las, "w") as fh:
             fh.write(src)
+        over = {"hecmw_solver": shim, "hecmw_hip_binding": os.path.join(shimdir, "hecmw_hip_binding.f90"),
+                "hecmw_matvec_hip": os.path.join(shimdir, "hecmw_matvec_hip.f90"), "hecmw_solver_las": las}
+        over.update(fistr1_overrides(shimdir))
+        link = (hiplib, "-Wl,-rpath," + os.path.dirname(hiplib), "-Wl,-rpath,/opt/rocm/lib")
         try:
-            build_variant("shim", [solve], False, a.jobs, provides, uses,
-                          overrides={"hecmw_solver": shim, "hecmw_hip_binding": os.path.join(shimdir, "hecmw_hip_binding.f90"),
-                                     "hecmw_matvec_hip": os.path.join(shimdir, "hecmw_matvec_hip.f90"), "hecmw_solver_las": las},
-                          defines=("USE_SHIM",), exe_name="shim_solve",
-                          extra_link=(hiplib, "-Wl,-rpath," + os.path.dirname(hiplib), "-Wl,-rpath,/opt/rocm/lib"))
+            if want_shim:
+                build_variant("shim", [solve], False, a.jobs, provides, uses, overrides=over,
+                              defines=("USE_SHIM",), exe_name="shim_solve", extra_link=link)
+            if want_f1:
+                build_variant("shim", [fmain], False, a.jobs, provides, uses, overrides=over,
+                              defines=("USE_SHIM",), exe_name="fistr1_hip", extra_link=link,
+                              c_main=cmain, c_main_flags=("-I", gen_cfg))
         finally:
             os.remove(las)
             os.rmdir(gen)

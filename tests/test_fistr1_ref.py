@@ -1,0 +1,58 @@
+"""The harness that judges fistr1 runs (oracle/fistr1_run.py = examples/test_FrontISTR.rb restated) and the reference's own
+main program built here (oracle/_ref/fistr1_ref): it must reproduce the *_correct.log files the reference ships, otherwise
+nothing measured with it means anything.  CPU only."""
+import os
+
+import pytest
+
+from oracle import fistr1_run as f1
+
+
+def _need(binary):
+    if not f1.have(binary):
+        if os.path.isdir("/root/reference"):
+            pytest.fail("oracle/_ref/%s missing although /root/reference is here: run python oracle/build_ref.py --only fistr1" % binary)
+        pytest.skip("oracle/_ref/%s not built (needs /root/reference at build time)" % binary)
+
+
+def test_log_reader_reads_both_formats():
+    old = f1.read_log(os.path.join(f1.DECKS, "exA", "A361_correct.log"))
+    assert len(old) == 1 and old[0]["Node"]["U3"] == (0.0, -9.8430E-01) and old[0]["Node"]["E31"] == (-7.5570E-05, -1.2244E-03)
+    assert old[0]["Element"]["SMS"] == (2.6641E+01, 2.4615E+00)
+    new = f1.read_log(os.path.join(f1.DECKS, "t05", "necking_fistr1_ref_0.log"))
+    assert len(new) == 9 and set(new[1]["Node"]) >= {"U1", "U2", "U3", "S33", "SMS"}
+    assert f1.compare_step(old[0], old[0]) == []
+    worse = {"Node": dict(old[0]["Node"], U3=(0.0, -9.8441E-01)), "Element": old[0]["Element"]}
+    assert f1.compare_step(worse, old[0]) == [("Node", "U3", "min", -9.8441E-01, -9.8430E-01)]
+    sta = f1.read_sta(os.path.join(f1.DECKS, "t05", "necking_fistr1_ref_FSTR.sta"))
+    assert [r[3] for r in sta] == [36, 5, 5, 5, 5, 5, 5, 5, 50] and sta[8][2] == "1F" and "MAXITER" in sta[8][4]
+
+
+def test_solver_card_rewrite(tmp_path):
+    f1.prepare("exA", str(tmp_path), "A361.msh", "A300.cnt", method="BiCGSTAB", precond=10)
+    s = open(tmp_path / "A300.cnt").read()
+    assert "!SOLVER,METHOD=BiCGSTAB,PRECOND=10,ITERLOG=YES,TIMELOG=YES" in s and "VISUAL" not in s
+    assert "!RESTART, FREQUENCY=100000" in s and s.rstrip().endswith("!END")
+
+
+@pytest.mark.parametrize("deck,cnt,threads", [("exA", "A300.cnt", 1), ("exA", "A300.cnt", 4), ("exI", "I300.cnt", 4)])
+def test_reference_program_reproduces_its_correct_logs(deck, cnt, threads):
+    _need("fistr1_ref")
+    r = f1.run_deck("fistr1_ref", deck, "A361.msh", cnt, threads=threads)
+    assert r["returncode"] == 0 and "FrontISTR Completed !!" in r["stdout"], r["stdout"][-2000:]
+    correct = f1.read_log(os.path.join(f1.DECKS, deck, "A361_correct.log"))
+    got = r["log"][1:]                                  # block 0 is the all-zero summary of step 0
+    assert len(got) == len(correct)
+    for a, c in zip(got, correct):
+        assert f1.compare_step(a, c) == []
+
+
+def test_reference_program_on_the_plastic_cylinder():
+    """tutorial/05 (configs[4]'s deck): 36 + 7 x 5 Newton iterations, stop at sub-step 9 -- SURVEY section 0."""
+    _need("fistr1_ref")
+    r = f1.run_deck("fistr1_ref", "t05", "necking.msh", "necking.cnt", threads=4)
+    assert [x[3] for x in r["sta"][:8]] == [36, 5, 5, 5, 5, 5, 5, 5] and r["sta"][8][2] == "1F"
+    want = f1.read_log(os.path.join(f1.DECKS, "t05", "necking_fistr1_ref_0.log"))
+    assert len(r["log"]) == len(want) == 9
+    for a, c in zip(r["log"], want):
+        assert f1.compare_step(a, c) == []

@@ -1,0 +1,84 @@
+"""fistr1 ITSELF drives the GPU (VERDICT r02 missing #1, SURVEY section 7 step 3's gate): oracle/_ref/fistr1_hip is the
+reference's own main program -- main.c -> fstr_main (fistr_main.f90:38-114) -> fstr_solve_NLGEOM -> fstr_Newton ->
+solve_LINEQ (fistr1/src/lib/solve_LINEQ.f90:15-24) -> hecmw_solve -- built from the reference's sources with module
+hecmw_solver taken from frontistr_amd/shim/ (oracle/build_ref.py --only fistr1), started as a fresh child process on the
+reference's own decks.  Judged the way the reference judges itself (examples/test_FrontISTR.rb: max / min of 0.log within
+1e-4 absolute of the shipped *_correct.log)."""
+import os
+import re
+
+import pytest
+
+from oracle import fistr1_run as f1
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(deck, mesh, cnt, **kw):
+    if not f1.have("fistr1_hip"):
+        pytest.skip("oracle/_ref/fistr1_hip not built (needs /root/reference at build time)")
+    r = f1.run_deck("fistr1_hip", deck, mesh, cnt, **kw)
+    assert r["returncode"] == 0, r["stdout"][-3000:]
+    assert "FrontISTR Completed !!" in r["stdout"] or "Fail to Converge" in r["stdout"], r["stdout"][-3000:]
+    assert "reference CPU solver used" not in r["stdout"]          # every solve ran on the GPU
+    return r
+
+
+def _iterlog(stdout):
+    """ITERLOG lines '(i7,1pe16.6)' grouped per solve (a banner starts a solve)."""
+    solves, cur = [], None
+    for line in stdout.split("\n"):
+        if line.startswith("### ") and "BLOCK" in line:
+            cur = []
+            solves.append(cur)
+        elif cur is not None and re.match(r"^\s*\d+\s+\d\.\d{6}E[-+]\d\d\s*$", line):
+            cur.append(float(line.split()[1]))
+    return solves
+
+
+@pytest.mark.parametrize("method,precond,banner,iters", [
+    (None, None, "### 3x3 BLOCK CG, DIAG, 1", 70),            # the deck as shipped (A300.cnt: CG, PRECOND=3)
+    ("CG", 1, "### 3x3 BLOCK CG, SSOR, 1", None),
+    ("CG", 10, "### 3x3 BLOCK CG, ILU(0), 1", 75),
+    ("BiCGSTAB", 10, "### 3x3 BLOCK BiCGSTAB, ILU(0), 1", 93)])
+def test_fistr1_exA_A361_on_the_gpu(method, precond, banner, iters):
+    """examples/static/exA: A361.msh + A300.cnt against A361_correct.log; iteration counts of the full fistr1 runs recorded in
+    SURVEY section 0 (CG+DIAG 70, CG+ILU(0) 75, BiCGSTAB+ILU(0) 93; CG+SSOR's 85 is the 1-thread natural order)."""
+    kw = {} if method is None else {"method": method, "precond": precond}
+    r = _run("exA", "A361.msh", "A300.cnt", **kw)
+    assert banner in r["stdout"], r["stdout"][:3000]
+    correct = f1.read_log(os.path.join(f1.DECKS, "exA", "A361_correct.log"))
+    assert len(r["log"]) == 2 and f1.compare_step(r["log"][-1], correct[-1]) == []
+    assert "### Relative residual =" in r["stdout"] and "### summary of linear solver" in r["stdout"]
+    h = _iterlog(r["stdout"])
+    assert len(h) == 1 and h[0][-1] <= 1e-8
+    if iters is not None:
+        tol = 1 if method != "BiCGSTAB" else max(2, int(0.15 * iters))
+        assert abs(len(h[0]) - iters) <= tol, len(h[0])
+
+
+def test_fistr1_exI_nlgeom_on_the_gpu():
+    """examples/static/exI: `!STATIC, TYPE=NLGEOM`, 10 sub-steps, 2 Newton iterations each -- every step's summary against
+    exI/A361_correct.log."""
+    r = _run("exI", "A361.msh", "I300.cnt")
+    correct = f1.read_log(os.path.join(f1.DECKS, "exI", "A361_correct.log"))
+    got = r["log"][1:]
+    assert len(got) == len(correct) == 10
+    for a, c in zip(got, correct):
+        assert f1.compare_step(a, c) == []
+    assert [x[3] for x in r["sta"]] == [2] * 10
+
+
+def test_fistr1_plastic_cylinder_on_the_gpu():
+    """tutorial/05_plastic_cylinder (configs[4]'s deck; multilinear Mises, updated Lagrange, CG + SSOR 1e-8, CONVERG 1e-3):
+    Newton counts 36, 5, 5, 5, 5, 5, 5, 5 and the stop at sub-step 9 exactly as the unmodified program (FSTR.sta), every
+    step's displacement / strain / stress extrema against the unmodified program's 0.log (tests/golden/decks/t05/, generator
+    make_fistr1_golden.py; the reference ships no correct-log for this deck).  121 linear solves through hecmw_solve."""
+    r = _run("t05", "necking.msh", "necking.cnt")
+    assert [x[3] for x in r["sta"][:8]] == [36, 5, 5, 5, 5, 5, 5, 5], r["sta"]
+    assert r["sta"][8][2] == "1F" and "MAXITER" in r["sta"][8][4]
+    assert r["stdout"].count("### 3x3 BLOCK CG, SSOR, 1") == 121
+    want = f1.read_log(os.path.join(f1.DECKS, "t05", "necking_fistr1_ref_0.log"))
+    assert len(r["log"]) == len(want) == 9
+    for a, c in zip(r["log"], want):
+        assert f1.compare_step(a, c) == []
