@@ -230,6 +230,57 @@ static int context_init(fx_context *c) {
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// Tuning knobs of a context: ONE table, settable on a live context through fx_set_option (same data, same placement: what an
+// A/B measurement needs) and, under the same names, from the environment at fx_create.  Defaults and what was measured with
+// each knob: fx_internal.h.
+// ---------------------------------------------------------------------------
+struct FxOption { const char *name; void (*set)(fx_context *, double); };
+static const FxOption g_fx_options[] = {
+    {"FX_TUNE_PLACEMENT", [](fx_context *c, double v) { c->tune_tries = std::max(0, (int)v); }},
+    {"FX_BFS_DEVICE_MIN", [](fx_context *c, double v) { c->bfs_device_min = (int)v; }},
+    {"FX_MC_DEVICE_MIN", [](fx_context *c, double v) { c->mc_device_min = (int)v; }},
+    {"FX_BFS_BATCH", [](fx_context *c, double v) { c->bfs_batch = std::max(1, (int)v); }},
+    {"FX_TUNE_BUDGET_MS", [](fx_context *c, double v) { c->tune_budget_s = 1e-3 * v; }},
+    {"FX_VAL2_POW2", [](fx_context *c, double v) { c->val2_pow2 = (int)v != 0; }},
+    {"FX_TUNE_HOLD_GB", [](fx_context *c, double v) { c->hold_max_bytes = (size_t)(v * 1e9); }},
+    {"FX_MC_BATCH", [](fx_context *c, double v) { c->mc_batch = std::max(1, (int)v); }},
+    {"FX_LAYOUT_DEVICE", [](fx_context *c, double v) { c->layout_device = (int)v != 0; }},
+    {"FX_PIPE_SPMV", [](fx_context *c, double v) { c->pipe_spmv = (int)v != 0; }},
+    {"FX_PIPE_SSOR", [](fx_context *c, double v) { c->pipe_ssor = (int)v != 0; }},
+    {"FX_SSOR_MODE", [](fx_context *c, double v) { c->ssor_mode = (int)v; }},
+    {"FX_PIPE_MAX_SLICES", [](fx_context *c, double v) { c->pipe_max_slices = (int)v; }},
+    {"FX_SSOR_BS", [](fx_context *c, double v) { c->ssor_bs = ((int)v == 64) ? 64 : 256; }},
+    {"FX_SSOR_SPW", [](fx_context *c, double v) { c->ssor_spw = std::max(1, std::min(8, (int)v)); }},
+    {"FX_SPMV_BS", [](fx_context *c, double v) { c->spmv_bs = ((int)v == 64) ? 64 : 256; }},
+    {"FX_SPMV_SPATIAL", [](fx_context *c, double v) { c->spmv_spatial = (int)v != 0; }},
+    {"FX_GRAPH", [](fx_context *c, double v) { c->graph_mode = (int)v; }},
+    {"FX_OVERLAP", [](fx_context *c, double v) { c->overlap = (int)v != 0; }},
+    {"FX_EISENSTAT", [](fx_context *c, double v) { c->eisenstat = (int)v != 0; }},
+    {"FX_EIS_FUSE", [](fx_context *c, double v) { c->eis_fuse = (int)v != 0; }},
+    {"FX_SPLIT_MAX_SLICES", [](fx_context *c, double v) { c->split_max_slices = (int)v; }},
+    {"FX_DATAFLOW", [](fx_context *c, double v) { c->df_mode = (int)v; }},
+    {"FX_CH_HOP", [](fx_context *c, double v) { c->ch_hop = std::max(0, (int)v); }},
+    {"FX_CH_GRID", [](fx_context *c, double v) { c->ch_grid = (int)v; }},
+    {"FX_CH_AHEAD", [](fx_context *c, double v) { c->ch_ahead = (int)v; }},
+    {"FX_CH_W", [](fx_context *c, double v) { c->ch_w = (int)v; }},
+    {"FX_CH_MAXLEN", [](fx_context *c, double v) { c->ch_maxlen = std::max(1, (int)v); }},
+    {"FX_DF_GRID", [](fx_context *c, double v) { c->df_grid = (int)v; }},
+    {"FX_DF_POLL", [](fx_context *c, double v) { c->df_poll = (int)v; }},
+    {"FX_DF_SLEEP", [](fx_context *c, double v) { c->df_sleep = std::max(0, (int)v); }},
+    {"FX_DF_WPS", [](fx_context *c, double v) { c->df_wps = ((int)v == 2 || (int)v == 4) ? (int)v : 8; }},
+    {"FX_DEBUG_ONECOLOR", [](fx_context *c, double v) { c->dbg_onecolor = (int)v != 0; }},
+    {"FX_SPLIT_WPS", [](fx_context *c, double v) { c->split_wps = ((int)v == 2 || (int)v == 4 || (int)v == 8) ? (int)v : 0; }},
+};
+
+extern "C" int fx_set_option(fx_context *c, const char *name, double value) {
+  if (!c || !name) { g_fx_error = "fx_set_option: null argument"; return FX_ERROR_RUNTIME; }
+  for (const FxOption &o : g_fx_options)
+    if (strcmp(o.name, name) == 0) { o.set(c, value); return 0; }
+  g_fx_error = std::string("fx_set_option: unknown option ") + name;
+  return FX_ERROR_UNSUPPORTED;
+}
+
 extern "C" int fx_create(int device, fx_context **out) {
   *out = nullptr;
   int ndev = 0;
@@ -254,43 +305,13 @@ extern "C" int fx_create(int device, fx_context **out) {
     void *dummy = nullptr;
     (void)hipMalloc(&dummy, (size_t)atoll(e) << 20);  // kept for the life of the process on purpose
   }
-  if (const char *e = getenv("FX_TUNE_PLACEMENT")) c->tune_tries = std::max(0, atoi(e));
-  if (const char *e = getenv("FX_BFS_DEVICE_MIN")) c->bfs_device_min = atoi(e);
-  if (const char *e = getenv("FX_MC_DEVICE_MIN")) c->mc_device_min = atoi(e);
-  if (const char *e = getenv("FX_BFS_BATCH")) c->bfs_batch = std::max(1, atoi(e));
-  if (const char *e = getenv("FX_TUNE_BUDGET_MS")) c->tune_budget_s = 1e-3 * atof(e);
-  if (const char *e = getenv("FX_VAL2_POW2")) c->val2_pow2 = atoi(e) != 0;
-  if (const char *e = getenv("FX_TUNE_HOLD_GB")) c->hold_max_bytes = (size_t)(atof(e) * 1e9);
-  if (const char *e = getenv("FX_MC_BATCH")) c->mc_batch = std::max(1, atoi(e));
-  if (const char *e = getenv("FX_LAYOUT_DEVICE")) c->layout_device = atoi(e) != 0;
-  if (const char *e = getenv("FX_PIPE_SPMV")) c->pipe_spmv = atoi(e) != 0;
-  if (const char *e = getenv("FX_PIPE_SSOR")) c->pipe_ssor = atoi(e) != 0;
-  if (const char *e = getenv("FX_SSOR_MODE")) c->ssor_mode = atoi(e);
-  if (const char *e = getenv("FX_PIPE_MAX_SLICES")) c->pipe_max_slices = atoi(e);
-  if (const char *e = getenv("FX_SSOR_BS")) c->ssor_bs = (atoi(e) == 64) ? 64 : 256;
-  if (const char *e = getenv("FX_SSOR_SPW")) c->ssor_spw = std::max(1, std::min(8, atoi(e)));
-  if (const char *e = getenv("FX_SPMV_BS")) c->spmv_bs = (atoi(e) == 64) ? 64 : 256;
-  if (const char *e = getenv("FX_SPMV_SPATIAL")) c->spmv_spatial = atoi(e) != 0;
-  if (const char *e = getenv("FX_GRAPH")) c->graph_mode = atoi(e);
-  if (const char *e = getenv("FX_OVERLAP")) c->overlap = atoi(e) != 0;
-  if (const char *e = getenv("FX_EISENSTAT")) c->eisenstat = atoi(e) != 0;
-  if (const char *e = getenv("FX_SPLIT_MAX_SLICES")) c->split_max_slices = atoi(e);
-  if (const char *e = getenv("FX_DATAFLOW")) c->df_mode = atoi(e);
-  if (const char *e = getenv("FX_CH_HOP")) c->ch_hop = std::max(0, atoi(e));
-  if (const char *e = getenv("FX_CH_GRID")) c->ch_grid = atoi(e);
-  if (const char *e = getenv("FX_CH_AHEAD")) c->ch_ahead = atoi(e);
-  if (const char *e = getenv("FX_CH_W")) c->ch_w = atoi(e);
-  if (const char *e = getenv("FX_CH_MAXLEN")) c->ch_maxlen = std::max(1, atoi(e));
+  for (const FxOption &o : g_fx_options)
+    if (const char *e = getenv(o.name)) o.set(c, atof(e));
   {  // chain sweeps: every workgroup of the launch must be resident at once
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tri_chain<8>, 256, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
     c->ch_grid_auto = std::max(1, c->n_cu * std::min(per_cu, 8));
   }
-  if (const char *e = getenv("FX_DF_GRID")) c->df_grid = atoi(e);
-  if (const char *e = getenv("FX_DF_POLL")) c->df_poll = atoi(e);
-  if (const char *e = getenv("FX_DF_SLEEP")) c->df_sleep = std::max(0, atoi(e));
-  if (const char *e = getenv("FX_DF_WPS")) c->df_wps = (atoi(e) == 2 || atoi(e) == 4) ? atoi(e) : 8;
-  if (const char *e = getenv("FX_SPLIT_WPS")) c->split_wps = (atoi(e) == 2 || atoi(e) == 4 || atoi(e) == 8) ? atoi(e) : 0;
   *out = c;
   return 0;
 }
@@ -1929,6 +1950,14 @@ static int precond_apply_once(fx_context *c, const double *r, double *z, bool wa
       hipLaunchKernelGGL((k_ssor_color_split<FWD, 4>), dim3(s1 - s0), dim3(256), 0, c->stream, s0, s1, BL.pair_ptr, BL.val2, \
                          BL.col2, sn, S.alu, r, zsweep, znat, part, gate_status(c));                                    \
   } while (0)
+    if (c->dbg_onecolor) {  // MEASUREMENT ONLY (wrong numbers): both half sweeps as ONE launch each, dependencies ignored -- what the sweeps would cost without 2 x ncolor dependent launches
+      const int s0 = 0, s1 = S.L.nslices, g = (s1 - s0 + spb - 1) / spb;
+      { const Bell &BL = S.L; if (bs == 64) SSOR_LAUNCH(true, 64, g, s0, s1, (double *)nullptr); else SSOR_LAUNCH(true, 256, g, s0, s1, (double *)nullptr); }
+      { const Bell &BL = S.U; if (bs == 64) SSOR_LAUNCH(false, 64, g, s0, s1, (double *)nullptr); else SSOR_LAUNCH(false, 256, g, s0, s1, (double *)nullptr); }
+      *nparts = 0;
+      HIP_TRY(hipGetLastError());
+      return 0;
+    }
     for (int col = 0; col < S.ncolor; col++) {
       const int s0 = S.color_slice[col], s1 = S.color_slice[col + 1];
       if (s1 <= s0) continue;
@@ -2000,10 +2029,11 @@ static int dot_into_partials(fx_context *c, const double *x, const double *y, co
 // Krylov drivers.  Device-resident state machine; the host enqueues whole
 // iterations and only polls the status word every `chunk` iterations.
 // ---------------------------------------------------------------------------
-static int krylov_init_state(fx_context *c, int maxit, double tol) {
+static int krylov_init_state(fx_context *c, int maxit, double tol, bool pause_verify = false) {
   KrylovState s;
   memset(&s, 0, sizeof s);
   s.iter = 1;
+  s.pause_verify = pause_verify ? 1 : 0;
   s.maxit = maxit;
   s.tol = tol;
   HIP_TRY(hipMemcpyAsync(c->st, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
@@ -2102,9 +2132,27 @@ static int eis_cg_iteration(fx_context *c, int it) {
   double *part_rho = c->partials + c->max_partials;
   // rho = r.M^-1 r = t.D~t (:168), beta (:193); ph = D~ t + beta ph  [= (D~+U)(z + beta p)]
   if (scalar_stage<OP_CG_RHO>(c, ugrid, 0, RECOMPUTE, part_rho)) return FX_ERROR_RUNTIME;
-  hipLaunchKernelGGL(k_cg_update_p, dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, n3, c->st, DT, PH);
-  // p = (D~+U)^-1 ph
-  if (eis_sweep_backward(c, PH, P, gate_status(c))) return FX_ERROR_RUNTIME;
+  if (c->eis_fuse) {  // p = (D~+U)^-1 ph with ph = D~ t + beta ph formed by each row's own lane on the way (k_eis_backward)
+    ClockScope cs(c, 1);
+    const int spb = c->ssor_bs / 64;
+    for (int col = S.ncolor - 1; col >= 0; col--) {
+      const int s0 = S.color_slice[col], s1 = S.color_slice[col + 1];
+      if (s1 <= s0) continue;
+      if (s1 - s0 <= c->split_max_slices)
+        hipLaunchKernelGGL((k_eis_backward_split<4>), dim3(s1 - s0), dim3(256), 0, c->stream, s0, s1, S.U.pair_ptr, S.U.val2, S.U.col2, S.alu,
+                           c->st, DT, PH, P, gate_status(c));
+      else if (c->ssor_bs == 64)
+        hipLaunchKernelGGL((k_eis_backward<64>), dim3((s1 - s0 + spb - 1) / spb), dim3(64), 0, c->stream, s0, s1, S.U.pair_ptr, S.U.val2,
+                           S.U.col2, S.alu, c->st, DT, PH, P, gate_status(c));
+      else
+        hipLaunchKernelGGL((k_eis_backward<256>), dim3((s1 - s0 + spb - 1) / spb), dim3(256), 0, c->stream, s0, s1, S.U.pair_ptr, S.U.val2,
+                           S.U.col2, S.alu, c->st, DT, PH, P, gate_status(c));
+    }
+  } else {
+    hipLaunchKernelGGL(k_cg_update_p, dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, n3, c->st, DT, PH);
+    // p = (D~+U)^-1 ph
+    if (eis_sweep_backward(c, PH, P, gate_status(c))) return FX_ERROR_RUNTIME;
+  }
   const double *HP = nullptr;
   if (halo_active(c)) {  // subdomain: halo part of p from its owners, then hp = H p (W[8])
     if (halo_update(c, P)) return FX_ERROR_RUNTIME;
@@ -2149,11 +2197,7 @@ static int eis_cg_iteration(fx_context *c, int it) {
   } else {
     hipLaunchKernelGGL((k_eis_update<1>), dim3(ugrid), dim3(FX_BLOCK), 0, c->stream, ns, c->st, S.dblk, sm1, P, Q, WH, X, R, T, DT,
                        c->partials, part_rho, gate_status(c));
-    if (scalar_stage<OP_RESID>(c, ugrid, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
-    // converged by the recurrence: true residual, re-test (:259-266); if the loop goes on, r IS the true residual now: refresh t
-    if (spmv(c, 1, 2, X, B, R, gate_verify(c), 1)) return FX_ERROR_RUNTIME;
-    if (scalar_stage<OP_VERIFY>(c, spmv_nparts(c), 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
-    if (eis_refresh_t(c, &c->st->t_current)) return FX_ERROR_RUNTIME;  // runs only while t_current == 0 (set by OP_VERIFY, cleared by OP_CG_RHO)
+    if (scalar_stage<OP_RESID>(c, ugrid, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;  // converged by the recurrence: the loop parks, verify_stage() follows from the host
   }
   HIP_TRY(hipGetLastError());
   return 0;
@@ -2186,7 +2230,7 @@ static int krylov_begin(fx_context *c, int method, int maxit, double tol) {
   const bool sweepy = (c->precond_kind == 1 || c->precond_kind == 10);
   c->k_graph = !c->clock.on && !multi_rank(c) && c->nranks <= 1 && c->halo.n_neighbor <= 0 &&
                (c->graph_mode == 2 || (c->graph_mode == 1 && sweepy && c->ord.nslots <= c->graph_max_rows));
-  if (krylov_init_state(c, maxit, tol)) return FX_ERROR_RUNTIME;
+  if (krylov_init_state(c, maxit, tol, true)) return FX_ERROR_RUNTIME;
   HIP_TRY(hipMemsetAsync(c->W[2], 0, (size_t)c->wlen * 8, c->stream));  // P
   if (c->precond_kind == 1 || c->precond_kind == 10)  // padding blocks multiply (value 0) x (the row's own stale entry): keep that entry finite
     HIP_TRY(hipMemsetAsync(c->ssor.zs, 0, (size_t)3 * c->ssor.nslots * 8, c->stream));
@@ -2234,13 +2278,21 @@ static int cg_iteration(fx_context *c, int it) {
     hipLaunchKernelGGL((k_cg_update_xr<true>), dim3(vgrid), dim3(FX_BLOCK), 0, c->stream, n3, c->st, P, Q, X, R, c->partials);
     np = vgrid;
   }
-  if (scalar_stage<OP_RESID>(c, np, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
-  // converged by the recurrence: recompute the true residual and re-test (:259-266)
-  if (it % RECOMPUTE != 0) {
-    if (spmv(c, 1, 2, X, B, R, gate_verify(c), 1)) return FX_ERROR_RUNTIME;
-    if (scalar_stage<OP_VERIFY>(c, spmv_nparts(c), 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
-  }
+  if (scalar_stage<OP_RESID>(c, np, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;  // converged by the recurrence: the loop parks, verify_stage() follows from the host
   HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// Converged by the recurrence (RESID <= TOL): recompute the true residual and re-test (hecmw_solver_CG.f90:259-266,
+// hecmw_solver_BiCGSTAB.f90:256-262).  OP_RESID parked the device loop (FX_ST_PAUSED: whatever was enqueued behind it ran as
+// no-ops); the host enqueues the check when its poll sees that -- once or twice per solve -- instead of carrying a gated SpMV, a
+// gated scalar stage (and, in Eisenstat's form, 21 gated sweep launches) through every iteration.  OP_VERIFY either ends the
+// loop or resumes it at the next iteration; in Eisenstat's form r then IS the true residual, so t is refreshed from it.
+static int verify_stage(fx_context *c) {
+  const int RECOMPUTE = (c->k_method == 1) ? 50 : 100;
+  if (spmv(c, 1, 2, c->Xs, c->Bs, c->W[0], gate_verify(c), 1)) return FX_ERROR_RUNTIME;
+  if (scalar_stage<OP_VERIFY>(c, spmv_nparts(c), 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
+  if (c->eis_active && eis_refresh_t(c, &c->st->t_current)) return FX_ERROR_RUNTIME;  // runs only if the loop goes on (t_current == 0)
   return 0;
 }
 
@@ -2275,11 +2327,7 @@ static int bicgstab_iteration(fx_context *c, int it) {
                        c->partials);
     np = vgrid;
   }
-  if (scalar_stage<OP_RESID>(c, np, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
-  if (it % RECOMPUTE != 0) {
-    if (spmv(c, 1, 2, X, B, R, gate_verify(c), 1)) return FX_ERROR_RUNTIME;
-    if (scalar_stage<OP_VERIFY>(c, spmv_nparts(c), 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
-  }
+  if (scalar_stage<OP_RESID>(c, np, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;  // converged by the recurrence: parks, see verify_stage()
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -2315,8 +2363,9 @@ static int krylov_steps(fx_context *c, int n, KrylovState *st_out) {
   const int recompute = (c->k_method == 1) ? 50 : 100;
   KrylovState s;
   memset(&s, 0, sizeof s);
-  int done = 0;
-  while (done < n && c->k_it <= c->k_maxit) {
+  const int last = (int)std::min<int64_t>((int64_t)c->k_it + n - 1, c->k_maxit);  // the last iteration this call may execute
+  int enq = 0;
+  while (c->k_it <= last) {
     const int it = c->k_it;
     int e = 0;
     if (c->k_graph) {
@@ -2328,9 +2377,13 @@ static int krylov_steps(fx_context *c, int n, KrylovState *st_out) {
     }
     if (e) return e;
     c->k_it++;
-    done++;
-    if (done % chunk == 0 || done == n || it == c->k_maxit) {
+    enq++;
+    if (enq % chunk == 0 || it == last) {
       if (poll_state(c, &s)) return FX_ERROR_RUNTIME;
+      if (s.status == FX_ST_PAUSED) {  // RESID <= TOL by the recurrence at iteration s.iter: true-residual check, then go on from there
+        if (verify_stage(c) || poll_state(c, &s)) return FX_ERROR_RUNTIME;
+        if (s.status == 0) c->k_it = s.iter;  // the iterations enqueued behind the parked one were no-ops
+      }
       if (s.status != 0) break;
     }
   }

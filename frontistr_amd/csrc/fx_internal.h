@@ -115,6 +115,7 @@ struct DiagDev {
 };
 
 // Scalars of the Krylov loops, resident on the device; the host only polls `status`.
+#define FX_ST_PAUSED 2  // KrylovState::status: waiting for the host to enqueue the true-residual check (hecmw_solver_CG.f90:259-266)
 struct KrylovState {
   double rho, rho1, beta, c1, alpha, omega, c2, cg0, cg1, dnrm2, bnrm2, resid, tol;
   int32_t iter;         // Fortran ITER of the iteration being executed
@@ -124,6 +125,8 @@ struct KrylovState {
   int32_t maxit;
   int32_t error;        // 3001 set while running (reference sets error and falls out of the DO)
   int32_t n_hist;       // residual-history lines written (the ITERLOG lines the reference would have printed)
+  int32_t pause_verify; // 1: RESID <= TOL by the recurrence parks the loop (status = FX_ST_PAUSED) and the HOST enqueues the true-residual
+                        // check at its next poll -- the rare path costs no launches per iteration; 0: the check rides in every iteration, gated
   int32_t t_current;    // Eisenstat form: 1 = t = (D~+L)^-1 r is current; 0 = r was replaced by the true residual, refresh t (set by OP_VERIFY, cleared by OP_CG_RHO)
 };
 
@@ -260,6 +263,8 @@ struct fx_context {
   // Multicolour SSOR with iterPREmax = 1, colour-major numbering, preconditioner built from the resident values (subdomains: plus
   // the halo term H p); anything else runs the standard loop.
   bool eisenstat = false, eis_active = false;
+  bool dbg_onecolor = false; // measurement only (FX_DEBUG_ONECOLOR): the half sweeps as one launch each, dependencies ignored
+  bool eis_fuse = true;      // direction update fused into the backward sweep (FX_EIS_FUSE=0: k_cg_update_p + the plain sweep)
   int64_t values_epoch = 0;  // counts the refreshes of the SpMV layout's values
   // Placement search of the SpMV's value array.  The identical kernel on identical data runs at 1.03-1.19 ms (10.1M DOF)
   // depending on WHERE hipMalloc put the 6.5 GB value array physically: same virtual layout, same alignment, different speed

@@ -663,6 +663,87 @@ __global__ __launch_bounds__(64 * WPS) void k_eis_forward_split(int32_t slice0, 
   }
 }
 
+// Backward half of the Eisenstat iteration with the direction update fused in: ph_i = dt_i + beta ph_i (hecmw_solver_CG.f90:188-197
+// in the transformed variables; beta = 0 on the first iteration), then p_i = D~_i^-1 (ph_i - sum_{j in U(i)} U_ij p_j).  Replaces
+// k_cg_update_p + k_ssor_color<true> on the U layout: ph is read and written by the row's own lane, one pass and one launch less.
+__device__ __forceinline__ void eis_backward_finish(int slice, int lane, double s0, double s1, double s2, const double *__restrict__ alu,
+                                                    const KrylovState *__restrict__ st, const double *__restrict__ dt,
+                                                    double *__restrict__ ph, double *__restrict__ p) {
+  const size_t o = (size_t)3 * (slice * 64 + lane);
+  double u[9];
+  const size_t base = (size_t)slice * 576 + lane;
+#pragma unroll
+  for (int e = 0; e < 9; e++) u[e] = alu[base + (size_t)e * 64];
+  double h0 = dt[o], h1 = dt[o + 1], h2 = dt[o + 2];
+  if (st->iter != 1) {
+    const double beta = st->beta;
+    h0 = h0 + beta * ph[o]; h1 = h1 + beta * ph[o + 1]; h2 = h2 + beta * ph[o + 2];
+  }
+  ph[o] = h0; ph[o + 1] = h1; ph[o + 2] = h2;
+  double x1 = h0 - s0, x2 = h1 - s1, x3 = h2 - s2;
+  lusolve33_dev(u, x1, x2, x3);
+  p[o] = x1; p[o + 1] = x2; p[o + 2] = x3;
+}
+
+template <int BS>
+__global__ __launch_bounds__(BS) void k_eis_backward(int32_t slice0, int32_t slice1, const int32_t *__restrict__ pair_ptr,
+                                                     const double *__restrict__ val2, const int *__restrict__ col2,
+                                                     const double *__restrict__ alu, const KrylovState *__restrict__ st,
+                                                     const double *__restrict__ dt, double *__restrict__ ph, double *__restrict__ p,
+                                                     const int32_t *__restrict__ gate) {
+  if (gate && *gate != 0) return;
+  const int vb = xcd_block(blockIdx.x, gridDim.x);
+  const int slice = slice0 + vb * (BS / 64) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (slice >= slice1) return;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  bell_row_sweep<true>(pair_ptr[slice], pair_ptr[slice + 1], val2, col2, lane, p, s0, s1, s2);
+  eis_backward_finish(slice, lane, s0, s1, s2, alu, st, dt, ph, p);
+}
+
+template <int WPS>
+__global__ __launch_bounds__(64 * WPS) void k_eis_backward_split(int32_t slice0, int32_t slice1, const int32_t *__restrict__ pair_ptr,
+                                                                 const double *__restrict__ val2, const int *__restrict__ col2,
+                                                                 const double *__restrict__ alu, const KrylovState *__restrict__ st,
+                                                                 const double *__restrict__ dt, double *__restrict__ ph,
+                                                                 double *__restrict__ p, const int32_t *__restrict__ gate) {
+  if (gate && *gate != 0) return;
+  __shared__ double part[WPS][3][64];
+  const int slice = slice0 + blockIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int h0 = pair_ptr[slice], h1 = pair_ptr[slice + 1];
+  const int np = (h1 - h0) >> 1;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  const double2 *vbase = (const double2 *)(val2 + (size_t)h0 * 576) + lane;
+  const int2 *cbase = (const int2 *)(col2 + (size_t)h0 * 64) + lane;
+  for (int i = w; i < np; i += WPS) {
+    const int2 cc = ld_stream(cbase + (size_t)i * 64);
+    double2 a[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) a[e] = ld_stream(vbase + (size_t)i * 576 + e * 64);
+    const double *xa = p + (size_t)3 * cc.x, *xb = p + (size_t)3 * cc.y;
+    const double xv[6] = {xa[0], xa[1], xa[2], xb[0], xb[1], xb[2]};
+    bell_pair_fma(a, xv, s0, s1, s2);
+  }
+  if (((h1 - h0) & 1) && w == (np % WPS)) {
+    const double *vt = val2 + (size_t)(h0 + 2 * np) * 576 + lane;
+    const int cc = ld_stream(col2 + (size_t)(h0 + 2 * np) * 64 + lane);
+    double a[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) a[e] = ld_stream(vt + e * 64);
+    const double x[3] = {p[(size_t)3 * cc], p[(size_t)3 * cc + 1], p[(size_t)3 * cc + 2]};
+    bell_single_fma(a, x, s0, s1, s2);
+  }
+  part[w][0][lane] = s0; part[w][1][lane] = s1; part[w][2][lane] = s2;
+  __syncthreads();
+  if (w == 0) {
+    s0 = part[0][0][lane]; s1 = part[0][1][lane]; s2 = part[0][2][lane];
+#pragma unroll
+    for (int k = 1; k < WPS; k++) { s0 += part[k][0][lane]; s1 += part[k][1][lane]; s2 += part[k][2][lane]; }
+    eis_backward_finish(slice, lane, s0, s1, s2, alu, st, dt, ph, p);
+  }
+}
+
 // hp = H p: the halo-column blocks of every row against the freshly exchanged halo part of p (rows without halo blocks get 0)
 __global__ __launch_bounds__(256) void k_eis_halo(int32_t nslices, const int32_t *__restrict__ pair_ptr, const double *__restrict__ val2,
                                                   const int *__restrict__ col2, const double *__restrict__ p, double *__restrict__ hp,
@@ -1665,7 +1746,7 @@ __global__ void k_scalar(const double *__restrict__ partials, int32_t nparts, in
                          KrylovState *__restrict__ st, double *__restrict__ hist, double *__restrict__ red,
                          int phase, int32_t recompute_every) {
   // gating: VERIFY runs only when a check is pending, everything else only while running
-  if (OP == OP_VERIFY) { if (st->status != 0 || st->need_verify != 1) return; }
+  if (OP == OP_VERIFY) { if ((st->status != 0 && st->status != FX_ST_PAUSED) || st->need_verify != 1) return; }
   else if (OP != OP_BNRM2 && OP != OP_PLAIN) { if (st->status != 0) return; }
   double v0 = 0.0, v1 = 0.0;
   if (phase != 2) {
@@ -1712,11 +1793,13 @@ __global__ void k_scalar(const double *__restrict__ partials, int32_t nparts, in
       if (resid <= st->tol) {
         if (it % recompute_every == 0) { st->status = 1; return; }
         st->need_verify = 1;
+        if (st->pause_verify) st->status = FX_ST_PAUSED;  // everything enqueued behind this is a no-op until the host has run the check
         return;
       }
     } else {
       st->need_verify = 0;
       if (resid <= st->tol) { st->status = 1; return; }
+      st->status = 0;     // (was FX_ST_PAUSED when the host ran the check) the loop goes on
       st->t_current = 0;  // r now holds the true residual and the loop goes on: the Eisenstat form refreshes t from it
     }
     if (it == st->maxit) { st->error = FX_ERROR_NOCONV_MAXIT; st->status = FX_ERROR_NOCONV_MAXIT; st->iter = it + 1; return; }

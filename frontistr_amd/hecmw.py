@@ -204,6 +204,12 @@ class SolverContext:
     def precond_setup(self, hecMAT):
         _chk(lib().fx_precond_setup(self.h, _ptr(hecMAT.Iarray), _ptr(hecMAT.Rarray)))
 
+    def set_option(self, name, value):
+        """Tuning knob of the live context (the FX_* names of csrc/fx_internal.h)."""
+        f = lib().fx_set_option
+        f.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        _chk(f(self.h, name.encode(), float(value)))
+
     def tune_seconds(self):
         """Wall time of the measured tuning steps of this context's set-ups so far (placement searches, work-vector roles)."""
         f = lib().fx_tune_seconds

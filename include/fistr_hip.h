@@ -150,6 +150,10 @@ int fx_get_stats(fx_context *ctx, int64_t out[16]);
  * timing of the work vectors -- as opposed to building the preconditioner (no reference counterpart: the reference has no
  * such step; FX_TUNE_PLACEMENT=0 switches the searches off) */
 double fx_tune_seconds(fx_context *ctx);
+/* Tuning knob of a live context (kernel variants, workgroup sizes, sweep modes: the FX_* names documented in
+ * frontistr_amd/csrc/fx_internal.h; the same names are read from the environment at fx_create).  No counterpart in the
+ * reference (its equivalents are build-time choices such as the OpenMP thread count).  Unknown name: FX_ERROR_UNSUPPORTED. */
+int fx_set_option(fx_context *ctx, const char *name, double value);
 /* measured read-streaming rate (GB/s) of this device over the resident matrix values: the on-box
  * ceiling reported beside the 8 TB/s vendor peak */
 int fx_stream_ceiling(fx_context *ctx, int nrepeat, double *gbs);
