@@ -247,7 +247,12 @@ def main():
     m.Iarray[2] = a.precond
     m.Rarray[0] = 1.0e-30                          # tolerance far below reach: no early exit
     t0 = time.time()
+    want_eis_variant = (a.method == 1 and a.precond == 1)
+    if want_eis_variant:
+        ctx.set_option("FX_EISENSTAT", 1)   # set-up also stores the unfactored diagonal blocks (243 MB) the one-pass form needs
     ctx.precond_setup(m)
+    if want_eis_variant and not a.eisenstat:
+        ctx.set_option("FX_EISENSTAT", 0)   # the headline loop is the reference's recurrence as written
     t_pre = time.time() - t0
     t_tune = ctx.tune_seconds()     # of which: placement searches + role timing (candidate allocations; fresh VRAM makes them slow)
     st = ctx.stats()
@@ -269,6 +274,36 @@ def main():
         dist.all_gather(g, t)
         dt = max(float(x[0]) for x in g)
         devices_used = len(set(int(x[1]) for x in g))
+
+    # Named variants in the same line: CG + SSOR in Eisenstat's one-pass form on the SAME context, data and
+    # placement, timed exactly like the headline (W untimed + K timed iterations between barriers, max over ranks).
+    variants = {}
+    if want_eis_variant and not a.eisenstat:
+        ctx.set_option("FX_EISENSTAT", 1)
+        ctx.krylov_begin(m)
+        ctx.krylov_steps(a.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        it_v, status_v, resid_v = ctx.krylov_steps(a.steps)
+        barrier()
+        dt_v = time.perf_counter() - t0
+        active = bool(ctx.stats()["eisenstat"])
+        ctx.set_option("FX_EISENSTAT", 0)
+        if world > 1:
+            tv = torch.tensor([dt_v], dtype=torch.float64)
+            gv = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(gv, tv)
+            dt_v = max(float(x[0]) for x in gv)
+        if active and status_v == 0 and it_v == a.warmup + a.steps + 1:
+            # bytes of one iteration in this form: L and U once (values + column ids), the diagonal factors in both sweeps, the
+            # diagonal blocks in the forward sweep and in the update, 22 vector passes
+            eis_bytes = 76 * (st["L_blocks"] + st["U_blocks"]) + 4 * 72 * N + 22 * 24 * N
+            variants["eisenstat"] = {
+                "what": "CG + multicolour SSOR(1) in Eisenstat's one-pass form (opt-in FX_EISENSTAT=1: same iterates to rounding, matrix streamed once per iteration)",
+                "it_per_s": world * a.steps / dt_v, "ms_per_step": 1e3 * dt_v / a.steps, "bytes": eis_bytes,
+                "achieved_GBs": eis_bytes / (dt_v / a.steps) / 1e9, "frac": eis_bytes / (dt_v / a.steps) / 1e9 / HBM_PEAK_GBS,
+                "resid_after_steps": resid_v,
+            }
 
     # roofline of the dominant kernel, timed live with HIP events on the solver stream: the variant the timed loop
     # launches (CG: SpMV with the fused p.q partial; BiCGSTAB: the plain product)
@@ -338,6 +373,7 @@ def main():
                     "note": "precond_setup = ordering + colouring + layouts + factors; placement_tuning = timing candidate allocations "
                             "of the value arrays (optional, FX_TUNE_PLACEMENT=0 off; ~0.2 s per candidate when the driver clears fresh VRAM)"},
         "resid_after_steps": resid,
+        "variants": variants,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cores = host_cores()     # every core this process may run on (affinity mask capped by the cgroup quota)

@@ -97,12 +97,6 @@ struct SsorDev {
   double *zs = nullptr;              // private sweep vector, 3*nslots, colour-major
   double *zb = nullptr;              // dataflow sweeps: the backward sweep's vector (zs holds the forward one), 3*nslots
   double *lu_D = nullptr, *lu_AL = nullptr, *lu_AU = nullptr;  // ILU(0): factor values in the reference CSR layout
-  // ILU(0) chain sweeps (FX_DATAFLOW=3, k_tri_chain): chains of consecutive natural rows, two visiting orders, natural-order sweep vectors
-  bool chain = false;
-  int32_t ch_nF = 0, ch_nB = 0;                                  // chains (units) of the forward / backward sweep
-  int32_t *ch_startF = nullptr, *ch_startB = nullptr;            // unit u covers rows [start[u], start[u + 1])
-  int32_t *ch_ordF = nullptr, *ch_ordB = nullptr;                // visiting orders (unit ids)
-  double *ch_zf = nullptr, *ch_zb = nullptr;
   std::vector<int32_t> slot_start;   // ILU(0): first slot of each level (ncolor+1)
   int32_t max_row_blocks = 0;        // ILU(0): largest number of off-diagonal blocks in a row (<= 32: lane-per-block factorisation)
   std::vector<int32_t> perm;         // new -> old (1-based), as the reference's perm(:)
@@ -115,6 +109,7 @@ struct DiagDev {
 };
 
 // Scalars of the Krylov loops, resident on the device; the host only polls `status`.
+#define FX_DF_RETRY (-77)  // internal: a dataflow sweep timed out, the context switched to df_mode 0, redo the work
 #define FX_ST_PAUSED 2  // KrylovState::status: waiting for the host to enqueue the true-residual check (hecmw_solver_CG.f90:259-266)
 struct KrylovState {
   double rho, rho1, beta, c1, alpha, omega, c2, cg0, cg1, dnrm2, bnrm2, resid, tol;
@@ -213,7 +208,12 @@ struct fx_context {
   // host copies of the profile (ordering, conversion maps)
   std::vector<int32_t> h_indexL, h_itemL, h_indexU, h_itemU;
   // preconditioner
-  int precond_kind = 0;  // 0 none, 1 SSOR, 3 DIAG, 10 ILU0
+  int precond_kind = 0;  // 0 none, 1 SSOR (multicolour), 3 DIAG, 10 ILU0, 11 SSOR in the natural order (level-scheduled like ILU0)
+  // PRECOND = 1 / 2 in the reference is TWO preconditioners: with one OpenMP thread the natural-order block Gauss-Seidel, with more
+  // the RCM + multicolour ordering (hecmw_precond_SSOR_33.f90:93-114; 143 vs 204 iterations on SURVEY section 0's cube).  The GPU
+  // default is the multicolour one (bandwidth-bound colour sweeps); FX_SSOR_NATURAL=1 / fx_set_option selects the other, whose
+  // sweeps run level by level through the dataflow launch of ILU(0) (latency-bound: 1,044 levels at 150^3 nodes).
+  bool ssor_natural = false;
   DiagDev diag;
   SsorDev ssor;
   bool precond_valid = false;
@@ -231,12 +231,15 @@ struct fx_context {
   // part of the mesh next to each other), so the x entries a region gathers stay in L2 across its colours.  The data
   // layout is untouched; only the block -> slice map changes.  FX_SPMV_SPATIAL=0: ascending slices.
   bool spmv_spatial = true;
-  // Colours / ILU levels with at most this many slices run the wave-split sweep (k_ssor_color_split, split_wps waves
-  // per slice): latency-bound launches.  FX_SPLIT_MAX_SLICES (0 = off) / FX_SPLIT_WPS (2, 4, 8; 0 = auto) override.
-  // Measured at 10.1M DOF (same process): SSOR apply 1.46-1.49 -> 1.415 ms with 4 waves per slice on the 12 small
-  // colours (8 waves: 1.44; all colours split: 1.41); ILU(0) apply (1044 levels) 19.9 -> 13.9 ms with 4 and 11.9 ms
-  // with 8 waves per slice, 10.7 ms with the diagonal factor prefetched (BiCGSTAB + ILU(0) 24 -> 43 it/s).  Auto: 8 for ILU(0) levels, 4 for SSOR colours.
-  int split_max_slices = 2048;
+  // The wave-split sweep (k_ssor_color_split, split_wps waves per slice: each wave issues all the loads of its block pairs at
+  // once, partial sums meet in LDS in a fixed order) hides latency by occupancy (64 VGPRs, 8 waves per SIMD) instead of the
+  // software pipeline of k_ssor_color (174 VGPRs, 2 waves per SIMD).  Round 1-2: used for latency-bound launches only (colours /
+  // ILU levels of <= 2048 slices): SSOR apply 1.46-1.49 -> 1.415 ms, ILU(0) level sweeps 19.9 -> 10.7 ms.  Round 3, same context
+  // (scripts/r3/ab_opts.py): EVERY colour wave-split 1.502 -> 1.478 ms per apply, Eisenstat iteration 1.918 -> 1.871 ms; forcing the
+  // pipelined kernel to 3 waves per SIMD (__launch_bounds__(BS, 3): 168 VGPRs + 6-8 spills) 1.47 -> 1.58 ms.  So the default is
+  // "all colours"; FX_SPLIT_MAX_SLICES brings the pipelined kernel back for larger colours, FX_SPLIT_WPS (2, 4, 8; 0 = auto:
+  // 8 for ILU(0) levels, 4 for SSOR colours) sets the waves per slice.
+  int split_max_slices = 1 << 30;
   int split_wps = 0;
   // Dataflow triangular sweeps (k_tri_dataflow): one persistent launch per apply, rows synchronised through
   // sentinel-tagged data instead of one launch per colour / level.  FX_DATAFLOW=0 off, 1 (default) ILU(0) levels,
@@ -250,6 +253,10 @@ struct fx_context {
   // between polls 4.9-5.3): 2,088 dependent hand-offs of ~2.3 us each -- the polls of the waiting workgroups compete
   // with the frontier's hand-offs, so fewer pollers and fewer re-read entries are faster.
   int df_mode = 1, df_grid = 0, df_wps = 8, df_poll = 1, df_sleep = 2;
+  int df_grid_max[3] = {128, 128, 128};  // co-resident workgroups of k_tri_dataflow<2 / 4 / 8 waves> (occupancy query at fx_create)
+  int df_grid_last = 0;       // workgroups of the last dataflow launch (after the co-residency clamp)
+  bool dbg_df_fail = false;   // test hook (FX_DEBUG_DF_FAIL): the dataflow launches report a timeout at once
+  int df_fallbacks = 0;       // times a timed-out dataflow sweep made this context fall back to the launch-per-level sweeps (fx_get_stats)
   int32_t *df_err = nullptr;  // device: raised by a sweep whose bounded spin ran out
   // software-pipelined row loop (2-deep: values + gathers of pair i+1 and ids of pair i+2 in flight while pair i
   // is multiplied; 116 VGPRs, 4 waves/SIMD).  Measured on MI355X at 10.1M DOF with the final layout (odd-tail BELL,
@@ -272,12 +279,6 @@ struct fx_context {
   // candidate allocations are filled and timed (3 SpMV launches each), the fastest is kept, the others are released.
   // Large systems only (>= tune_min_slices), once per symbolic build, bounded by free device memory.  FX_TUNE_PLACEMENT=0 off.
   bool layout_device = true;        // BELL source maps built by k_bell_count / k_bell_map (FX_LAYOUT_DEVICE=0: host threads)
-  int32_t ch_hop = 12;              // chain sweeps: memory hand-off priced in row steps by the set-up's start-time estimate (FX_CH_HOP)
-  int32_t ch_maxlen = 512;          // chain sweeps: longest chain handled as one unit (FX_CH_MAXLEN)
-  int32_t ch_w = 8;                 // chain sweeps: rows between the issue of a row's loads and its step (4, 6 or 8; FX_CH_W)
-  int32_t ch_ahead = 10;            // chain sweeps: a segment starts when the row this many steps in has its outside operands (FX_CH_AHEAD, 0: at once)
-  int32_t ch_grid_auto = 256;       // n_cu x resident workgroups of k_tri_chain per CU
-  int32_t ch_grid = 0;              // chain sweeps: workgroups (0: as many as are co-resident, FX_CH_GRID)
   int32_t mc_batch = 32;            // rounds of the device multicolouring between two looks at the queue length by the host (FX_MC_BATCH)
   int32_t mc_device_min = 100000;   // block rows from which the multicolouring of the SSOR set-up runs on the device (FX_MC_DEVICE_MIN)
   bool val2_pow2 = true;            // BELL value arrays of a gigabyte or more: ask hipMalloc for the next power of two -- ONE block of the driver's allocator, the fast placement class (FX_VAL2_POW2=0: the exact size)
@@ -322,6 +323,7 @@ struct fx_context {
   hipGraphExec_t g_normal = nullptr, g_recompute = nullptr;
   // communication
   int rank = 0, nranks = 1;
+  int view_petot = 1;        // PETOT of the comm view the profile came with (require_transport)
   int32_t nn_internal = 0;
   void *nccl = nullptr;
   // host-staged communication hooks (testing / non-RCCL transports): see fx_comm_set_host_callbacks

@@ -83,7 +83,7 @@ static int hk_prepare(fx_context *c, int maxit, double tol, int extra) {
   for (int k = 0; k < 8; k++) HIP_TRY(hipMemsetAsync(c->W[k], 0, (size_t)c->wlen * 8, c->stream));
   if (ensure_extra(c, extra)) return FX_ERROR_RUNTIME;
   HIP_TRY(hipMemsetAsync(c->extra, 0, (size_t)extra * c->wlen * 8, c->stream));
-  if (c->precond_kind == 1 || c->precond_kind == 10)
+  if (c->precond_kind == 1 || level_sched(c))
     HIP_TRY(hipMemsetAsync(c->ssor.zs, 0, (size_t)3 * c->ssor.nslots * 8, c->stream));
   return 0;
 }

@@ -875,6 +875,8 @@ static int nn_solve(fx_context *c, const fx_matrix_view *m, const fx_comm_view *
                     fx_solve_info *info, double *hist, int32_t hist_len) {
   HIP_TRY(hipSetDevice(c->device));
   if (m->NDOF < 1 || m->NDOF > 6) { g_fx_error = "NDOF must be 1..6"; return FX_ERROR_UNSUPPORTED; }
+  c->view_petot = cm ? std::max(1, (int)cm->PETOT) : 1;
+  if (require_transport(c, "fx_solve")) return FX_ERROR_RUNTIME;
   const int maxit = Iarray[0], precond = Iarray[2], method2 = Iarray[7], iterpremax = Iarray[4];
   int method = Iarray[1];
   const bool scaling = Iarray[6] != 0;  // SCALING=YES

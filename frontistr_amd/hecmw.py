@@ -262,8 +262,12 @@ class SolverContext:
         keys = ("N", "NP", "NPL", "NPU", "M_pairs", "M_blocks", "M_slices", "ncolor", "L_pairs", "L_blocks",
                 "U_pairs", "U_blocks", "ssor_slices", "wg_interior", "wg_boundary", "eisenstat")
         st = {k: int(out[i]) for i, k in enumerate(keys)}
-        st["chain_sweeps"] = (st["eisenstat"] >> 1) & 1
-        st["eisenstat"] &= 1
+        v = st["eisenstat"]
+        st["ssor_natural"] = (v >> 1) & 1     # PRECOND = 1 resident as the natural-order (level-scheduled) SSOR
+        st["df_mode"] = (v >> 2) & 3            # 0: one launch per colour / level; 1: dataflow ILU(0) sweeps; 2: also SSOR
+        st["df_fallbacks"] = (v >> 8) & 0xFF    # timed-out dataflow sweeps that made the context fall back to df_mode 0
+        st["df_grid"] = v >> 16                 # workgroups of the last dataflow launch (after the co-residency clamp)
+        st["eisenstat"] = v & 1
         return st
 
     def krylov_begin(self, hecMAT):

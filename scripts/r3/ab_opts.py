@@ -12,6 +12,7 @@ if "--method" in args:
 if "--precond" in args:
     i = args.index("--precond"); precond = int(args[i + 1]); del args[i:i + 2]
 from frontistr_amd import hecmw as hip
+if os.environ.get('FX_LIBPATH'): hip.LIBPATH = os.environ['FX_LIBPATH']
 from frontistr_amd.mesh import CubeMesh
 n = int(os.environ.get("AB_N", "149"))
 mesh = CubeMesh(n)

@@ -2,6 +2,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from frontistr_amd import hecmw as hip
+if os.environ.get('FX_LIBPATH'): hip.LIBPATH = os.environ['FX_LIBPATH']
 from frontistr_amd.mesh import CubeMesh
 mesh = CubeMesh(int(os.environ.get("AB_N", "149")))
 hm = hip.hecmwST_local_mesh(n_node=mesh.n_node); hm.elem_node_item = mesh.conn.ravel()

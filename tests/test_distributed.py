@@ -75,11 +75,18 @@ def check_against_serial(res, ser, meth):
     assert np.all(np.abs(h0[:k] - ser["history"][:k]) <= 1e-9 * ser["history"][:k])
 
 
-@pytest.mark.parametrize("world,m", [(2, 5), (4, 4)])
+DIMS = {2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}    # bench.py:decomposition -- the 8-rank case is the driver's SCALE run
+
+
+@pytest.mark.parametrize("world,m", [(2, 5), (4, 4), (8, 3), (8, 4)])
 def test_partition_tables_are_consistent(world, m):
     from frontistr_amd.partition import cube_subdomain
-    dims = {2: (2, 1, 1), 4: (2, 2, 1)}[world]
+    dims = DIMS[world]
     subs = [cube_subdomain(m, dims, r) for r in range(world)]
+    if world == 8:      # every rank of the 2x2x2 split has 7 neighbours -- 3 faces, 3 edges, 1 corner
+        for s in subs:
+            sizes = sorted(int(s.import_index[q + 1] - s.import_index[q]) for q in range(len(s.neighbor_pe)))
+            assert len(s.neighbor_pe) == 7 and sizes == [1] + [m] * 3 + [m * m] * 3, (s.rank, sizes)
     owner = {}
     for s in subs:
         assert s.nn_internal == m ** 3
@@ -98,12 +105,30 @@ def test_partition_tables_are_consistent(world, m):
         assert (s.conn.min(axis=1) <= s.nn_internal).all() and s.conn.max() <= s.n_node
 
 
-@pytest.mark.parametrize("world,m,meth", [(2, 5, 1), (4, 4, 1), (2, 5, 2)])
+@pytest.mark.parametrize("world,m,meth", [(2, 5, 1), (4, 4, 1), (2, 5, 2), (8, 3, 1), (8, 3, 2)])
 def test_distributed_oracle_block_jacobi_equals_serial(oracle, tmp_path, world, m, meth):
-    dims = {2: (2, 1, 1), 4: (2, 2, 1)}[world]
+    dims = DIMS[world]
     res = run_world("oracle", world, m, meth, 3, tmp_path)
     ser = serial_reference(oracle, dims, m, meth, 3)
     check_against_serial(res, ser, meth)
+
+
+@pytest.mark.parametrize("meth,pc", [(1, 1), (2, 10)])
+def test_oracle_fixture_of_the_2x2x2_decomposition(oracle, tmp_path, meth, pc):
+    """bench.py's 8-rank decomposition through the oracle with the LOCALIZED preconditioners (SSOR, ILU(0): halo columns dropped,
+    hecmw_matrix_reorder.f90:50): every rank the same count, the field of the undecomposed cube, and the iteration count /
+    history head the -m gpu test of the same decomposition compares with (tests/golden/dist_2x2x2_oracle.json) still current."""
+    import json
+    res = run_world("oracle", 8, 6, meth, pc, tmp_path)
+    ser = serial_reference(oracle, (2, 2, 2), 6, meth, pc)
+    xs = ser["X"].reshape(-1, 3)
+    for r in res:
+        assert int(r["code"]) == 0
+        assert np.abs(r["X"].reshape(-1, 3) - xs[r["gid"]]).max() < 2e-7 * np.abs(xs).max()
+    assert len({int(r["it"]) for r in res}) == 1
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "dist_2x2x2_oracle.json")))["m6_meth%d_pc%d" % (meth, pc)]
+    assert int(res[0]["it"]) == gold["iter"]
+    assert np.allclose(res[0]["hist"][:10], gold["history_head"], rtol=1e-12, atol=0.0)
 
 
 def test_distributed_oracle_localized_ssor_converges(oracle, tmp_path):

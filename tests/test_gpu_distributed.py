@@ -428,3 +428,84 @@ def test_eisenstat_form_on_subdomains(tmp_path, monkeypatch, world, m):
         k = min(10, len(a["hist"]), len(b["hist"]))
         assert np.all(np.abs(a["hist"][:k] - b["hist"][:k]) <= 1e-9 * a["hist"][:k])
         assert np.abs(a["X"] - b["X"]).max() < 1e-8 * np.abs(a["X"]).max()
+
+
+@pytest.mark.parametrize("meth,pc", [(1, 1), (2, 10), (1, 3)])
+def test_bench_decomposition_2x2x2_eight_contexts(oracle, meth, pc):
+    """bench.py's own 8-rank decomposition (bench.py:decomposition -> cube_subdomain(m, (2, 2, 2), r): 7 neighbours per rank,
+    face / edge / corner messages; hecmw_solver_SR_33.F90:42-124) on the one GPU of the test box: 8 contexts + 8
+    threads, CG + SSOR and BiCGSTAB + ILU(0) (and CG + block-Jacobi, which must equal the serial solve).  The interior / boundary
+    overlap of the SpMV on and off must be BIT-identical on every rank; the localized preconditioners must give the field of the
+    undecomposed cube and the iteration count of the distributed CPU oracle (gloo, world 8)."""
+    from frontistr_amd import hecmw as hip
+    from frontistr_amd.partition import cube_subdomain
+    from thread_world import ThreadWorld
+    m = 6
+    subs = [cube_subdomain(m, (2, 2, 2), r) for r in range(8)]
+
+    def run(overlap):
+        def rank_main(r, world):
+            sub = subs[r]
+            hm = sub.hecmesh(hip)
+            hm.elem_node_item = sub.conn.ravel()
+            mat = hip.hecmw_mat_con(hm, hip.hecmwST_matrix())
+            ctx = hip.SolverContext(device=0)
+            ctx.set_option("FX_OVERLAP", overlap)
+            cbs = world.callbacks(r, sub)
+            assert hip.lib().fx_comm_set_host_callbacks(ctx.h, r, 8, cbs[0], cbs[1], None) == 0
+            ctx.upload(mat, hm, what=hip.FX_UP_PROFILE)
+            ctx.assemble_c3d8(sub.coord, sub.conn, 210000.0, 0.3, elemopt=1, load=sub.load(), bc=sub.dirichlet())
+            mat.Iarray[0] = 10000; mat.Iarray[1] = meth; mat.Iarray[2] = pc
+            code = ctx.solve_resident(mat)
+            ctx.download_x(mat)
+            st = ctx.stats()
+            res = dict(X=mat.X.copy(), it=ctx.info.iterations, hist=ctx.history.copy(), code=code, gid=sub.global_id,
+                       conv=int(mat.Iarray[80]), wg=(st["wg_interior"], st["wg_boundary"]), nnb=len(sub.neighbor_pe))
+            ctx.close()
+            return res
+        return ThreadWorld(8).run(rank_main)
+
+    ser, ovl = run(0), run(1)
+    for a, b in zip(ser, ovl):
+        assert a["code"] == b["code"] == 0 and a["conv"] == b["conv"] == 1 and a["nnb"] == 7
+        assert a["it"] == b["it"] and np.array_equal(a["hist"], b["hist"]) and np.array_equal(a["X"], b["X"])
+        assert b["wg"][1] > 0
+    assert len(set(int(r["it"]) for r in ovl)) == 1
+    sref = serial_reference(oracle, (2, 2, 2), m, meth, pc)
+    if pc == 3:
+        check_against_serial(ovl, sref, meth)
+        return
+    xs = sref["X"].reshape(-1, 3)
+    for r in ovl:
+        assert np.abs(r["X"].reshape(-1, 3) - xs[r["gid"]]).max() < 2e-7 * np.abs(xs).max()
+    # the same decomposition through the CPU oracle (8 gloo ranks): tests/golden/dist_2x2x2_oracle.json, kept current by
+    # tests/test_distributed.py::test_oracle_fixture_of_the_2x2x2_decomposition (8 more processes may not run beside the GPU contexts)
+    import json, os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "dist_2x2x2_oracle.json")))["m%d_meth%d_pc%d" % (m, meth, pc)]
+    it_o = gold["iter"]
+    tol = 1 if meth == 1 else max(2, int(0.15 * it_o))
+    assert abs(int(ovl[0]["it"]) - it_o) <= tol, (ovl[0]["it"], it_o)
+    h, ho = ovl[0]["hist"], np.array(gold["history_head"])
+    assert np.all(np.abs(h[:len(ho)] - ho) <= 1e-8 * ho)
+
+
+def test_library_refuses_a_decomposed_view_without_transport():
+    """A raw C-ABI caller that passes comm->PETOT > 1 but never set up a transport would get rank-local dot products: the library
+    says so instead (the reference would be inside MPI_Allreduce here, hecmw_comm_f.F90:346-379)."""
+    from frontistr_amd import hecmw as hip
+    from frontistr_amd.partition import cube_subdomain
+    sub = cube_subdomain(4, (2, 1, 1), 0)
+    hm = sub.hecmesh(hip)
+    hm.elem_node_item = sub.conn.ravel()
+    mat = hip.hecmw_mat_con(hm, hip.hecmwST_matrix())
+    ctx = hip.SolverContext(device=0)
+    ctx.upload(mat, hm, what=hip.FX_UP_PROFILE)
+    ctx.assemble_c3d8(sub.coord, sub.conn, 210000.0, 0.3, elemopt=1, load=sub.load(), bc=sub.dirichlet())
+    mat.Iarray[0] = 100; mat.Iarray[1] = 1; mat.Iarray[2] = 3
+    with pytest.raises(hip.HecmwSolverError) as ei:
+        ctx.solve_resident(mat)
+    assert "PETOT = 2" in str(ei.value) and "no transport" in str(ei.value)
+    with pytest.raises(hip.HecmwSolverError) as ei:
+        ctx.krylov_begin(mat)
+    assert "no transport" in str(ei.value)
+    ctx.close()

@@ -728,54 +728,6 @@ def test_dataflow_sweeps_equal_launch_per_level_sweeps_bitwise(hip, deck, pc, mo
     assert relerr(ref[2], ref[4]) < 1e-13 and relerr(ref[8], ref[4]) < 1e-13
 
 
-@pytest.mark.parametrize("deck", DECKS + ["cube20"])
-def test_chain_sweeps_equal_level_sweeps(hip, oracle, deck, monkeypatch):
-    """k_tri_chain (FX_DATAFLOW=3, opt-in: a workgroup walks a chain of consecutive rows in the reference's sequential order -- one
-    wave substitutes, two prepare operands ahead of it, one publishes; dependencies inside the chain through registers / LDS,
-    the others through sentinel-tagged memory; chains dealt in the order of the set-up's start-time estimate) against the
-    launch-per-level sweeps on the same ILU(0) factors: z = M^-1 r equal to rounding (the sum over a row's blocks is a
-    butterfly instead of the sequential loop), repeatable bit for bit, with one workgroup, with a few and with as many as fit,
-    chains cut short and chunked, several pipeline depths, with and without the start-up probe."""
-    if deck == "cube20":
-        from frontistr_amd.mesh import CubeMesh
-        mesh = CubeMesh(20, skew=0.03)
-        A = oracle.assemble(1, mesh.coord, mesh.conn, 210000.0, 0.3, bc=mesh.dirichlet(), load=mesh.load())
-    else:
-        A = golden_matrix(load_golden(deck))
-    r = np.cos(0.11 * np.arange(3 * A.NP) + 0.3)
-    keys = ("FX_DATAFLOW", "FX_CH_GRID", "FX_CH_HOP", "FX_CH_MAXLEN", "FX_CH_W", "FX_CH_AHEAD")
-
-    def apply(env):
-        for k in keys:
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        m = to_hecmat(hip, A)
-        m.Iarray[2] = 10
-        ctx = hip.SolverContext()
-        ctx.upload(m)
-        ctx.precond_setup(m)
-        z = ctx.precond_apply(r)
-        ctx.precond_apply(np.sin(1.7 * r) + 0.5)
-        z2 = ctx.precond_apply(r)
-        assert ctx.stats()["chain_sweeps"] == (1 if env.get("FX_DATAFLOW") == "3" else 0)   # rows of up to 16 blocks: all decks here
-        ctx.close()
-        assert np.array_equal(z, z2)
-        return z[:3 * A.N]
-
-    lev = apply(dict(FX_DATAFLOW="0"))
-    assert np.all(np.isfinite(lev))
-    first = {}
-    for grid, hop, extra in (("1", "12", {}), ("3", "0", dict(FX_CH_MAXLEN="7", FX_CH_W="4")), ("7", "40", dict(FX_CH_MAXLEN="100", FX_CH_W="6")),
-                             ("2", "5", dict(FX_CH_MAXLEN="7")), ("0", "12", dict(FX_CH_AHEAD="0")), ("0", "12", {})):
-        ch = apply(dict(FX_DATAFLOW="3", FX_CH_GRID=grid, FX_CH_HOP=hop, **extra))
-        assert relerr(ch, lev) < 1e-12, (grid, hop, extra)
-        # who waits for whom and how deep the pipeline is never changes an operand; where a chain is cut does change how the
-        # block on the previous row enters the sum (registers of the chain wave, or the butterfly): rounding
-        ref = first.setdefault(extra.get("FX_CH_MAXLEN", ""), ch)
-        assert np.array_equal(ch, ref), (grid, hop, extra)
-
-
 @pytest.mark.parametrize("k", [0, 1, 3, 4, 5, 7, 8])
 def test_divergence_retries_against_reference_golden(hip, oracle, k):
     """The retry loop of hecmw_solve_iterative on the GPU against real reference runs (tests/golden/retry.npz): same outcome
@@ -942,3 +894,102 @@ def test_device_built_layouts_equal_host_built(hip, oracle, deck, pc, monkeypatc
     a, b = out["1"], out["0"]
     assert a[5] == b[5] and a[2] == b[2] == 0
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+
+
+def test_dataflow_grid_is_clamped_to_the_co_resident_bound(hip):
+    """FX_DF_GRID beyond what the occupancy query admits would break the progress argument of k_tri_dataflow (every workgroup
+    resident at once): the launch is clamped, results equal the launch-per-level sweeps bit for bit."""
+    from frontistr_amd.mesh import CubeMesh
+    mesh = CubeMesh(24)                      # 15,625 rows = 245 slices: more slices than the default grid of 128 workgroups
+    hm = hip.hecmwST_local_mesh(n_node=mesh.n_node)
+    hm.elem_node_item = mesh.conn.ravel()
+    m = hip.hecmw_mat_con(hm, hip.hecmwST_matrix())
+    ctx = hip.SolverContext()
+    ctx.upload(m, what=hip.FX_UP_PROFILE)
+    ctx.assemble_c3d8(mesh.coord, mesh.conn, 210000.0, 0.3, elemopt=1, load=mesh.load(), bc=mesh.dirichlet())
+    m.Iarray[1] = 2; m.Iarray[2] = 10
+    ctx.precond_setup(m)
+    r = np.cos(0.37 * np.arange(3 * m.NP))
+    ctx.set_option("FX_DATAFLOW", 0)
+    z0 = ctx.precond_apply(r)
+    ctx.set_option("FX_DATAFLOW", 1)
+    ctx.set_option("FX_DF_GRID", 1 << 20)
+    z1 = ctx.precond_apply(r)
+    st = ctx.stats()
+    assert 0 < st["df_grid"] <= 245 and st["df_grid"] <= 256 * 8          # slices, and CUs x 8 workgroups at most
+    assert st["df_fallbacks"] == 0 and np.array_equal(z0, z1)
+    ctx.close()
+
+
+@pytest.mark.parametrize("meth", [2, 4])
+def test_timed_out_dataflow_sweep_falls_back_to_level_sweeps(hip, oracle, meth):
+    """a dataflow sweep whose bounded wait runs out (workgroups not co-resident on a shared device) must not fail
+    the solve or leave sentinel-contaminated vectors behind.  FX_DEBUG_DF_FAIL makes every dataflow launch report a timeout:
+    the context switches to the launch-per-level sweeps, the solve (device state machine: BiCGSTAB; host-driven recurrence:
+    GPBiCG) and the host-visible apply are redone -- same answers as a context that never used the dataflow sweeps."""
+    g = load_golden("cube4")
+    A = golden_matrix(g)
+    r = np.cos(0.11 * np.arange(3 * A.NP) + 0.3)
+    out = {}
+    for tag in ("level", "fail"):
+        m = to_hecmat(hip, A)
+        m.Iarray[0] = 1000; m.Iarray[1] = meth; m.Iarray[2] = 10
+        ctx = hip.SolverContext()
+        ctx.set_option("FX_DATAFLOW", 0 if tag == "level" else 1)
+        ctx.upload(m)
+        ctx.precond_setup(m)
+        if tag == "fail":
+            ctx.set_option("FX_DEBUG_DF_FAIL", 1)
+        z = ctx.precond_apply(r)
+        if tag == "fail":
+            assert ctx.stats()["df_fallbacks"] == 1 and ctx.stats()["df_mode"] == 0
+            ctx.set_option("FX_DATAFLOW", 1)          # and once more inside a solve
+        code = ctx.solve_resident(m)
+        ctx.download_x(m)
+        out[tag] = (z.copy(), m.X.copy(), ctx.info.iterations, code, ctx.stats()["df_fallbacks"], ctx.stats()["df_mode"])
+        ctx.close()
+    assert np.array_equal(out["level"][0], out["fail"][0])
+    assert np.array_equal(out["level"][1], out["fail"][1]) and out["level"][2] == out["fail"][2] and out["fail"][3] == 0
+    assert out["fail"][4] == 2 and out["fail"][5] == 0 and out["level"][4] == 0
+
+
+@pytest.mark.parametrize("deck", DECKS)
+@pytest.mark.parametrize("meth", [1, 2])
+def test_natural_order_ssor_matches_the_serial_reference(hip, oracle, deck, meth):
+    """PRECOND = 1 in a serial / flat-MPI build of the reference is the NATURAL-order block Gauss-Seidel (nthreads == 1,
+    hecmw_precond_SSOR_33.f90:93-101, sweeps :300-410), a different preconditioner from the multicolour one (143 vs 204
+    iterations on SURVEY section 0's cube).  FX_SSOR_NATURAL=1 runs it on the GPU: the dependency levels of ILU(0), the
+    original L / U blocks, one dataflow launch per apply.  Against the reference's own 1-thread golden runs (sol_m*_p1_t1):
+    the apply to 1e-12 of the oracle's, CG count +-1 / BiCGSTAB 15 %, field 1e-8 / 1e-7, first history lines to the printed digits."""
+    g = load_golden(deck)
+    A = golden_matrix(g)
+    m = to_hecmat(hip, A)
+    m.Iarray[0] = 10000; m.Iarray[1] = meth; m.Iarray[2] = 1
+    ctx = hip.SolverContext()
+    ctx.set_option("FX_SSOR_NATURAL", 1)
+    ctx.upload(m)
+    ctx.precond_setup(m)
+    r = np.cos(0.11 * np.arange(3 * A.NP) + 0.3)
+    z = ctx.precond_apply(r)
+    zo = oracle.Precond(A, 1, nthreads=1).apply(r)
+    assert relerr(z[:3 * A.N], zo[:3 * A.N]) < 1e-12
+    st = ctx.stats()
+    assert st["ssor_natural"] == 1 and st["df_mode"] == 1
+    code = hip.hecmw_solve(None, m, ctx=ctx)
+    tag = "sol_m%d_p1_t1_" % meth
+    it_ref, h_ref, x_ref = int(g[tag + "iter"]), g[tag + "hist"], g[tag + "X"]
+    if deck == "exA_A361" and meth == 2 and code == hip.HECMW_SOLVER_ERROR_NOCONV_MAXIT:
+        assert_documented_breakdown(hip, ctx, m, 10000)
+        ctx.close()
+        return
+    assert code == 0 and m.Iarray[80] == 1
+    check_solve(ctx.info, ctx.history, m.X, it_ref, h_ref, x_ref, meth, printed=True, whole=(deck != "exA_A361"))
+    # ... and it is NOT the multicolour preconditioner: that one needs a different number of iterations on these decks
+    it_mc = int(g["sol_m%d_p1_t4_iter" % meth])
+    if meth == 1 and deck != "exA_A361":
+        assert it_mc != it_ref and abs(ctx.info.iterations - it_ref) < abs(ctx.info.iterations - it_mc)
+    # the level sweeps (FX_DATAFLOW=0) give the same bits as the one dataflow launch
+    ctx.set_option("FX_DATAFLOW", 0)
+    z0 = ctx.precond_apply(r)
+    assert np.array_equal(z0, z)
+    ctx.close()
