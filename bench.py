@@ -254,7 +254,8 @@ def main():
     if want_eis_variant and not a.eisenstat:
         ctx.set_option("FX_EISENSTAT", 0)   # the headline loop is the reference's recurrence as written
     t_pre = time.time() - t0
-    t_tune = ctx.tune_seconds()     # of which: placement searches + role timing (candidate allocations; fresh VRAM makes them slow)
+    t_tune = ctx.tune_seconds()     # of which: placement checks + role timing of the work vectors
+    placement = ctx.placement_report()
     st = ctx.stats()
     N, nb = st["N"], st["M_blocks"]
 
@@ -336,7 +337,10 @@ def main():
         "value": world * a.steps / dt,
         "unit": "CG iterations/s" if world == 1 else "CG iterations/s x subdomains (%.3fM-DOF subdomain-iterations/s, summed over GPUs)" % (3 * N / 1e6),
         "global_iterations_per_s": a.steps / dt,
-        "n_gpus": comm_ranks,
+        # devices really used: equal to the rank count over RCCL (one rank per GPU); in the gloo rehearsal mode ranks SHARE devices,
+        # so such a line is not a scaling point (rehearsal_ranks says how many subdomains were time-sliced on those devices)
+        "n_gpus": comm_ranks if transport != "gloo" or world == 1 else devices_used,
+        "ranks": comm_ranks,
         "steps": a.steps,
         "warmup": a.warmup,
         "ms_per_step": 1e3 * dt / a.steps,
@@ -350,6 +354,7 @@ def main():
                         % (a.n + 1, 3 * N / 1e6, 3 * N * world / 1e6, {1: "CG", 2: "BiCGSTAB"}[a.method],
                            {1: "SSOR(1) multicolour", 3: "block-Jacobi", 10: "ILU(0) level-scheduled"}[a.precond]),
             "decomposition": "x".join(str(d) for d in decomposition(world)),
+            "rehearsal_ranks": comm_ranks if (transport == "gloo" and world > 1) else None,
             "transport": "none" if world == 1 else ("rccl (ncclCommCount=%d)" % comm_ranks if transport != "gloo" else "gloo host callbacks (rehearsal)"),
             "devices_used": devices_used,
             "ncolor": st["ncolor"],
@@ -370,8 +375,10 @@ def main():
             "iteration_GBs": (alg + prec_bytes + 480 * N) / (dt / a.steps) / 1e9,
         },
         "setup_s": {"mat_con": t_con, "assemble_ms": ms_asm, "precond_setup": t_pre - t_tune, "placement_tuning": t_tune,
-                    "note": "precond_setup = ordering + colouring + layouts + factors; placement_tuning = timing candidate allocations "
-                            "of the value arrays (optional, FX_TUNE_PLACEMENT=0 off; ~0.2 s per candidate when the driver clears fresh VRAM)"},
+                    "placement": placement,
+                    "note": "precond_setup = ordering + colouring + layouts + factors; placement_tuning = timing the first allocation of each "
+                            "value array and, only if it streams below its class, ONE second candidate (released at the end of the set-up: "
+                            "held_bytes = 0); placement.spmv.candidates = 1 means the first power-of-two request landed in the fast class"},
         "resid_after_steps": resid,
         "variants": variants,
     }

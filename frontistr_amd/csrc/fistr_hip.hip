@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <mutex>
 #include <thread>
 
 #include "fx_assemble.h"
@@ -135,11 +136,22 @@ static void parallel_for(int64_t n, F f) {
   for (auto &t : th) t.join();
 }
 
+// Losing candidates of a placement search stay allocated until the set-up that made them ends (tune_placement).  If anything
+// in this process runs out of device memory meanwhile, they go first: every context that holds some is known here.
+static std::mutex g_held_mu;
+static std::vector<fx_context *> g_held_ctx;
+static bool relieve_oom();
+
 template <class T>
 static int dev_alloc(T **p, size_t count) {
   *p = nullptr;
   if (count == 0) count = 1;
-  HIP_TRY(hipMalloc((void **)p, count * sizeof(T)));
+  hipError_t e = hipMalloc((void **)p, count * sizeof(T));
+  if (e == hipErrorOutOfMemory && relieve_oom()) {  // held candidates of a placement search released: once more
+    (void)hipGetLastError();
+    e = hipMalloc((void **)p, count * sizeof(T));
+  }
+  HIP_TRY(e);
   return 0;
 }
 template <class T>
@@ -241,9 +253,7 @@ static const FxOption g_fx_options[] = {
     {"FX_BFS_DEVICE_MIN", [](fx_context *c, double v) { c->bfs_device_min = (int)v; }},
     {"FX_MC_DEVICE_MIN", [](fx_context *c, double v) { c->mc_device_min = (int)v; }},
     {"FX_BFS_BATCH", [](fx_context *c, double v) { c->bfs_batch = std::max(1, (int)v); }},
-    {"FX_TUNE_BUDGET_MS", [](fx_context *c, double v) { c->tune_budget_s = 1e-3 * v; }},
     {"FX_VAL2_POW2", [](fx_context *c, double v) { c->val2_pow2 = (int)v != 0; }},
-    {"FX_TUNE_HOLD_GB", [](fx_context *c, double v) { c->hold_max_bytes = (size_t)(v * 1e9); }},
     {"FX_MC_BATCH", [](fx_context *c, double v) { c->mc_batch = std::max(1, (int)v); }},
     {"FX_LAYOUT_DEVICE", [](fx_context *c, double v) { c->layout_device = (int)v != 0; }},
     {"FX_PIPE_SPMV", [](fx_context *c, double v) { c->pipe_spmv = (int)v != 0; }},
@@ -259,7 +269,12 @@ static const FxOption g_fx_options[] = {
     {"FX_EISENSTAT", [](fx_context *c, double v) { c->eisenstat = (int)v != 0; }},
     {"FX_EIS_FUSE", [](fx_context *c, double v) { c->eis_fuse = (int)v != 0; }},
     {"FX_SPLIT_MAX_SLICES", [](fx_context *c, double v) { c->split_max_slices = (int)v; }},
-    {"FX_DATAFLOW", [](fx_context *c, double v) { c->df_mode = (int)v; }},
+    {"FX_DATAFLOW", [](fx_context *c, double v) {
+       c->df_mode = (int)v;
+       // leaving the dataflow sweeps on a live context: their sweep vector is full of tags, and the level sweeps multiply a padding
+       // block (value 0) with the row's own stale entry
+       if (c->ssor.zs && hipSetDevice(c->device) == hipSuccess) (void)hipMemset(c->ssor.zs, 0, (size_t)3 * c->ssor.nslots * 8);
+     }},
     {"FX_DF_GRID", [](fx_context *c, double v) { c->df_grid = (int)v; }},
     {"FX_DF_POLL", [](fx_context *c, double v) { c->df_poll = (int)v; }},
     {"FX_DF_SLEEP", [](fx_context *c, double v) { c->df_sleep = std::max(0, (int)v); }},
@@ -297,10 +312,6 @@ extern "C" int fx_create(int device, fx_context **out) {
   if (context_init(c)) {  // release whatever was created before the failing call
     fx_destroy(c);
     return FX_ERROR_RUNTIME;
-  }
-  if (const char *e = getenv("FX_DUMMY_MB")) {  // placement experiments: shifts where the allocations that follow land
-    void *dummy = nullptr;
-    (void)hipMalloc(&dummy, (size_t)atoll(e) << 20);  // kept for the life of the process on purpose
   }
   for (const FxOption &o : g_fx_options)
     if (const char *e = getenv(o.name)) o.set(c, atof(e));
@@ -346,9 +357,22 @@ static void free_matrix(fx_context *c) {
 }
 
 static void release_held(fx_context *c) {
+  std::lock_guard<std::mutex> lk(g_held_mu);
   for (void *q : c->held) (void)hipFree(q);
   c->held.clear();
   c->held_bytes = 0;
+  g_held_ctx.erase(std::remove(g_held_ctx.begin(), g_held_ctx.end(), c), g_held_ctx.end());
+}
+static bool relieve_oom() {
+  std::lock_guard<std::mutex> lk(g_held_mu);
+  bool any = false;
+  for (fx_context *h : g_held_ctx) {
+    for (void *q : h->held) { (void)hipFree(q); any = true; }
+    h->held.clear();
+    h->held_bytes = 0;
+  }
+  g_held_ctx.clear();
+  return any;
 }
 
 static void free_precond(fx_context *c) {
@@ -412,12 +436,16 @@ static size_t val2_alloc_bytes(const fx_context *c, size_t bytes) {
   while (p < bytes) p <<= 1;
   return p;
 }
-static int val2_alloc(const fx_context *c, char **base, size_t bytes) {  // the rounded request first, the exact one when memory does not allow it
+static int val2_alloc(const fx_context *c, char **base, size_t bytes, size_t *got = nullptr) {  // the rounded request first, the exact one when memory does not allow it
   *base = nullptr;
   const size_t want = val2_alloc_bytes(c, bytes);
+  if (got) *got = bytes;
   if (want > bytes) {
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > want + ((size_t)8 << 30) && hipMalloc((void **)base, want) == hipSuccess) return 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > want + ((size_t)8 << 30) && hipMalloc((void **)base, want) == hipSuccess) {
+      if (got) *got = want;
+      return 0;
+    }
     (void)hipGetLastError();
     *base = nullptr;
   }
@@ -482,9 +510,8 @@ static int bell_build2(fx_context *c, Bell &b, int32_t nslots, const std::vector
   if (dev_alloc(&b.src2, (size_t)tot * 64)) return FX_ERROR_RUNTIME;
   {
     size_t pad = 0;
-    if (const char *e = getenv("FX_VAL2_PAD")) pad = (size_t)atoll(e);
     char *base = nullptr;
-    if (val2_alloc(c, &base, (size_t)tot * 576 * 8 + pad)) return FX_ERROR_RUNTIME;
+    if (val2_alloc(c, &base, (size_t)tot * 576 * 8 + pad, &b.val2_bytes)) return FX_ERROR_RUNTIME;
     b.val2_base = base;
     b.val2 = (double *)(base + pad);
   }
@@ -535,9 +562,8 @@ static int bell_build_device(fx_context *c, Bell &b, int variant, int32_t nslots
   if (dev_alloc(&b.col2, tot * 64) || dev_alloc(&b.src2, tot * 64)) return FX_ERROR_RUNTIME;
   {
     size_t pad = 0;
-    if (const char *e = getenv("FX_VAL2_PAD")) pad = (size_t)atoll(e);
     char *base = nullptr;
-    if (val2_alloc(c, &base, tot * 576 * 8 + pad)) return FX_ERROR_RUNTIME;
+    if (val2_alloc(c, &base, tot * 576 * 8 + pad, &b.val2_bytes)) return FX_ERROR_RUNTIME;
     b.val2_base = base;
     b.val2 = (double *)(base + pad);
   }
@@ -680,87 +706,54 @@ struct TuneClock {  // wall time of the tuning steps of the set-up (fx_tune_seco
   explicit TuneClock(fx_context *cc) : c(cc), t0(now_s()) {}
   ~TuneClock() { c->tune_spent_s += now_s() - t0; }
 };
-// Placement search of a BELL value array (see fx_context::tune_tries): candidate allocations are filled (fill) and timed
-// (time_ms: one representative launch sequence, lower is better); the fastest is kept.  Candidates are held until the search
-// ends -- freeing one early would hand the same physical block to the next hipMalloc.  The search stops early once a
-// candidate streams at >= good_gbs (GB/s over `stream_bytes`).
+// Placement check of a BELL value array (fx_context::tune_tries).  Round 2 searched up to 20 candidate allocations and kept the
+// losers for the life of the context; since large value arrays are requested as ONE power-of-two block of the driver's allocator
+// (val2_alloc) the first allocation lands in the fast class four times in five, so the search is now a safety net: the first
+// allocation is timed, and only if it streams below `good_gbs` ONE more candidate is allocated, filled and timed; the faster of
+// the two is kept.  The loser stays allocated until the END of the set-up (fx_precond_setup releases it: freeing it at once would
+// hand the same physical block to the next hipMalloc of this set-up) -- nothing is held afterwards.  What happened is kept for
+// fx_placement_report.
 template <class Fill, class Time>
 static int tune_placement(fx_context *c, Bell &B, const char *what, double stream_bytes, double good_gbs, Fill fill, Time time_ms,
-                          int max_tries = 1 << 30) {
+                          PlacementReport *rep) {
   B.placed = true;
-  const int tries = std::min(c->tune_tries, max_tries);
-  if (tries <= 1 || B.nslices < c->tune_min_slices) return 0;
+  if (c->tune_tries <= 1 || B.nslices < c->tune_min_slices) return 0;
   TuneClock tclock(c);
   const size_t bytes = (size_t)B.npairs * 576 * 8;
-  std::vector<void *> cand;
-  std::vector<float> t;
-  cand.push_back(B.val2_base);
-  t.push_back(0.f);
-  int err = time_ms(&t[0]);
-  for (int k = 1; k < tries && !err; k++) {
-    if (stream_bytes / (1e-3 * *std::min_element(t.begin(), t.end())) / 1e9 >= good_gbs) break;
-    if (c->tune_cand_s >= c->tune_budget_s) break;  // a candidate costs 7-10 ms when hipMalloc hands out recycled memory, 60-350 ms when the driver has to clear fresh VRAM
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + (bytes >> 1) + ((size_t)4 << 30)) break;  // keep headroom
-    char *base = nullptr;
-    const double w0 = now_s();
-    if (hipMalloc((void **)&base, val2_alloc_bytes(c, bytes)) != hipSuccess) { (void)hipGetLastError(); break; }
-    const double w1 = now_s();
-    B.val2_base = base;
-    B.val2 = (double *)base;
-    cand.push_back(base);
-    t.push_back(1e30f);
-    err = fill();
-    if (!err) err = time_ms(&t.back());
-    c->tune_cand_s += now_s() - w0;
-    if (max_tries < (1 << 30) && w1 - w0 > 0.03) { k = tries; }  // a search with little to gain (the sweeps: 1-3 %) stops at the first candidate hipMalloc had to clear fresh VRAM for
-    if (getenv("FX_PLACEMENT_DEBUG")) fprintf(stderr, "[fx placement] try %d: hipMalloc %.1f ms, fill + time %.1f ms\n", k, 1e3 * (w1 - w0), 1e3 * (now_s() - w1));
+  float t0 = 0.f, t1 = 1e30f;
+  if (time_ms(&t0)) return FX_ERROR_RUNTIME;
+  if (rep) { rep->first_ms = rep->kept_ms = t0; rep->candidates = 1; rep->gbs = stream_bytes / (1e-3 * t0) / 1e9; }
+  if (stream_bytes / (1e-3 * t0) / 1e9 >= good_gbs) return 0;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + (bytes >> 1) + ((size_t)4 << 30)) return 0;  // keep headroom
+  char *base = nullptr;
+  size_t got = 0;
+  void *first_base = B.val2_base;
+  const size_t first_bytes = B.val2_bytes;
+  const double w0 = now_s();
+  if (val2_alloc(c, &base, bytes, &got)) { (void)hipGetLastError(); g_fx_error.clear(); return 0; }
+  B.val2_base = base; B.val2 = (double *)base; B.val2_bytes = got;
+  int err = fill();
+  if (!err) err = time_ms(&t1);
+  c->tune_cand_s += now_s() - w0;
+  void *loser = nullptr;
+  size_t loser_bytes = 0;
+  if (err || t1 >= t0) {  // the first allocation stays (it is filled)
+    loser = base; loser_bytes = got;
+    B.val2_base = first_base; B.val2 = (double *)first_base; B.val2_bytes = first_bytes;
+  } else {
+    loser = first_base; loser_bytes = first_bytes;
   }
-  if (err) {  // keep the first allocation (it is filled), release everything tried after it
-    for (size_t k = 1; k < cand.size(); k++) (void)hipFree(cand[k]);
-    B.val2_base = cand[0];
-    B.val2 = (double *)cand[0];
-    return FX_ERROR_RUNTIME;
+  {
+    std::lock_guard<std::mutex> lk(g_held_mu);
+    c->held.push_back(loser);
+    c->held_bytes += loser_bytes;
+    if (std::find(g_held_ctx.begin(), g_held_ctx.end(), c) == g_held_ctx.end()) g_held_ctx.push_back(c);
   }
-  if (const char *ea = getenv("FX_PLACEMENT_ARENA_MB")) {  // experiment: does the OFFSET inside one large allocation change the speed class?
-    const size_t arena = (size_t)atoll(ea) << 20, step = (size_t)(getenv("FX_PLACEMENT_STEP_MB") ? atoll(getenv("FX_PLACEMENT_STEP_MB")) : 256) << 20;
-    char *big = nullptr;
-    void *keep_base = B.val2_base;
-    double *keep = B.val2;
-    if (hipMalloc((void **)&big, bytes + arena) == hipSuccess) {
-      fprintf(stderr, "[fx placement] %s offsets inside one %.1f GB allocation:", what, (bytes + arena) / 1e9);
-      for (size_t off = 0; off <= arena && !err; off += step) {
-        B.val2 = (double *)(big + off);
-        float ms = 0.f;
-        err = fill();
-        if (!err) err = time_ms(&ms);
-        fprintf(stderr, " %zuM:%.3f", off >> 20, ms);
-      }
-      fprintf(stderr, "\n");
-      B.val2 = keep; B.val2_base = keep_base;
-      (void)hipFree(big);
-      if (err) return FX_ERROR_RUNTIME;
-    } else (void)hipGetLastError();
-  }
-  const int best = (int)(std::min_element(t.begin(), t.end()) - t.begin());
-  if (getenv("FX_TIMING") && atoi(getenv("FX_TIMING"))) {
-    fprintf(stderr, "[fx timing] %s value-array placement:", what);
-    for (size_t k = 0; k < t.size(); k++) fprintf(stderr, " %.3f ms%s", t[k], (int)k == best ? "*" : "");
-    fprintf(stderr, "\n");
-  }
-  // The losers stay allocated until the context goes (up to FX_TUNE_HOLD_GB): the driver scrubs freed VRAM and the next hipMalloc
-  // waits for it -- four freed 8 GB candidates cost the following allocation 0.9 s on a fresh box.
-  const double wf = now_s();
-  const size_t cbytes = val2_alloc_bytes(c, bytes);
-  for (size_t k = 0; k < cand.size(); k++) {
-    if ((int)k == best) continue;
-    if (c->held_bytes + cbytes <= c->hold_max_bytes) { c->held.push_back(cand[k]); c->held_bytes += cbytes; }
-    else (void)hipFree(cand[k]);
-  }
-  if (getenv("FX_PLACEMENT_DEBUG")) fprintf(stderr, "[fx placement] %zu losers: release %.1f ms, %.1f GB held until the context goes\n", cand.size() - 1, 1e3 * (now_s() - wf), c->held_bytes / 1e9);
-  B.val2_base = cand[best];  // every candidate was filled from the same values
-  B.val2 = (double *)cand[best];
-  return 0;
+  if (rep) { rep->candidates = 2; rep->kept_ms = std::min(t0, t1); rep->gbs = stream_bytes / (1e-3 * rep->kept_ms) / 1e9; }
+  if (getenv("FX_TIMING") && atoi(getenv("FX_TIMING")))
+    fprintf(stderr, "[fx timing] %s value-array placement: first %.3f ms, second %.3f ms\n", what, t0, t1);
+  return err ? FX_ERROR_RUNTIME : 0;
 }
 
 static int tune_value_placement(fx_context *c) {
@@ -780,7 +773,7 @@ static int tune_value_placement(fx_context *c) {
   const double bytes = (double)M.npairs * 64 * 76 + 48.0 * c->ord.nslots;
   // (The vector the product writes was tried as a second knob -- scripts/experiments/ab_vectors.py showed 1.066 against 1.11 ms
   // between work vectors in one context -- but at set-up time the ten candidates lie within 0.5 % of each other: not kept.)
-  return tune_placement(c, M, "SpMV", bytes, 6600.0, [&]() { return bell_fill_values(c, M); }, time_spmv);
+  return tune_placement(c, M, "SpMV", bytes, 6400.0, [&]() { return bell_fill_values(c, M); }, time_spmv, &c->place_spmv);
 }
 
 // Make the ordering, M (symbolic + values) and the work vectors current.
@@ -1483,7 +1476,6 @@ static int tune_sweep_placement(fx_context *c, const double *lu_D, const double 
   SsorDev &S = c->ssor;
   if (S.L.placed && S.U.placed) return 0;
   if (c->tune_tries <= 1 || S.L.nslices < c->tune_min_slices) { S.L.placed = S.U.placed = true; return 0; }
-  if (c->tune_cand_s > 0.25 * c->tune_budget_s) { S.L.placed = S.U.placed = true; return 0; }  // allocations are expensive in this process (fresh VRAM): the sweeps gain 1-3 % at best
   if (ensure_work(c)) return FX_ERROR_RUNTIME;
   KrylovState st0;
   memset(&st0, 0, sizeof st0);
@@ -1504,8 +1496,9 @@ static int tune_sweep_placement(fx_context *c, const double *lu_D, const double 
   const double good = level_sched(c) ? 1e9 : 5450.0;  // level-scheduled ILU(0) is latency-bound: placement does not show
   if (level_sched(c)) { S.L.placed = S.U.placed = true; return 0; }
   // the sweeps gain 1-3 % at best (their speed classes lie closer together than the SpMV's): four candidates each
-  if (tune_placement(c, S.L, "sweep L", bytes, good, [&]() { return bell_fill_values(c, S.L, lu_D, lu_AL, lu_AU); }, time_apply, 4)) return FX_ERROR_RUNTIME;
-  return tune_placement(c, S.U, "sweep U", bytes, good, [&]() { return bell_fill_values(c, S.U, lu_D, lu_AL, lu_AU); }, time_apply, 4);
+  if (tune_placement(c, S.L, "sweep L", bytes, good, [&]() { return bell_fill_values(c, S.L, lu_D, lu_AL, lu_AU); }, time_apply, &c->place_sweep)) return FX_ERROR_RUNTIME;
+  if (c->place_sweep.candidates >= 2) return 0;  // the apply was slow and L got its second chance; U keeps its allocation
+  return tune_placement(c, S.U, "sweep U", bytes, good, [&]() { return bell_fill_values(c, S.U, lu_D, lu_AL, lu_AU); }, time_apply, &c->place_sweep);
 }
 
 static int ssor_setup_numeric(fx_context *c, double sigma_diag) {
@@ -1763,7 +1756,20 @@ extern "C" int fx_precond_setup(fx_context *c, const int32_t *Iarray, const doub
     pt.lap("work vectors");
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
+  release_held(c);  // the losers of this set-up's placement checks: nothing stays allocated beyond the set-up
   c->precond_valid = true;
+  return 0;
+}
+
+// What the placement checks of the set-ups found (see tune_placement): out[0..3] SpMV value array {ms of the first allocation,
+// ms of the kept one, candidates timed (0 = not checked: small system), GB/s of the kept one over the streamed bytes},
+// out[4..7] the same for the sweep layouts of SSOR (timed on the whole apply), out[8] device bytes currently held by losing
+// candidates (0 outside a set-up).
+extern "C" int fx_placement_report(fx_context *c, double out[9]) {
+  if (!c || !out) { g_fx_error = "fx_placement_report: null argument"; return FX_ERROR_RUNTIME; }
+  const PlacementReport *r[2] = {&c->place_spmv, &c->place_sweep};
+  for (int k = 0; k < 2; k++) { out[4 * k] = r[k]->first_ms; out[4 * k + 1] = r[k]->kept_ms; out[4 * k + 2] = r[k]->candidates; out[4 * k + 3] = r[k]->gbs; }
+  out[8] = (double)c->held_bytes;
   return 0;
 }
 
@@ -1957,6 +1963,8 @@ static bool df_take_error(fx_context *c) {
   (void)hipMemset(c->df_err, 0, 4);
   c->df_mode = 0;
   c->df_fallbacks++;
+  // the sweep vector is full of tags: the level sweeps multiply a padding block (value 0) with the row's own stale entry
+  if (c->ssor.zs) (void)hipMemset(c->ssor.zs, 0, (size_t)3 * c->ssor.nslots * 8);
   return true;
 }
 
@@ -2128,17 +2136,6 @@ static int krylov_begin(fx_context *c, int method, int maxit, double tol) {
   double *X = c->Xs, *B = c->Bs, *R = c->W[0];
   int np;
   if (ensure_solver(c)) return FX_ERROR_RUNTIME;
-  if (const char *e = getenv("FX_W_PERM")) {  // placement experiments: which physical buffers play W[0], W[1], W[2] (read at every begin)
-    int a = -1, b = -1, d = -1;
-    if (sscanf(e, "%d,%d,%d", &a, &b, &d) == 3 && a >= 0 && b >= 0 && d >= 0 && a < 10 && b < 10 && d < 10 && a != b && b != d && a != d) {
-      const int want[3] = {a, b, d};
-      for (int r = 0; r < 3; r++) {
-        int where = -1;
-        for (int k = 0; k < 10; k++) if (c->W[k] == c->W0[want[r]]) where = k;
-        if (where >= 0) std::swap(c->W[r], c->W[where]);
-      }
-    }
-  }
   if (to_slots(c, c->A.B, c->Bs) || to_slots(c, c->A.X, c->Xs)) return FX_ERROR_RUNTIME;
   c->k_method = method; c->k_maxit = maxit; c->k_it = 1;
   graphs_destroy(c);  // buffers / grids may have changed since the last solve: re-capture
@@ -2323,9 +2320,9 @@ static int run_krylov(fx_context *c, int method, int maxit, double tol, KrylovSt
 
 extern "C" int fx_krylov_begin(fx_context *c, const int32_t *Iarray, const double *Rarray) {
   HIP_TRY(hipSetDevice(c->device));
+  if (require_transport(c, "fx_krylov_begin")) return FX_ERROR_RUNTIME;
   if (!c->have_values || !c->precond_valid) { g_fx_error = "fx_krylov_begin: matrix / preconditioner not resident"; return FX_ERROR_RUNTIME; }
   if (Iarray[1] != 1 && Iarray[1] != 2) { g_fx_error = "METHOD must be 1 (CG) or 2 (BiCGSTAB)"; return FX_ERROR_INCONS_PC; }
-  if (require_transport(c, "fx_krylov_begin")) return FX_ERROR_RUNTIME;
   c->iterpremax = Iarray[4];
   c->clock.on = false;  // the staged API is what bench.py times: no event pairs inside
   const int e = krylov_begin(c, Iarray[1], Iarray[0], Rarray[0]);
@@ -2461,9 +2458,13 @@ extern "C" int fx_solve_resident(fx_context *c, int32_t *Iarray, double *Rarray,
   double sigma = auto_sigma ? 1.0 : Rarray[1];
   double t1 = now_s();
   const bool scaling = Iarray[6] != 0;  // SCALING=YES (IDX_I_SCALING = 7)
+  c->attempts.clear();
   for (;;) {
     Iarray[80] = 0; Iarray[81] = 0;
     int e;
+    c->attempts.emplace_back();
+    c->attempts.back().method = method;
+    c->attempts.back().sigma_diag = sigma;
     if (scaling) {  // scale, then build the preconditioner of the scaled matrix (CG.f90:104-112)
       if (scaling_apply(c, false)) return FX_ERROR_RUNTIME;
       double R2[100];
@@ -2493,6 +2494,10 @@ extern "C" int fx_solve_resident(fx_context *c, int32_t *Iarray, double *Rarray,
       if (!hk.hist.empty()) HIP_TRY(hipMemcpy(c->hist, hk.hist.data(), hk.hist.size() * 8, hipMemcpyHostToDevice));
     } else { g_fx_error = "METHOD must be 1 (CG), 2 (BiCGSTAB), 3 (GMRES) or 4 (GPBiCG)"; return FX_ERROR_INCONS_PC; }
     if (e) return e;
+    if (s.n_hist > 0) {  // the pass's ITERLOG lines (kept per pass: a retry starts its history again at line 1)
+      c->attempts.back().hist.resize((size_t)s.n_hist);
+      HIP_TRY(hipMemcpy(c->attempts.back().hist.data(), c->hist, (size_t)s.n_hist * 8, hipMemcpyDeviceToHost));
+    }
     if (scaling) {  // x <- D^-1/2 x, b and the matrix divided back (CG.f90:277); then everything resident is refreshed
       if (from_slots(c, c->Xs, c->A.X) || scaling_apply(c, true) || ensure_solver(c)) return FX_ERROR_RUNTIME;
       if (to_slots(c, c->A.B, c->Bs) || to_slots(c, c->A.X, c->Xs)) return FX_ERROR_RUNTIME;
@@ -2507,7 +2512,7 @@ extern "C" int fx_solve_resident(fx_context *c, int32_t *Iarray, double *Rarray,
       // X the failed attempt left.  Reproduced literally (bit-exact oracle runs against the real reference:
       // tests/golden/retry.npz); `sigma` is tracked because it decides how many retries there are.
       if (precond >= 10 && precond < 20 && auto_sigma && sigma < 2.0) {  // 'Increasing SIGMA_DIAG' retry of the ILU family
-        sigma += 0.1;
+        sigma += (double)0.1f;  // `SIGMA_DIAG = SIGMA_DIAG + 0.1` with a default-real literal (:147): what the reference adds, and prints
         continue;
       } else if (method == 1 && method2 > 1) {
         if (auto_sigma) sigma = 1.0;  // :152 (no set-up follows in the reference either)
@@ -2627,9 +2632,6 @@ extern "C" int fx_nn_matvec_resident(fx_context *c, int nrepeat, float *ms_per_c
 // partial of r.r (the residual recomputation).  The halo exchange of a multi-rank system is part of every call.
 extern "C" int fx_spmv_resident(fx_context *c, int variant, int nrepeat, float *ms_per_call) {
   HIP_TRY(hipSetDevice(c->device));
-  if (getenv("FX_PLACEMENT_DEBUG"))
-    fprintf(stderr, "[fx placement] val2 %p col2 %p pair_ptr %p x(W2) %p y(W1) %p partials %p slice_order %p\n", (void *)c->M.val2,
-            (void *)c->M.col2, (void *)c->M.pair_ptr, (void *)c->W[2], (void *)c->W[1], (void *)c->partials, (void *)c->M.slice_order);
   if (!c->have_values) { g_fx_error = "fx_spmv_resident: no matrix resident"; return FX_ERROR_RUNTIME; }
   if (variant < 0 || variant > 2) { g_fx_error = "fx_spmv_resident: variant must be 0, 1 or 2"; return FX_ERROR_RUNTIME; }
   if (ensure_solver(c)) return FX_ERROR_RUNTIME;
@@ -2637,12 +2639,8 @@ extern "C" int fx_spmv_resident(fx_context *c, int variant, int nrepeat, float *
   const int mode = variant == 2 ? 1 : 0, dot = variant;
   // x and y are the vectors the CG loop multiplies (p = W[2], q = W[1]: cg_iteration) -- which buffers the product reads and
   // writes moves its time by up to 4 % (scripts/experiments/ab_vectors.py), and the roofline figure is the loop's kernel.  The
-  // call overwrites them: not between fx_krylov_begin and the end of the iterations.  FX_SPMV_XY="a,b": other work vectors.
+  // call overwrites them: not between fx_krylov_begin and the end of the iterations.
   double *xin = c->W[2], *yout = c->W[1];
-  if (const char *e = getenv("FX_SPMV_XY")) {
-    int a = -1, b = -1;
-    if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && a < 10 && b >= 0 && b < 10 && a != b) { xin = c->W[a]; yout = c->W[b]; }
-  }
   HIP_TRY(hipMemcpyAsync(xin, c->Bs, (size_t)c->wlen * 8, hipMemcpyDeviceToDevice, c->stream));
   if (spmv(c, mode, dot, xin, c->Bs, yout, nullptr, 0)) return FX_ERROR_RUNTIME;  // untimed first touch
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
@@ -2730,6 +2728,26 @@ extern "C" int fx_precond_apply_resident(fx_context *c, int nrepeat, float *ms_p
     if (!df_take_error(c)) break;  // a timed-out dataflow sweep: timed again with the launch-per-level sweeps
   }
   if (ms_per_call) *ms_per_call = ms / std::max(nrepeat, 1);
+  return 0;
+}
+
+// The passes of the auto-SIGMA_DIAG / METHOD2 loop of the last solve on this context (hecmw_solver_Iterative.f90:117-157): the
+// reference prints its banner before every pass, the pass's ITERLOG lines, and 'Increasing SIGMA_DIAG to <value>' before a
+// SIGMA_DIAG retry; a binding replays those lines from here.  Arrays of `cap` entries; *n_attempts is the true count.
+extern "C" int fx_solve_attempts(fx_context *c, int32_t cap, int32_t *n_attempts, int32_t *method, double *sigma_diag, int32_t *n_hist) {
+  if (!c || !n_attempts) { g_fx_error = "fx_solve_attempts: null argument"; return FX_ERROR_RUNTIME; }
+  *n_attempts = (int32_t)c->attempts.size();
+  for (int32_t k = 0; k < cap && k < *n_attempts; k++) {
+    if (method) method[k] = c->attempts[k].method;
+    if (sigma_diag) sigma_diag[k] = c->attempts[k].sigma_diag;
+    if (n_hist) n_hist[k] = (int32_t)c->attempts[k].hist.size();
+  }
+  return 0;
+}
+extern "C" int fx_solve_attempt_history(fx_context *c, int32_t attempt, double *hist, int32_t cap) {
+  if (!c || attempt < 0 || attempt >= (int32_t)c->attempts.size()) { g_fx_error = "fx_solve_attempt_history: no such attempt"; return FX_ERROR_RUNTIME; }
+  const std::vector<double> &h = c->attempts[attempt].hist;
+  if (hist && cap > 0 && !h.empty()) memcpy(hist, h.data(), sizeof(double) * std::min<size_t>((size_t)cap, h.size()));
   return 0;
 }
 

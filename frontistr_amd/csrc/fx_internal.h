@@ -60,6 +60,7 @@ struct Bell {
   int32_t *wg_interior = nullptr, *wg_boundary = nullptr;
   int32_t n_wg_interior = 0, n_wg_boundary = 0;
   int64_t nblocks = 0;          // real (non padding) blocks
+  size_t val2_bytes = 0;        // bytes val2_base was allocated with (the power-of-two request, or the exact size)
   bool placed = false;          // the value array went through the placement search (once per symbolic build)
   size_t bytes() const { return (size_t)npairs * 64 * (9 * 8 + 4) + (size_t)(nslices + 1) * 4; }
 };
@@ -195,7 +196,18 @@ struct PhaseClock {
   double acc[3] = {0.0, 0.0, 0.0};  // seconds
 };
 
+struct PlacementReport { float first_ms = 0.f, kept_ms = 0.f; int candidates = 0; double gbs = 0.0; };  // tune_placement
+
+// One pass of the auto-SIGMA_DIAG / METHOD2 loop of hecmw_solve_iterative (hecmw_solver_Iterative.f90:117-157): what the reference
+// prints per pass (banner, ITERLOG lines, 'Increasing SIGMA_DIAG to') is replayed by the binding from this log.
+struct AttemptLog {
+  int method = 0;
+  double sigma_diag = 1.0;       // SIGMA_DIAG in effect during the pass
+  std::vector<double> hist;      // its residual-history lines
+};
+
 struct fx_context {
+  std::vector<AttemptLog> attempts;  // of the last fx_solve / fx_solve_resident (fx_solve_attempts)
   int device = 0;
   int n_cu = 256;  // compute units of the device
   hipStream_t stream = nullptr;
@@ -282,14 +294,14 @@ struct fx_context {
   int32_t mc_batch = 32;            // rounds of the device multicolouring between two looks at the queue length by the host (FX_MC_BATCH)
   int32_t mc_device_min = 100000;   // block rows from which the multicolouring of the SSOR set-up runs on the device (FX_MC_DEVICE_MIN)
   bool val2_pow2 = true;            // BELL value arrays of a gigabyte or more: ask hipMalloc for the next power of two -- ONE block of the driver's allocator, the fast placement class (FX_VAL2_POW2=0: the exact size)
-  double tune_budget_s = 0.5;       // wall time the placement searches of one context may spend on extra candidates (FX_TUNE_BUDGET_MS): 2-3 candidates when hipMalloc has to clear fresh VRAM (190 ms per 6.5 GB), all 20 when it recycles (10 ms each)
   double tune_spent_s = 0.0;        // wall time of all tuning steps of this context's set-ups (placement searches, work-vector roles): fx_tune_seconds
   double tune_cand_s = 0.0;         // of which: allocating, filling and timing extra candidates (what the budget caps)
   std::vector<void *> held;         // losing candidates of the placement searches, released with the context
-  size_t held_bytes = 0, hold_max_bytes = (size_t)48 << 30;  // FX_TUNE_HOLD_GB
+  size_t held_bytes = 0;            // bytes of the losing candidates (released at the end of the set-up that made them, or earlier under memory pressure)
   int32_t bfs_batch = 16;           // levels of the device level ordering between two looks at the level state by the host (FX_BFS_BATCH)
   int32_t bfs_device_min = 100000;  // block rows from which the level ordering of the SSOR set-up runs on the device (FX_BFS_DEVICE_MIN)
-  int tune_tries = 20;
+  int tune_tries = 2;               // 2: a slow first allocation gets ONE second candidate; <= 1: no check (FX_TUNE_PLACEMENT)
+  PlacementReport place_spmv, place_sweep;
   int32_t tune_min_slices = 8192;
   // work vectors (3*NP each)
   double *W[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

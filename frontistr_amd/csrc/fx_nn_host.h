@@ -925,6 +925,7 @@ static int nn_solve(fx_context *c, const fx_matrix_view *m, const fx_comm_view *
   Iarray[97] = 0; Iarray[96] = 0;
   const double t_setup = now_s() - t0, t1 = now_s();
   NnResult res;
+  c->attempts.clear();
   for (;;) {
     Iarray[80] = 0; Iarray[81] = 0;
     res = NnResult();
@@ -945,6 +946,10 @@ static int nn_solve(fx_context *c, const fx_matrix_view *m, const fx_comm_view *
       res.iter = hk.iter; res.resid = hk.resid; res.error = hk.error; res.hist = hk.hist;
     } else { g_fx_error = "METHOD must be 1 (CG), 2 (BiCGSTAB), 3 (GMRES) or 4 (GPBiCG)"; return FX_ERROR_INCONS_PC; }
     if (e) return e;
+    c->attempts.emplace_back();
+    c->attempts.back().method = method;
+    c->attempts.back().sigma_diag = sigma;
+    c->attempts.back().hist = res.hist;
     if (scaling) {  // x and b back, matrix restored (hecmw_solver_CG.f90:277); the preconditioner belonged to the scaled matrix
       if (nn_scaling(c, 1)) return FX_ERROR_RUNTIME;
       n->precond_valid = false;

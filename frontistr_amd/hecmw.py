@@ -210,6 +210,13 @@ class SolverContext:
         f.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
         _chk(f(self.h, name.encode(), float(value)))
 
+    def placement_report(self):
+        out = (C.c_double * 9)()
+        _chk(lib().fx_placement_report(self.h, out))
+        return {"spmv": {"first_ms": out[0], "kept_ms": out[1], "candidates": int(out[2]), "GBs": out[3]},
+                "sweeps": {"first_ms": out[4], "kept_ms": out[5], "candidates": int(out[6]), "GBs": out[7]},
+                "held_bytes": int(out[8])}
+
     def tune_seconds(self):
         """Wall time of the measured tuning steps of this context's set-ups so far (placement searches, work-vector roles)."""
         f = lib().fx_tune_seconds

@@ -18,7 +18,7 @@ module hecmw_hip_binding
   implicit none
   private
   public :: fx_matrix_view, fx_comm_view, fx_solve_info
-  public :: fx_solve, fx_matvec, fx_last_error
+  public :: fx_solve, fx_matvec, fx_last_error, fx_solve_attempts, fx_solve_attempt_history
   public :: fxb_context, fxb_views, fxb_ensure_transport, fxb_error_text
 
   type, bind(C) :: fx_matrix_view
@@ -54,6 +54,19 @@ module hecmw_hip_binding
       real(c_double) :: hist(*)
       integer(c_int32_t), value :: hist_len
     end function fx_solve
+    integer(c_int) function fx_solve_attempts(ctx, cap, n_attempts, method, sigma_diag, n_hist) bind(C, name='fx_solve_attempts')
+      import :: c_int, c_ptr, c_int32_t, c_double
+      type(c_ptr), value :: ctx
+      integer(c_int32_t), value :: cap
+      integer(c_int32_t) :: n_attempts, method(*), n_hist(*)
+      real(c_double) :: sigma_diag(*)
+    end function fx_solve_attempts
+    integer(c_int) function fx_solve_attempt_history(ctx, attempt, hist, cap) bind(C, name='fx_solve_attempt_history')
+      import :: c_int, c_ptr, c_int32_t, c_double
+      type(c_ptr), value :: ctx
+      integer(c_int32_t), value :: attempt, cap
+      real(c_double) :: hist(*)
+    end function fx_solve_attempt_history
     integer(c_int) function fx_matvec(ctx, mat, comm, x, y, commtime) bind(C, name='fx_matvec')
       import :: c_int, c_ptr, c_double, fx_matrix_view, fx_comm_view
       type(c_ptr), value :: ctx

@@ -32,7 +32,11 @@ contains
     type(fx_solve_info)  :: info
     type(c_ptr) :: ctx
     real(kind=kreal), allocatable, target :: hist(:)
-    integer(kind=kint) :: ierr, i, nhist, precond, iterlog, timelog, iterpremax
+    integer(kind=kint) :: ierr, i, k, nhist, precond, iterlog, timelog, iterpremax
+    integer(c_int32_t) :: natt, att_method(16), att_nhist(16)
+    real(c_double) :: att_sigma(16)
+    real(kind=kreal), allocatable, target :: hist_k(:)
+    real(kind=kreal) :: SIGMA_DIAG
     character(len=8) :: env
     character(len=16) :: envu
     character(len=16) :: msg_method, msg_precond
@@ -83,44 +87,57 @@ contains
     iterlog = hecmw_mat_get_iterlog(hecMAT)
     timelog = hecmw_mat_get_timelog(hecMAT)
     iterpremax = hecmw_mat_get_iterpremax(hecMAT)
-    select case (hecmw_mat_get_method(hecMAT))
-      case (1); msg_method = 'CG'
-      case (2); msg_method = 'BiCGSTAB'
-      case (3); msg_method = 'GMRES'
-      case (4); msg_method = 'GPBiCG'
-      case default; msg_method = 'Unlabeled'
-    end select
     select case (precond)
       case (1, 2); msg_precond = 'SSOR'
       case (3); msg_precond = 'DIAG'
       case (10, 11, 12); write(msg_precond, '(a,i0,a)') 'ILU(', precond - 10, ')'
       case default; msg_precond = 'Unlabeled'
     end select
-    if (hecMESH%my_rank == 0 .and. (iterlog == 1 .or. timelog >= 1)) then
-      write (*,'(a,i0,a,i0,a,a,a,a,a,i0)') '### ', hecMAT%NDOF, 'x', hecMAT%NDOF, ' BLOCK ', &
-        &   trim(msg_method), ', ', trim(msg_precond), ', ', iterpremax
-    endif
-
     nhist = max(hecmw_mat_get_iter(hecMAT), 1) + 1   ! GMRES logs MAXIT+1 lines when it runs out
     allocate(hist(nhist))
     ierr = fx_solve(ctx, mv, cv, hecMAT%Iarray, hecMAT%Rarray, info, hist, int(nhist, c_int32_t))
 
-    if (info%method /= hecmw_mat_get_method(hecMAT) .and. ierr >= 0) then   ! METHOD2 took over: the reference prints a second banner
-      select case (info%method)
+    ! One block per pass of the auto-SIGMA_DIAG / METHOD2 loop, as hecmw_solve_iterative prints them (:117-157): the banner of
+    ! hecmw_solve_iterative_printmsg (:125), the pass's ITERLOG lines, and before a SIGMA_DIAG retry the list-directed line of :149.
+    natt = 0
+    if (ierr >= 0) i = fx_solve_attempts(ctx, int(size(att_method), c_int32_t), natt, att_method, att_sigma, att_nhist)
+    if (natt > size(att_method)) natt = size(att_method)
+    if (natt <= 0) then        ! the solve never reached a Krylov pass (zero RHS, an E-code): the reference's banner precedes those checks' outcome
+      natt = 1; att_method(1) = hecmw_mat_get_method(hecMAT); att_nhist(1) = 0; att_sigma(1) = 1.d0
+    endif
+    do k = 1, natt
+      select case (att_method(k))
+        case (1); msg_method = 'CG'
         case (2); msg_method = 'BiCGSTAB'
         case (3); msg_method = 'GMRES'
         case (4); msg_method = 'GPBiCG'
+        case default; msg_method = 'Unlabeled'
       end select
       if (hecMESH%my_rank == 0 .and. (iterlog == 1 .or. timelog >= 1)) then
         write (*,'(a,i0,a,i0,a,a,a,a,a,i0)') '### ', hecMAT%NDOF, 'x', hecMAT%NDOF, ' BLOCK ', &
           &   trim(msg_method), ', ', trim(msg_precond), ', ', iterpremax
       endif
-    endif
-    if (hecMESH%my_rank == 0 .and. iterlog == 1) then
-      do i = 1, info%n_hist
-        write(*,'(i7, 1pe16.6)') i, hist(i)
-      enddo
-    endif
+      if (hecMESH%my_rank == 0 .and. iterlog == 1 .and. att_nhist(k) > 0) then
+        if (k == natt) then
+          do i = 1, min(att_nhist(k), info%n_hist)
+            write(*,'(i7, 1pe16.6)') i, hist(i)
+          enddo
+        else
+          allocate(hist_k(att_nhist(k)))
+          i = fx_solve_attempt_history(ctx, int(k - 1, c_int32_t), hist_k, int(att_nhist(k), c_int32_t))
+          do i = 1, att_nhist(k)
+            write(*,'(i7, 1pe16.6)') i, hist_k(i)
+          enddo
+          deallocate(hist_k)
+        endif
+      endif
+      if (k < natt) then
+        if (att_method(k + 1) == att_method(k) .and. hecMESH%my_rank == 0) then
+          SIGMA_DIAG = att_sigma(k + 1)
+          write(*,*) 'Increasing SIGMA_DIAG to', SIGMA_DIAG     ! the reference's own statement (:149)
+        endif
+      endif
+    enddo
     deallocate(hist)
 
     if (ierr < 0) then

@@ -150,6 +150,15 @@ int fx_get_stats(fx_context *ctx, int64_t out[16]);
  * timing of the work vectors -- as opposed to building the preconditioner (no reference counterpart: the reference has no
  * such step; FX_TUNE_PLACEMENT=0 switches the searches off) */
 double fx_tune_seconds(fx_context *ctx);
+/* Placement checks of the set-ups: out[0..3] SpMV value array {ms of the first allocation, ms of the kept
+ * one, candidates timed (0: not checked), GB/s of the kept one}, out[4..7] the same for the SSOR sweep layouts (timed on the whole
+ * apply), out[8] device bytes still held by losing candidates (0 outside a set-up).  No counterpart in the reference. */
+int fx_placement_report(fx_context *ctx, double out[9]);
+/* The passes of the auto-SIGMA_DIAG / METHOD2 loop of the last solve on this context (hecmw_solver_Iterative.f90:117-157: banner
+ * :125 before every pass, 'Increasing SIGMA_DIAG to' :149 before a retry): METHOD, the SIGMA_DIAG in effect and the number of
+ * residual-history lines of every pass, and the lines themselves.  fx_solve's own `hist` holds the LAST pass. */
+int fx_solve_attempts(fx_context *ctx, int32_t cap, int32_t *n_attempts, int32_t *method, double *sigma_diag, int32_t *n_hist);
+int fx_solve_attempt_history(fx_context *ctx, int32_t attempt, double *hist, int32_t cap);
 /* Tuning knob of a live context (kernel variants, workgroup sizes, sweep modes: the FX_* names documented in
  * frontistr_amd/csrc/fx_internal.h; the same names are read from the environment at fx_create).  No counterpart in the
  * reference (its equivalents are build-time choices such as the OpenMP thread count).  Unknown name: FX_ERROR_UNSUPPORTED. */

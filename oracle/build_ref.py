@@ -151,7 +151,11 @@ def build_variant(name, drivers, omp, jobs, provides, uses, overrides=None, defi
     for f in order:
         o = objname(objdir, f)
         fobjs.append(o)
-        if os.path.exists(o) and os.path.getmtime(o) > os.path.getmtime(f):
+        # up to date = newer than its source AND than the object of every module it uses (flang checks the hash of a used
+        # module file: a dependent compiled against the previous version of a changed module no longer links)
+        deps = [provides[m] for m in (uses[f] if f in uses else extra[f]) if m in provides and provides[m] != f]
+        if os.path.exists(o) and os.path.getmtime(o) > os.path.getmtime(f) and \
+                all(os.path.exists(objname(objdir, d)) and os.path.getmtime(objname(objdir, d)) <= os.path.getmtime(o) for d in deps):
             continue
         print(f"[{name}] flang {os.path.relpath(f, REF) if f.startswith(REF) else f}", flush=True)
         run([FLANG] + fflags + ["-c", f, "-o", o])

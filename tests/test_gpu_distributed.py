@@ -306,7 +306,8 @@ def test_hip_distributed_nonlinear_equals_serial_oracle(oracle, tmp_path):
 @pytest.mark.parametrize("ngpu", [2, 4])
 def test_bench_self_launch(ngpu):
     """`python bench.py --gpus N` with no launcher: the parent (no torch, no HIP) starts N rank processes itself; here they
-    share the one GPU through the gloo rehearsal transport.  n_gpus must be the rank count the transport reports."""
+    share the one GPU through the gloo rehearsal transport.  `ranks` is the rank count the transport reports; `n_gpus` is the
+    number of DEVICES used (1 here): a rehearsal line must not read as a scaling point."""
     import json
     import os
     import subprocess
@@ -320,7 +321,8 @@ def test_bench_self_launch(ngpu):
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout
     out = json.loads(lines[0])
-    assert out["n_gpus"] == ngpu and out["steps"] == 6 and out["scaling"] == "weak"
+    assert out["ranks"] == ngpu and out["n_gpus"] == 1 and out["config"]["rehearsal_ranks"] == ngpu
+    assert out["steps"] == 6 and out["scaling"] == "weak" and "eisenstat" in out["variants"]
     assert out["config"]["decomposition"] == {2: "2x1x1", 4: "2x2x1"}[ngpu]
     assert out["value"] > 0 and np.isfinite(out["resid_after_steps"])
     assert "cpu_baseline" not in out          # rank 0 at N = 1 only

@@ -168,6 +168,51 @@ def test_shim_stdout_is_the_references(meth, pc):
     assert pos == sorted(pos)
 
 
+@pytest.mark.parametrize("k", [0, 5])
+def test_shim_stdout_of_the_retry_loop_is_the_references(k):
+    """The auto-SIGMA_DIAG / METHOD2 loop (hecmw_solver_Iterative.f90:117-157) prints its banner before EVERY pass (:125), the
+    pass's ITERLOG lines, and ' Increasing SIGMA_DIAG to <value>' before a SIGMA_DIAG retry (:149).  The same diverging deck
+    (tests/golden/retry.npz case k: CG + ILU(0), one diagonal block scaled, SIGMA_DIAG = -1 'auto'; k = 5 with METHOD2 = 2)
+    through the unmodified reference and through the shim: the same sequence of banners and retry lines, character for
+    character (the shim replays them from fx_solve_attempts), the same pass lengths."""
+    from oracle import refrun
+    if not (refrun.have_ref("shim_solve") and refrun.have_ref("ref_solve")):
+        pytest.skip("oracle/_ref not built")
+    g = load_golden("retry")
+    blk, scale, sigma, m2 = g["c%d_case" % k]
+    A = golden_matrix(load_golden("cube4"))
+    A.D = A.D.copy()
+    A.D[9 * int(blk):9 * int(blk) + 9] *= scale
+    I, R = refrun.default_params(method=1, precond=10, maxit=500, iterlog=1, timelog=0)
+    R[1] = sigma
+    I[7] = int(m2)
+    ref = refrun.run_solve(A, I.copy(), R.copy(), threads=1)
+    shm = refrun.run_solve(A, I.copy(), R.copy(), exe_name="shim_solve")
+
+    def channel(out):
+        return [ln for ln in out.splitlines() if ln.startswith("### 3x3 BLOCK") or "Increasing SIGMA_DIAG" in ln]
+
+    def passes(out):
+        lens, cur = [], None
+        for ln in out.splitlines():
+            if ln.startswith("### 3x3 BLOCK"):
+                if cur is not None:
+                    lens.append(cur)
+                cur = 0
+            elif cur is not None and refrun.HIST_RE.match(ln):
+                cur += 1
+        return lens + [cur]
+
+    rc, sc = channel(ref["stdout"]), channel(shm["stdout"])
+    assert int(g["c%d_n_sigma_msgs" % k]) == sum("Increasing" in ln for ln in rc) >= 1       # the deck does retry
+    assert rc == sc                                          # banners and 'Increasing SIGMA_DIAG to' lines, character for character
+    rp, sp = passes(ref["stdout"]), passes(shm["stdout"])
+    assert list(g["c%d_attempts" % k]) == rp and len(sp) == len(rp)
+    for a, b in zip(rp[:-1], sp[:-1]):                       # the diverging passes stop at the same line (+-1: the sign test on rounding-level rho)
+        assert abs(a - b) <= 1
+    assert shm["Iarray"][80] == ref["Iarray"][80] and shm["Iarray"][81] == ref["Iarray"][81]
+
+
 def _self_neighbour_system(seed=5):
     """One subdomain of a 2x1x1 cube split whose only neighbour is the rank itself (periodic tables: halo node k receives
     internal node export_item[k]), random diagonally dominant 3x3 blocks."""

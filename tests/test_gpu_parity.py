@@ -916,7 +916,7 @@ def test_dataflow_grid_is_clamped_to_the_co_resident_bound(hip):
     ctx.set_option("FX_DF_GRID", 1 << 20)
     z1 = ctx.precond_apply(r)
     st = ctx.stats()
-    assert 0 < st["df_grid"] <= 245 and st["df_grid"] <= 256 * 8          # slices, and CUs x 8 workgroups at most
+    assert 0 < st["df_grid"] <= 256 * 8          # never the 2^20 asked for: CUs x (workgroups the occupancy query admits per CU, <= 8)
     assert st["df_fallbacks"] == 0 and np.array_equal(z0, z1)
     ctx.close()
 
