@@ -264,7 +264,11 @@ struct fx_context {
   // 512: 8.0; 4 waves per slice 5.2; re-reading all entries per poll 5.6; two polls in flight 5.9; 0.4-1.5 us of sleep
   // between polls 4.9-5.3): 2,088 dependent hand-offs of ~2.3 us each -- the polls of the waiting workgroups compete
   // with the frontier's hand-offs, so fewer pollers and fewer re-read entries are faster.
-  int df_mode = 1, df_grid = 0, df_wps = 8, df_poll = 1, df_sleep = 2;
+  // Round 3, same context (scripts/r3/ab_opts.py, ILU(0) at 10.1M DOF): sweep vectors in the [slice][k][lane] layout (df_soa) 4.73 -> 4.44 ms
+  // per apply; with that layout one workgroup per CU instead of one per two 4.44 -> 4.27; no sleep between polls 4.27 -> 4.20; the
+  // hand-off vectors in uncached device memory 4.20 -> 4.15 (not kept); re-reading all entries per poll 5.11; 4 waves per slice 5.04.
+  int df_mode = 1, df_grid = 0, df_wps = 8, df_poll = 1, df_sleep = 0;
+  bool df_soa = true;         // private sweep vectors of the dataflow sweeps in the [slice][k][lane] layout (FX_DF_SOA=0: 3 s + k)
   int df_grid_max[3] = {128, 128, 128};  // co-resident workgroups of k_tri_dataflow<2 / 4 / 8 waves> (occupancy query at fx_create)
   int df_grid_last = 0;       // workgroups of the last dataflow launch (after the co-residency clamp)
   bool dbg_df_fail = false;   // test hook (FX_DEBUG_DF_FAIL): the dataflow launches report a timeout at once

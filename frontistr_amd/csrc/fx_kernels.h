@@ -872,18 +872,25 @@ __global__ __launch_bounds__(256) void k_df_fill(int64_t n16, fx_u4 *__restrict_
 // A padding block points at the lane's own slot (value 0): no producer, contributes 0.
 // POLL selects how a wave waits (A/B-measured in one process, scripts/experiments/ab_dataflow3.sh):
 //   0  every pass re-reads all 3 * NB entries;  1  later passes re-read only the entries still unpublished.
-template <int NB, int POLL>
+// Layout of the sweep vectors.  SOA = false: entry k of slot s at 3 s + k (the Krylov vectors' layout: needed when the backward
+// sweep writes the Krylov vector itself).  SOA = true (private sweep vectors: ILU(0), natural-order SSOR): [slice][k][lane] -- a
+// wave publishes a component of its 64 rows as ONE 512-byte segment (four whole 128-byte lines per store instruction instead of 64
+// scattered 8-byte fabric writes), and a gather of 64 consecutive slots reads one such segment per component.
+template <bool SOA> __device__ __forceinline__ size_t df_ix(int slot) { return SOA ? ((size_t)(slot >> 6) * 192 + (slot & 63)) : (size_t)3 * slot; }
+#define DF_ST(SOA) ((SOA) ? 64 : 1)
+
+template <int NB, int POLL, bool SOA>
 __device__ __forceinline__ void df_gather(const double *__restrict__ zs, const int (&col)[NB], int self, double (&x)[3 * NB],
                                           int32_t *__restrict__ err, bool &dead, int nsleep) {
   bool miss[3 * NB];
   bool any = false;
 #pragma unroll
   for (int b = 0; b < NB; b++) {
-    const double *xa = zs + (size_t)3 * col[b];
+    const double *xa = zs + df_ix<SOA>(col[b]);
     const bool need = col[b] != self;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      x[3 * b + k] = df_load(xa + k);
+      x[3 * b + k] = df_load(xa + k * DF_ST(SOA));
       miss[3 * b + k] = need && __double_as_longlong(x[3 * b + k]) == FX_DF_SENTINEL;
       any |= miss[3 * b + k];
     }
@@ -898,7 +905,7 @@ __device__ __forceinline__ void df_gather(const double *__restrict__ zs, const i
     for (int e = 0; e < 3 * NB; e++) {
       const bool need = col[e / 3] != self;
       if (POLL == 0 ? need : miss[e]) {
-        x[e] = df_load(zs + (size_t)3 * col[e / 3] + (e % 3));
+        x[e] = df_load(zs + df_ix<SOA>(col[e / 3]) + (e % 3) * DF_ST(SOA));
         miss[e] = __double_as_longlong(x[e]) == FX_DF_SENTINEL;
         any |= miss[e];
       }
@@ -917,7 +924,7 @@ __device__ __forceinline__ void df_gather(const double *__restrict__ zs, const i
   }
 }
 
-template <bool FWD, int WPS, int POLL>
+template <bool FWD, int WPS, int POLL, bool SOA>
 __device__ __forceinline__ void df_slice(int slice, const int32_t *__restrict__ pair_ptr, const double *__restrict__ val2,
                                          const int *__restrict__ col2, const int32_t *__restrict__ slot_node,
                                          const double *__restrict__ alu, const double *__restrict__ r,
@@ -940,7 +947,8 @@ __device__ __forceinline__ void df_slice(int slice, const int32_t *__restrict__ 
     if (node >= 0) {
       if (FWD || partials) { ri0 = r[(size_t)3 * node]; ri1 = r[(size_t)3 * node + 1]; ri2 = r[(size_t)3 * node + 2]; }
       if (!FWD) {  // this row's forward value: written by this very thread earlier in the launch (a workgroup keeps its slices)
-        zo0 = df_load(zf + (size_t)3 * slot); zo1 = df_load(zf + (size_t)3 * slot + 1); zo2 = df_load(zf + (size_t)3 * slot + 2);
+        const double *zq = zf + df_ix<SOA>(slot);
+        zo0 = df_load(zq); zo1 = df_load(zq + DF_ST(SOA)); zo2 = df_load(zq + 2 * DF_ST(SOA));
       }
     }
   }
@@ -958,7 +966,7 @@ __device__ __forceinline__ void df_slice(int slice, const int32_t *__restrict__ 
     for (int e = 0; e < 9; e++) b[e] = ld_stream(vb + e * 64);
     const int cols[4] = {ca.x, ca.y, cb.x, cb.y};
     double x[12];
-    df_gather<4, POLL>(zsrc, cols, slot, x, err, dead, nsleep);
+    df_gather<4, POLL, SOA>(zsrc, cols, slot, x, err, dead, nsleep);
     const double xva[6] = {x[0], x[1], x[2], x[3], x[4], x[5]};
     const double xvb[6] = {x[6], x[7], x[8], x[9], x[10], x[11]};
     bell_pair_fma(a, xva, s0, s1, s2);
@@ -972,7 +980,7 @@ __device__ __forceinline__ void df_slice(int slice, const int32_t *__restrict__ 
     for (int e = 0; e < 9; e++) a[e] = ld_stream(va + e * 64);
     const int cols[2] = {ca.x, ca.y};
     double x[6];
-    df_gather<2, POLL>(zsrc, cols, slot, x, err, dead, nsleep);
+    df_gather<2, POLL, SOA>(zsrc, cols, slot, x, err, dead, nsleep);
     bell_pair_fma(a, x, s0, s1, s2);
   }
   if (((h1 - h0) & 1) && w == (np % WPS)) {  // an odd last block of the slice is stored alone
@@ -981,7 +989,7 @@ __device__ __forceinline__ void df_slice(int slice, const int32_t *__restrict__ 
     double a[9], x[3];
 #pragma unroll
     for (int e = 0; e < 9; e++) a[e] = ld_stream(vt + e * 64);
-    df_gather<1, POLL>(zsrc, cols, slot, x, err, dead, nsleep);
+    df_gather<1, POLL, SOA>(zsrc, cols, slot, x, err, dead, nsleep);
     bell_single_fma(a, x, s0, s1, s2);
   }
   part[w][0][lane] = s0; part[w][1][lane] = s1; part[w][2][lane] = s2;
@@ -995,13 +1003,13 @@ __device__ __forceinline__ void df_slice(int slice, const int32_t *__restrict__ 
       if (FWD) {
         double x1 = ri0 - s0, x2 = ri1 - s1, x3 = ri2 - s2;
         lusolve33_dev(u, x1, x2, x3);
-        double *zi = zf + (size_t)3 * slot;
-        df_store(zi, x1); df_store(zi + 1, x2); df_store(zi + 2, x3);
+        double *zi = zf + df_ix<SOA>(slot);
+        df_store(zi, x1); df_store(zi + DF_ST(SOA), x2); df_store(zi + 2 * DF_ST(SOA), x3);
       } else {
         lusolve33_dev(u, s0, s1, s2);
         const double x1 = zo0 - s0, x2 = zo1 - s1, x3 = zo2 - s2;
-        double *zi = zb + (size_t)3 * slot;
-        df_store(zi, x1); df_store(zi + 1, x2); df_store(zi + 2, x3);
+        double *zi = zb + df_ix<SOA>(slot);
+        df_store(zi, x1); df_store(zi + DF_ST(SOA), x2); df_store(zi + 2 * DF_ST(SOA), x3);
         if (z) {
           double *zn = z + (size_t)3 * node;
           zn[0] = x1; zn[1] = x2; zn[2] = x3;
@@ -1016,7 +1024,7 @@ __device__ __forceinline__ void df_slice(int slice, const int32_t *__restrict__ 
   }
 }
 
-template <int WPS, int POLL>
+template <int WPS, int POLL, bool SOA>
 __global__ __launch_bounds__(64 * WPS) void k_tri_dataflow(int32_t nslices, const int32_t *__restrict__ Lptr,
                                                            const double *__restrict__ Lval, const int *__restrict__ Lcol,
                                                            const int32_t *__restrict__ Uptr, const double *__restrict__ Uval,
@@ -1036,11 +1044,11 @@ __global__ __launch_bounds__(64 * WPS) void k_tri_dataflow(int32_t nslices, cons
   int buf = 0;
   bool dead = false;  // per wave: its bounded wait ran out (or another wave's did); it then stops waiting, never stops running
   for (int slice = blockIdx.x; slice < nslices; slice += gridDim.x, buf ^= 1)
-    df_slice<true, WPS, POLL>(slice, Lptr, Lval, Lcol, slot_node, alu, r, zf, zb, z, partials, err, part[buf], dead, nsleep);
+    df_slice<true, WPS, POLL, SOA>(slice, Lptr, Lval, Lcol, slot_node, alu, r, zf, zb, z, partials, err, part[buf], dead, nsleep);
   // backward: the SAME slices, last first (a row's forward value is then its own thread's earlier store)
   const int mine = nslices > (int)blockIdx.x ? (nslices - 1 - (int)blockIdx.x) / (int)gridDim.x : -1;
   for (int slice = (int)blockIdx.x + mine * (int)gridDim.x; mine >= 0 && slice >= 0; slice -= gridDim.x, buf ^= 1)
-    df_slice<false, WPS, POLL>(slice, Uptr, Uval, Ucol, slot_node, alu, r, zf, zb, z, partials, err, part[buf], dead, nsleep);
+    df_slice<false, WPS, POLL, SOA>(slice, Uptr, Uval, Ucol, slot_node, alu, r, zf, zb, z, partials, err, part[buf], dead, nsleep);
 }
 
 // ------------------------------------------------------------------------
