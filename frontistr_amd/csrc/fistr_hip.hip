@@ -275,6 +275,7 @@ static const FxOption g_fx_options[] = {
        // block (value 0) with the row's own stale entry
        if (c->ssor.zs && hipSetDevice(c->device) == hipSuccess) (void)hipMemset(c->ssor.zs, 0, (size_t)3 * c->ssor.nslots * 8);
      }},
+    {"FX_DF_SOA", [](fx_context *c, double v) { c->df_soa = (int)v != 0; }},
     {"FX_DF_GRID", [](fx_context *c, double v) { c->df_grid = (int)v; }},
     {"FX_DF_POLL", [](fx_context *c, double v) { c->df_poll = (int)v; }},
     {"FX_DF_SLEEP", [](fx_context *c, double v) { c->df_sleep = std::max(0, (int)v); }},
@@ -317,9 +318,9 @@ extern "C" int fx_create(int device, fx_context **out) {
     if (const char *e = getenv(o.name)) o.set(c, atof(e));
   {  // dataflow sweeps: the co-residency bound of each instantiation (workgroups per CU x CUs), the clamp of FX_DF_GRID
     int pc[3] = {0, 0, 0};
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc[0], k_tri_dataflow<2, 1>, 128, 0) != hipSuccess) pc[0] = 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc[1], k_tri_dataflow<4, 1>, 256, 0) != hipSuccess) pc[1] = 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc[2], k_tri_dataflow<8, 1>, 512, 0) != hipSuccess) pc[2] = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc[0], k_tri_dataflow<2, 1, true>, 128, 0) != hipSuccess) pc[0] = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc[1], k_tri_dataflow<4, 1, true>, 256, 0) != hipSuccess) pc[1] = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc[2], k_tri_dataflow<8, 1, true>, 512, 0) != hipSuccess) pc[2] = 1;
     (void)hipGetLastError();
     for (int k = 0; k < 3; k++) c->df_grid_max[k] = std::max(1, c->n_cu * std::max(1, std::min(pc[k], 8)));
   }
@@ -1808,14 +1809,19 @@ static int precond_apply_once(fx_context *c, const double *r, double *z, bool wa
       hipLaunchKernelGGL(k_df_fill, dim3(grid_for((int64_t)(vbytes / 16), 256, 2048)), dim3(256), 0, c->stream, (int64_t)(vbytes / 16),
                          (fx_u4 *)S.zs, (fx_u4 *)zbk);  // 3 * 64 * 8 bytes per slice: a multiple of 16
       // every workgroup of the launch must be resident at once (the progress argument of k_tri_dataflow): the default is one per
-      // two CUs; FX_DF_GRID is clamped to what the occupancy query admits per CU (df_grid_max, fx_create)
-      int grid = c->df_grid > 0 ? std::min(c->df_grid, c->df_grid_max[c->df_wps == 2 ? 0 : (c->df_wps == 8 ? 2 : 1)]) : std::max(1, c->n_cu / 2);
+      // CU; FX_DF_GRID is clamped to what the occupancy query admits per CU (df_grid_max, fx_create)
+      int grid = c->df_grid > 0 ? std::min(c->df_grid, c->df_grid_max[c->df_wps == 2 ? 0 : (c->df_wps == 8 ? 2 : 1)]) : std::min(c->n_cu, c->df_grid_max[c->df_wps == 2 ? 0 : (c->df_wps == 8 ? 2 : 1)]);
       grid = std::max(1, std::min(grid, (int)nsl));
       c->df_grid_last = grid;
       double *part = want_dot ? c->partials : (double *)nullptr;
-#define DF_LAUNCH2(W, P)                                                                                                    \
-  hipLaunchKernelGGL((k_tri_dataflow<W, P>), dim3(grid), dim3(64 * W), 0, c->stream, nsl, S.L.pair_ptr, S.L.val2, S.L.col2, \
+#define DF_LAUNCH3(W, P, SOA)                                                                                                       \
+  hipLaunchKernelGGL((k_tri_dataflow<W, P, SOA>), dim3(grid), dim3(64 * W), 0, c->stream, nsl, S.L.pair_ptr, S.L.val2, S.L.col2, \
                      S.U.pair_ptr, S.U.val2, S.U.col2, sn, S.alu, r, S.zs, zbk, znat, part, gate_status(c), c->df_err, c->dbg_df_fail ? -1 : c->df_sleep)
+#define DF_LAUNCH2(W, P)                                    \
+  do {                                                      \
+    if (!full && c->df_soa) DF_LAUNCH3(W, P, true);         \
+    else DF_LAUNCH3(W, P, false);                           \
+  } while (0)
 #define DF_LAUNCH(W)                    \
   do {                                  \
     if (c->df_poll == 0) DF_LAUNCH2(W, 0); \
@@ -1824,6 +1830,7 @@ static int precond_apply_once(fx_context *c, const double *r, double *z, bool wa
       if (c->df_wps == 2) DF_LAUNCH(2);
       else if (c->df_wps == 8) DF_LAUNCH(8);
       else DF_LAUNCH(4);
+#undef DF_LAUNCH3
 #undef DF_LAUNCH
 #undef DF_LAUNCH2
       HIP_TRY(hipGetLastError());
