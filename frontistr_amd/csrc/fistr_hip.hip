@@ -2588,6 +2588,31 @@ extern "C" int fx_solve(fx_context *c, const fx_matrix_view *m, const fx_comm_vi
   return e ? e : ret;
 }
 
+// hecmw_solve for a system whose MATRIX was produced on the device (fx_nl_stiffness_at / fx_assemble_c3d8) and whose right-hand
+// side and prescribed dofs come from the host -- what fistr1's fstr_Newton hands over when the binding of INTEGRATION.md section 5
+// is in place: B and X go up (3*NP doubles each), the hecmw_mat_ass_bc calls fstr_AddBC made are applied to the resident matrix
+// and B (fx_mat_ass_bc), the resident system is solved, X comes back.  D / AL / AU of `m` are ignored (may be NULL).
+extern "C" int fx_solve_device_matrix(fx_context *c, const fx_matrix_view *m, const fx_comm_view *cm, int32_t n_bc, const int32_t *bc_node,
+                                      const int32_t *bc_dof, const double *bc_val, int32_t *Iarray, double *Rarray, fx_solve_info *info,
+                                      double *hist, int32_t hist_len) {
+  if (Iarray[98] != 1) { g_fx_error = "Iarray(99) selects a direct solver: outside the GPU hot path"; return FX_ERROR_UNSUPPORTED; }
+  if (m->NDOF != 3) { g_fx_error = "fx_solve_device_matrix: NDOF = 3 only"; return FX_ERROR_UNSUPPORTED; }
+  if (!c->have_profile || !c->have_values || c->A.N != m->N || c->A.NP != m->NP || c->A.NPL != m->NPL || c->A.NPU != m->NPU) {
+    g_fx_error = "fx_solve_device_matrix: no device-assembled matrix of this shape is resident";
+    return FX_ERROR_RUNTIME;
+  }
+  fx_matrix_view mv = *m;
+  mv.D = nullptr; mv.AL = nullptr; mv.AU = nullptr;
+  int e = fx_upload(c, &mv, cm, FX_UP_RHS | FX_UP_X);
+  if (e) return e;
+  if ((e = fx_mat_ass_bc(c, n_bc, bc_node, bc_dof, bc_val))) return e;
+  c->host_D = nullptr; c->host_AL = nullptr; c->host_AU = nullptr;  // the resident values are nobody's host arrays: a later fx_solve uploads its own
+  const int ret = fx_solve_resident(c, Iarray, Rarray, info, hist, hist_len);
+  if (ret < 0 || ret == FX_ERROR_ZERO_DIAG || ret == FX_ERROR_INCONS_PC) return ret;
+  e = fx_download_x(c, m->X, 3 * m->NP);
+  return e ? e : ret;
+}
+
 extern "C" int fx_matvec(fx_context *c, const fx_matrix_view *m, const fx_comm_view *cm, double *x, double *y,
                          double *commtime) {
   if (m->NDOF != 3) return nn_matvec(c, m, cm, x, y, commtime);

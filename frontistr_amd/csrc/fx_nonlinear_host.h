@@ -291,6 +291,71 @@ extern "C" int fx_nl_update(fx_context *c, double out[4], float *ms_update) {
   return 0;
 }
 
+// ---- the same two steps for a caller that keeps fstr_Newton's loop on the host (the Fortran binding of INTEGRATION.md section 5:
+// fistr1's own fstr_Newton drives them).  unode / dunode are the host's (fstrSOLID%unode, %dunode: 3*NP doubles each travel per
+// call, the 6.5 GB matrix does not); no boundary conditions, no right-hand side: fstr_AddBC and fstr_Update_NDForce stay the
+// reference's, their hecmw_mat_ass_bc calls reach the resident matrix through fx_mat_ass_bc.
+extern "C" int fx_nl_stiffness_at(fx_context *c, const double *unode, const double *dunode, float *ms_assemble) {
+  NL_READY("fx_nl_stiffness_at");
+  NlDev &n = c->nl;
+  const size_t np3 = (size_t)3 * c->A.NP * 8;
+  if (unode) HIP_TRY(hipMemcpyAsync(n.unode, unode, np3, hipMemcpyHostToDevice, c->stream));
+  if (dunode) HIP_TRY(hipMemcpyAsync(n.dunode, dunode, np3, hipMemcpyHostToDevice, c->stream));
+  return fx_nl_stiffness(c, 0, nullptr, nullptr, nullptr, ms_assemble);
+}
+
+// fstr_UpdateNewton (fstr_Update.f90:25-293) for the host's dunode (the host has already added the solver's X, fstr_solve_NonLinear.f90:95-97):
+// stresses / strains / plastic state of every quadrature point on the device, internal force QFORCE back to the host (before the
+// caller's hecmw_update_3_R, :284).
+extern "C" int fx_nl_update_at(fx_context *c, const double *dunode, double *qforce, float *ms_update) {
+  NL_READY("fx_nl_update_at");
+  NlDev &n = c->nl;
+  const size_t np3 = (size_t)3 * c->A.NP * 8;
+  if (dunode) HIP_TRY(hipMemcpyAsync(n.dunode, dunode, np3, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  HIP_TRY(hipMemsetAsync(n.qforce, 0, np3, c->stream));
+  nl_launch_update(c, nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(c->ev1, c->stream));
+  if (n.mat.plastic) n.latch = 1;  // MatlMatrix(..., isEp=1) has now been called (calMatMatrix.f90:43-45)
+  for (const NlMat &m : n.h_mats) if (m.plastic) n.latch = 1;
+  if (qforce) HIP_TRY(hipMemcpyAsync(qforce, n.qforce, np3, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (ms_update) HIP_TRY(hipEventElapsedTime(ms_update, c->ev0, c->ev1));
+  return 0;
+}
+
+// hecmw_mat_ass_bc (hecmw_mat_ass.f90:292-429) for a list of prescribed dofs on the RESIDENT matrix and right-hand side: column
+// times value moved to B, row and column zeroed, unit diagonal, B = value.  The list is what fstr_AddBC would have passed call by call.
+extern "C" int fx_mat_ass_bc(fx_context *c, int32_t n_bc, const int32_t *bc_node, const int32_t *bc_dof, const double *bc_val) {
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->have_values) { g_fx_error = "fx_mat_ass_bc: no matrix values resident"; return FX_ERROR_RUNTIME; }
+  if (n_bc <= 0) return 0;
+  DevCSR &A = c->A;
+  for (int32_t k = 0; k < n_bc; k++)
+    if (bc_node[k] < 1 || bc_node[k] > A.NP || bc_dof[k] < 1 || bc_dof[k] > 3) { g_fx_error = "fx_mat_ass_bc: node id / dof out of range"; return FX_ERROR_RUNTIME; }
+  DevScratch tmp;
+  uint8_t *d_flag = nullptr;
+  double *d_bcv = nullptr, *d_val = nullptr;
+  int32_t *d_node = nullptr, *d_dof = nullptr;
+  if (tmp.alloc(&d_flag, (size_t)3 * A.NP) || tmp.alloc(&d_bcv, (size_t)3 * A.NP) || tmp.alloc(&d_node, (size_t)n_bc) ||
+      tmp.alloc(&d_dof, (size_t)n_bc) || tmp.alloc(&d_val, (size_t)n_bc))
+    return FX_ERROR_RUNTIME;
+  HIP_TRY(hipMemsetAsync(d_flag, 0, (size_t)3 * A.NP, c->stream));
+  HIP_TRY(hipMemsetAsync(d_bcv, 0, (size_t)3 * A.NP * 8, c->stream));
+  HIP_TRY(hipMemcpyAsync(d_node, bc_node, (size_t)n_bc * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(d_dof, bc_dof, (size_t)n_bc * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(d_val, bc_val, (size_t)n_bc * 8, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_bc_mark, dim3((n_bc + 255) / 256), dim3(256), 0, c->stream, n_bc, d_node, d_dof, d_val, d_flag, d_bcv);
+  const dim3 g((A.NP + 255) / 256);
+  hipLaunchKernelGGL((k_bc_apply<1>), g, dim3(256), 0, c->stream, A.NP, A.indexL, A.itemL, A.indexU, A.itemU, A.D, A.AL, A.AU, A.B, d_flag, d_bcv);
+  hipLaunchKernelGGL((k_bc_apply<2>), g, dim3(256), 0, c->stream, A.NP, A.indexL, A.itemL, A.indexU, A.itemU, A.D, A.AL, A.AU, A.B, d_flag, d_bcv);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->bell_valid = false;  // the streaming layouts re-gather the values on next use
+  return 0;
+}
+
 // End of a converged substep (fstr_Newton :156-162): unode += dunode, fstr_UpdateState.
 extern "C" int fx_nl_commit(fx_context *c) {
   NL_READY("fx_nl_commit");

@@ -19,6 +19,11 @@ module hecmw_hip_binding
   private
   public :: fx_matrix_view, fx_comm_view, fx_solve_info
   public :: fx_solve, fx_matvec, fx_last_error, fx_solve_attempts, fx_solve_attempt_history
+  ! device-side assembly / stress update driven by fistr1's own fstr_Newton (INTEGRATION.md section 5)
+  public :: fx_mesh_view, fx_material_view, fx_nl_state_view
+  public :: fx_upload, fx_solve_device_matrix, fx_nl_init_sections, fx_nl_stiffness_at, fx_nl_update_at, fx_nl_commit, fx_nl_get_state, &
+            fx_nl_set_state
+  public :: fxb_matrix_on_device, fxb_defer_bc, fxb_solve_device_matrix, FX_UP_PROFILE
   public :: fxb_context, fxb_views, fxb_ensure_transport, fxb_error_text
 
   type, bind(C) :: fx_matrix_view
@@ -31,6 +36,25 @@ module hecmw_hip_binding
     integer(c_int32_t) :: my_rank, PETOT, nn_internal, n_node, n_neighbor_pe
     type(c_ptr) :: neighbor_pe, import_index, import_item, export_index, export_item
   end type fx_comm_view
+
+  type, bind(C) :: fx_mesh_view
+    integer(c_int32_t) :: n_node, n_elem
+    type(c_ptr) :: coord, conn
+  end type fx_mesh_view
+
+  type, bind(C) :: fx_material_view
+    real(c_double) :: E, nu
+    integer(c_int32_t) :: plastic, harden, nlgeom, ntab
+    real(c_double) :: plconst(3)
+    type(c_ptr) :: tab
+  end type fx_material_view
+
+  type, bind(C) :: fx_nl_state_view
+    type(c_ptr) :: stress, strain, stress_bak, strain_bak, plstrain, fstat, istat, unode, dunode, qforce
+    integer(c_int32_t) :: latch
+  end type fx_nl_state_view
+
+  integer(c_int), parameter :: FX_UP_PROFILE = 1
 
   type, bind(C) :: fx_solve_info
     integer(c_int32_t) :: iterations, method, precond, ncolor, n_hist
@@ -54,6 +78,62 @@ module hecmw_hip_binding
       real(c_double) :: hist(*)
       integer(c_int32_t), value :: hist_len
     end function fx_solve
+    integer(c_int) function fx_upload(ctx, mat, comm, what) bind(C, name='fx_upload')
+      import :: c_int, c_ptr, fx_matrix_view, fx_comm_view
+      type(c_ptr), value :: ctx
+      type(fx_matrix_view) :: mat
+      type(fx_comm_view) :: comm
+      integer(c_int), value :: what
+    end function fx_upload
+    integer(c_int) function fx_solve_device_matrix(ctx, mat, comm, n_bc, bc_node, bc_dof, bc_val, Iarray, Rarray, info, hist, hist_len) &
+        bind(C, name='fx_solve_device_matrix')
+      import :: c_int, c_ptr, c_int32_t, c_double, fx_matrix_view, fx_comm_view, fx_solve_info
+      type(c_ptr), value :: ctx
+      type(fx_matrix_view) :: mat
+      type(fx_comm_view) :: comm
+      integer(c_int32_t), value :: n_bc
+      integer(c_int32_t) :: bc_node(*), bc_dof(*)
+      real(c_double) :: bc_val(*)
+      integer(c_int32_t) :: Iarray(100)
+      real(c_double) :: Rarray(100)
+      type(fx_solve_info) :: info
+      real(c_double) :: hist(*)
+      integer(c_int32_t), value :: hist_len
+    end function fx_solve_device_matrix
+    integer(c_int) function fx_nl_init_sections(ctx, mesh, n_mat, mats, elem_mat) bind(C, name='fx_nl_init_sections')
+      import :: c_int, c_ptr, c_int32_t, fx_mesh_view, fx_material_view
+      type(c_ptr), value :: ctx
+      type(fx_mesh_view) :: mesh
+      integer(c_int32_t), value :: n_mat
+      type(fx_material_view) :: mats(*)
+      integer(c_int32_t) :: elem_mat(*)
+    end function fx_nl_init_sections
+    integer(c_int) function fx_nl_stiffness_at(ctx, unode, dunode, ms) bind(C, name='fx_nl_stiffness_at')
+      import :: c_int, c_ptr, c_double, c_float
+      type(c_ptr), value :: ctx
+      real(c_double) :: unode(*), dunode(*)
+      real(c_float) :: ms
+    end function fx_nl_stiffness_at
+    integer(c_int) function fx_nl_update_at(ctx, dunode, qforce, ms) bind(C, name='fx_nl_update_at')
+      import :: c_int, c_ptr, c_double, c_float
+      type(c_ptr), value :: ctx
+      real(c_double) :: dunode(*), qforce(*)
+      real(c_float) :: ms
+    end function fx_nl_update_at
+    integer(c_int) function fx_nl_commit(ctx) bind(C, name='fx_nl_commit')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx
+    end function fx_nl_commit
+    integer(c_int) function fx_nl_get_state(ctx, s) bind(C, name='fx_nl_get_state')
+      import :: c_int, c_ptr, fx_nl_state_view
+      type(c_ptr), value :: ctx
+      type(fx_nl_state_view) :: s
+    end function fx_nl_get_state
+    integer(c_int) function fx_nl_set_state(ctx, s) bind(C, name='fx_nl_set_state')
+      import :: c_int, c_ptr, fx_nl_state_view
+      type(c_ptr), value :: ctx
+      type(fx_nl_state_view) :: s
+    end function fx_nl_set_state
     integer(c_int) function fx_solve_attempts(ctx, cap, n_attempts, method, sigma_diag, n_hist) bind(C, name='fx_solve_attempts')
       import :: c_int, c_ptr, c_int32_t, c_double
       type(c_ptr), value :: ctx
@@ -105,12 +185,63 @@ module hecmw_hip_binding
   end interface
 
   type(c_ptr), save :: the_ctx = c_null_ptr
+  ! The matrix of the next hecmw_solve was assembled ON the device (set by the fistr1-side binding of fstr_StiffMatrix): hecMAT%D / AL /
+  ! AU on the host are stale, hecmw_mat_ass_bc only records its prescribed dofs (fxb_defer_bc), hecmw_solve applies them to the resident
+  ! matrix and solves it (fxb_solve_device_matrix).
+  logical, save :: fxb_matrix_on_device = .false.
+  integer(c_int32_t), allocatable, save :: dbc_node(:), dbc_dof(:)
+  real(c_double), allocatable, save :: dbc_val(:)
+  integer, save :: n_dbc = 0
   integer, save :: transport = 0              ! 0 none yet, 1 RCCL, 2 host callbacks through the reference's MPI layer
   ! what the callbacks need: the mesh whose tables they serve and the block size of the vector in flight
   type(hecmwST_local_mesh), pointer, save :: cb_mesh => null()
   integer(kind=kint), save :: cb_ndof = 3
 
 contains
+
+  !> hecmw_mat_ass_bc's hook (three-line patch of hecmw_mat_ass.f90:292, INTEGRATION.md section 5): while the matrix lives on the
+  !> device the prescribed dof is recorded for the solve instead of being eliminated from the (stale) host arrays.
+  logical function fxb_defer_bc(inode, idof, rhs)
+    integer(kind=kint), intent(in) :: inode, idof
+    real(kind=kreal), intent(in) :: rhs
+    integer(c_int32_t), allocatable :: ti(:)
+    real(c_double), allocatable :: tr(:)
+    integer :: cap
+    fxb_defer_bc = fxb_matrix_on_device
+    if (.not. fxb_matrix_on_device) return
+    if (.not. allocated(dbc_node)) then
+      allocate(dbc_node(1024), dbc_dof(1024), dbc_val(1024))
+    else if (n_dbc >= size(dbc_node)) then
+      cap = 2 * size(dbc_node)
+      allocate(ti(cap)); ti(1:n_dbc) = dbc_node(1:n_dbc); call move_alloc(ti, dbc_node)
+      allocate(ti(cap)); ti(1:n_dbc) = dbc_dof(1:n_dbc);  call move_alloc(ti, dbc_dof)
+      allocate(tr(cap)); tr(1:n_dbc) = dbc_val(1:n_dbc);  call move_alloc(tr, dbc_val)
+    endif
+    n_dbc = n_dbc + 1
+    dbc_node(n_dbc) = inode; dbc_dof(n_dbc) = idof; dbc_val(n_dbc) = rhs
+  end function fxb_defer_bc
+
+  !> hecmw_solve on the device-assembled matrix: right-hand side and X of hecMAT, the recorded prescribed dofs.
+  function fxb_solve_device_matrix(ctx, mv, cv, hecMAT, info, hist, nhist) result(ierr)
+    type(c_ptr), intent(in) :: ctx
+    type(fx_matrix_view) :: mv
+    type(fx_comm_view) :: cv
+    type(hecmwST_matrix), target :: hecMAT
+    type(fx_solve_info) :: info
+    real(c_double) :: hist(*)
+    integer(c_int32_t), intent(in) :: nhist
+    integer(c_int) :: ierr
+    integer(c_int32_t) :: none_i(1)
+    real(c_double) :: none_r(1)
+    if (n_dbc > 0) then
+      ierr = fx_solve_device_matrix(ctx, mv, cv, int(n_dbc, c_int32_t), dbc_node, dbc_dof, dbc_val, hecMAT%Iarray, hecMAT%Rarray, &
+                                    info, hist, nhist)
+    else
+      none_i = 0; none_r = 0.d0
+      ierr = fx_solve_device_matrix(ctx, mv, cv, 0_c_int32_t, none_i, none_i, none_r, hecMAT%Iarray, hecMAT%Rarray, info, hist, nhist)
+    endif
+    n_dbc = 0
+  end function fxb_solve_device_matrix
 
   !> The device context of this rank, created on first use (device = local rank: fx_create(-1)).
   function fxb_context(hecMESH) result(ctx)

@@ -95,7 +95,11 @@ contains
     end select
     nhist = max(hecmw_mat_get_iter(hecMAT), 1) + 1   ! GMRES logs MAXIT+1 lines when it runs out
     allocate(hist(nhist))
-    ierr = fx_solve(ctx, mv, cv, hecMAT%Iarray, hecMAT%Rarray, info, hist, int(nhist, c_int32_t))
+    if (fxb_matrix_on_device .and. hecMAT%NDOF == 3) then   ! the matrix was assembled on the device (fstr_StiffMatrix binding): B, X and the prescribed dofs go up
+      ierr = fxb_solve_device_matrix(ctx, mv, cv, hecMAT, info, hist, int(nhist, c_int32_t))
+    else
+      ierr = fx_solve(ctx, mv, cv, hecMAT%Iarray, hecMAT%Rarray, info, hist, int(nhist, c_int32_t))
+    endif
 
     ! One block per pass of the auto-SIGMA_DIAG / METHOD2 loop, as hecmw_solve_iterative prints them (:117-157): the banner of
     ! hecmw_solve_iterative_printmsg (:125), the pass's ITERLOG lines, and before a SIGMA_DIAG retry the list-directed line of :149.

@@ -256,6 +256,20 @@ int fx_nl_stiffness(fx_context *ctx, int32_t n_bc, const int32_t *bc_node, const
 /* dunode += X, fstr_UpdateNewton (fstr_Update.f90:25-293), fstr_Update_NDForce
  * (fstr_Residual.f90:23-71); out = {|B|^2,|X|^2,|QFORCE|^2,|dunode|^2} (may be NULL). */
 int fx_nl_update(fx_context *ctx, double out[4], float *ms_update);
+/* hecmw_solve (hecmw_solver.f90:9) for a matrix that was assembled ON the device: B and X of `mat` go up, the prescribed dofs
+ * fstr_AddBC passed to hecmw_mat_ass_bc (hecmw_mat_ass.f90:292-429) are applied to the resident matrix and B, the resident system
+ * is solved as fx_solve does, X comes back.  mat->D / AL / AU are ignored. */
+int fx_solve_device_matrix(fx_context *ctx, const fx_matrix_view *mat, const fx_comm_view *comm, int32_t n_bc, const int32_t *bc_node,
+                           const int32_t *bc_dof, const double *bc_val, int32_t *Iarray, double *Rarray, fx_solve_info *info,
+                           double *hist, int32_t hist_len);
+/* The two element loops for a caller that keeps fstr_Newton's own loop on the host (the Fortran binding of INTEGRATION.md section 5).
+ * fx_nl_stiffness_at: fstr_StiffMatrix (fstr_StiffMatrix.f90:18-212) for the host's unode / dunode (3*NP each, may be NULL = keep the
+ *   resident ones), tangent into the resident D / AL / AU, no boundary conditions (fstr_AddBC follows on the host side).
+ * fx_nl_update_at: fstr_UpdateNewton (fstr_Update.f90:25-293) for the host's dunode; QFORCE (3*NP) is written back.
+ * fx_mat_ass_bc: hecmw_mat_ass_bc (hecmw_mat_ass.f90:292-429) for a list of prescribed dofs on the resident matrix and B. */
+int fx_nl_stiffness_at(fx_context *ctx, const double *unode, const double *dunode, float *ms_assemble);
+int fx_nl_update_at(fx_context *ctx, const double *dunode, double *qforce, float *ms_update);
+int fx_mat_ass_bc(fx_context *ctx, int32_t n_bc, const int32_t *bc_node, const int32_t *bc_dof, const double *bc_val);
 /* unode += dunode, fstr_UpdateState (fstr_Update.f90:296-345). */
 int fx_nl_commit(fx_context *ctx);
 int fx_nl_get_state(fx_context *ctx, fx_nl_state_view *s);

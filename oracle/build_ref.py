@@ -263,15 +263,44 @@ def render_config_header(outdir):
         fh.write("".join(out))
 
 
-def fistr1_overrides(shimdir):
-    """Further reference modules a GPU build of fistr1 swaps (device assembly / stress update bindings); empty until
-    the files exist."""
+def fistr1_overrides(shimdir, gen):
+    """The fistr1-side half of the GPU build: the element loops of fstr_StiffMatrix / fstr_UpdateNewton /
+    fstr_UpdateState forwarded to the device for the decks the kernels cover.  The reference's own modules stay in the binary under
+    a new name (ONE renamed module line each, applied to scratch copies under oracle/_ref/, removed after the build) and
+    hecmw_mat_ass_bc gets a three-line hook (its prescribed dofs are recorded while the matrix lives on the device)."""
     over = {}
-    for mod, fn in (("m_fstr_stiffmatrix_hip", "fstr_stiffmatrix_hip.f90"),):
-        f = os.path.join(shimdir, fn)
-        if os.path.exists(f):
-            over[mod] = f
-    return over
+    need = ["fstr_device_hip.f90", "fstr_StiffMatrix_hip.f90", "fstr_Update_hip.f90"]
+    if not all(os.path.exists(os.path.join(shimdir, n)) for n in need):
+        return over, []
+    scratch = []
+
+    def patched(rel, edits, name):
+        with open(os.path.join(REF, rel)) as fh:
+            src = fh.read()
+        for a, b in edits:
+            assert src.count(a) == 1, "%s changed: update the patch (%r)" % (rel, a)
+            src = src.replace(a, b, 1)
+        out = os.path.join(gen, name)
+        with open(out, "w") as fh:
+            fh.write(src)
+        scratch.append(out)
+        return out
+
+    over["m_fstr_stiffmatrix_ref"] = patched("fistr1/src/analysis/static/fstr_StiffMatrix.f90",
+                                             [("\nmodule m_fstr_StiffMatrix\n", "\nmodule m_fstr_StiffMatrix_ref\n"),
+                                              ("end module m_fstr_StiffMatrix", "end module m_fstr_StiffMatrix_ref")], "fstr_StiffMatrix_ref.f90")
+    over["m_fstr_update_ref"] = patched("fistr1/src/analysis/static/fstr_Update.f90",
+                                        [("\nmodule m_fstr_Update\n", "\nmodule m_fstr_Update_ref\n"),
+                                         ("end module m_fstr_Update", "end module m_fstr_Update_ref")], "fstr_Update_ref.f90")
+    over["hecmw_matrix_ass"] = patched("hecmw1/src/solver/matrix/hecmw_mat_ass.f90",
+                                       [("\nmodule hecmw_matrix_ass\n  use hecmw_util\n", "\nmodule hecmw_matrix_ass\n  use hecmw_util\n  use hecmw_hip_binding, only: fxb_defer_bc\n"),
+                                        ("    NDOF = hecMAT%NDOF\n    if( NDOF < idof ) return\n\n    !C-- DIAGONAL block\n\n    hecMAT%B(NDOF*inode-(NDOF-idof)) = RHS\n",
+                                         "    NDOF = hecMAT%NDOF\n    if( NDOF < idof ) return\n    if (.not. present(conMAT)) then\n      if (fxb_defer_bc(inode, idof, RHS)) return\n    endif\n\n    !C-- DIAGONAL block\n\n    hecMAT%B(NDOF*inode-(NDOF-idof)) = RHS\n")],
+                                       "hecmw_mat_ass.f90")
+    over["m_fstr_stiffmatrix"] = os.path.join(shimdir, "fstr_StiffMatrix_hip.f90")
+    over["m_fstr_update"] = os.path.join(shimdir, "fstr_Update_hip.f90")
+    over["fstr_device_hip"] = os.path.join(shimdir, "fstr_device_hip.f90")
+    return over, scratch
 
 
 def build_partitioner(jobs):
@@ -372,18 +401,22 @@ def main():
             fh.write(src)
         over = {"hecmw_solver": shim, "hecmw_hip_binding": os.path.join(shimdir, "hecmw_hip_binding.f90"),
                 "hecmw_matvec_hip": os.path.join(shimdir, "hecmw_matvec_hip.f90"), "hecmw_solver_las": las}
-        over.update(fistr1_overrides(shimdir))
+        f1over, scratch = fistr1_overrides(shimdir, gen)
         link = (hiplib, "-Wl,-rpath," + os.path.dirname(hiplib), "-Wl,-rpath,/opt/rocm/lib")
         try:
             if want_shim:
                 build_variant("shim", [solve], False, a.jobs, provides, uses, overrides=over,
                               defines=("USE_SHIM",), exe_name="shim_solve", extra_link=link)
             if want_f1:
-                build_variant("shim", [fmain], False, a.jobs, provides, uses, overrides=over,
+                over1 = dict(over)
+                over1.update(f1over)
+                build_variant("f1hip", [fmain], False, a.jobs, provides, uses, overrides=over1,
                               defines=("USE_SHIM",), exe_name="fistr1_hip", extra_link=link,
                               c_main=cmain, c_main_flags=("-I", gen_cfg))
         finally:
-            os.remove(las)
+            for f in [las] + scratch:
+                if os.path.exists(f):
+                    os.remove(f)
             os.rmdir(gen)
     return 0
 

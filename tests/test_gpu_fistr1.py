@@ -47,6 +47,7 @@ def test_fistr1_exA_A361_on_the_gpu(method, precond, banner, iters):
     kw = {} if method is None else {"method": method, "precond": precond}
     r = _run("exA", "A361.msh", "A300.cnt", **kw)
     assert banner in r["stdout"], r["stdout"][:3000]
+    assert DEVICE_ASSEMBLY not in r["stdout"]          # linear STATIC: the incompatible-mode element, host element loops
     correct = f1.read_log(os.path.join(f1.DECKS, "exA", "A361_correct.log"))
     assert len(r["log"]) == 2 and f1.compare_step(r["log"][-1], correct[-1]) == []
     assert "### Relative residual =" in r["stdout"] and "### summary of linear solver" in r["stdout"]
@@ -57,10 +58,17 @@ def test_fistr1_exA_A361_on_the_gpu(method, precond, banner, iters):
         assert abs(len(h[0]) - iters) <= tol, len(h[0])
 
 
-def test_fistr1_exI_nlgeom_on_the_gpu():
+DEVICE_ASSEMBLY = "### libfistr_hip: stiffness assembly and stress update on the device"
+
+
+@pytest.mark.parametrize("assembly", ["device", "host"])
+def test_fistr1_exI_nlgeom_on_the_gpu(assembly):
     """examples/static/exI: `!STATIC, TYPE=NLGEOM`, 10 sub-steps, 2 Newton iterations each -- every step's summary against
-    exI/A361_correct.log."""
-    r = _run("exI", "A361.msh", "I300.cnt")
+    exI/A361_correct.log.  `device`: fstr_StiffMatrix / fstr_UpdateNewton / fstr_UpdateState run on the GPU too (the fistr1-side
+    binding of INTEGRATION.md section 5: the matrix never crosses PCIe); `host` (HECMW_GPU_ASSEMBLY=0): the reference's element loops,
+    only hecmw_solve on the GPU."""
+    r = _run("exI", "A361.msh", "I300.cnt", env={} if assembly == "device" else {"HECMW_GPU_ASSEMBLY": "0"})
+    assert (DEVICE_ASSEMBLY in r["stdout"]) == (assembly == "device")
     correct = f1.read_log(os.path.join(f1.DECKS, "exI", "A361_correct.log"))
     got = r["log"][1:]
     assert len(got) == len(correct) == 10
@@ -69,12 +77,14 @@ def test_fistr1_exI_nlgeom_on_the_gpu():
     assert [x[3] for x in r["sta"]] == [2] * 10
 
 
-def test_fistr1_plastic_cylinder_on_the_gpu():
+@pytest.mark.parametrize("assembly", ["device", "host"])
+def test_fistr1_plastic_cylinder_on_the_gpu(assembly):
     """tutorial/05_plastic_cylinder (configs[4]'s deck; multilinear Mises, updated Lagrange, CG + SSOR 1e-8, CONVERG 1e-3):
     Newton counts 36, 5, 5, 5, 5, 5, 5, 5 and the stop at sub-step 9 exactly as the unmodified program (FSTR.sta), every
     step's displacement / strain / stress extrema against the unmodified program's 0.log (tests/golden/decks/t05/, generator
     make_fistr1_golden.py; the reference ships no correct-log for this deck).  121 linear solves through hecmw_solve."""
-    r = _run("t05", "necking.msh", "necking.cnt")
+    r = _run("t05", "necking.msh", "necking.cnt", env={} if assembly == "device" else {"HECMW_GPU_ASSEMBLY": "0"})
+    assert (DEVICE_ASSEMBLY in r["stdout"]) == (assembly == "device")
     assert [x[3] for x in r["sta"][:8]] == [36, 5, 5, 5, 5, 5, 5, 5], r["sta"]
     assert r["sta"][8][2] == "1F" and "MAXITER" in r["sta"][8][4]
     assert r["stdout"].count("### 3x3 BLOCK CG, SSOR, 1") == 121
