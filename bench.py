@@ -251,7 +251,7 @@ def main():
     t0 = time.time()
     want_eis_variant = (a.method == 1 and a.precond == 1)
     if want_eis_variant:
-        ctx.set_option("FX_EISENSTAT", 1)   # set-up also stores the unfactored diagonal blocks (243 MB) the one-pass form needs
+        ctx.set_option("FX_EISENSTAT", 1)   # on a subdomain the set-up also builds the halo-column layout the one-pass form needs
     ctx.precond_setup(m)
     if want_eis_variant and not a.eisenstat:
         ctx.set_option("FX_EISENSTAT", 0)   # the headline loop is the reference's recurrence as written
@@ -281,32 +281,39 @@ def main():
     # Named variants in the same line: CG + SSOR in Eisenstat's one-pass form on the SAME context, data and
     # placement, timed exactly like the headline (W untimed + K timed iterations between barriers, max over ranks).
     variants = {}
-    if want_eis_variant and not a.eisenstat:
-        ctx.set_option("FX_EISENSTAT", 1)
-        ctx.krylov_begin(m)
-        ctx.krylov_steps(a.warmup)
-        barrier()
-        t0 = time.perf_counter()
-        it_v, status_v, resid_v = ctx.krylov_steps(a.steps)
-        barrier()
-        dt_v = time.perf_counter() - t0
-        active = bool(ctx.stats()["eisenstat"])
-        ctx.set_option("FX_EISENSTAT", 0)
-        if world > 1:
-            tv = torch.tensor([dt_v], dtype=torch.float64)
-            gv = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
-            dist.all_gather(gv, tv)
-            dt_v = max(float(x[0]) for x in gv)
-        if active and status_v == 0 and it_v == a.warmup + a.steps + 1:
-            # bytes of one iteration in this form: L and U once (values + column ids), the diagonal factors in both sweeps, the
-            # diagonal blocks in the forward sweep and in the update, 22 vector passes
-            eis_bytes = 76 * (st["L_blocks"] + st["U_blocks"]) + 4 * 72 * N + 22 * 24 * N
-            variants["eisenstat"] = {
-                "what": "CG + multicolour SSOR(1) in Eisenstat's one-pass form (opt-in FX_EISENSTAT=1: same iterates to rounding, matrix streamed once per iteration)",
-                "it_per_s": world * a.steps / dt_v, "ms_per_step": 1e3 * dt_v / a.steps, "bytes": eis_bytes,
-                "achieved_GBs": eis_bytes / (dt_v / a.steps) / 1e9, "frac": eis_bytes / (dt_v / a.steps) / 1e9 / HBM_PEAK_GBS,
-                "resid_after_steps": resid_v,
-            }
+    try:
+        if want_eis_variant and not a.eisenstat:
+            ctx.set_option("FX_EISENSTAT", 1)
+            ctx.krylov_begin(m)
+            ctx.krylov_steps(a.warmup)
+            barrier()
+            t0 = time.perf_counter()
+            it_v, status_v, resid_v = ctx.krylov_steps(a.steps)
+            barrier()
+            dt_v = time.perf_counter() - t0
+            active = bool(ctx.stats()["eisenstat"])
+            ctx.set_option("FX_EISENSTAT", 0)
+            if world > 1:
+                tv = torch.tensor([dt_v], dtype=torch.float64)
+                gv = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+                dist.all_gather(gv, tv)
+                dt_v = max(float(x[0]) for x in gv)
+            if active and status_v == 0 and it_v == a.warmup + a.steps + 1:
+                # bytes of one iteration in this form: L and U once (values + column ids), the diagonal factors in both sweeps and in
+                # the update (D~ x is formed from them: no second diagonal array), 21 vector passes
+                eis_bytes = 76 * (st["L_blocks"] + st["U_blocks"]) + 3 * 72 * N + 21 * 24 * N
+                variants["eisenstat"] = {
+                    "what": "CG + multicolour SSOR(1) in Eisenstat's one-pass form (opt-in FX_EISENSTAT=1: same iterates to rounding, matrix streamed once per iteration)",
+                    "it_per_s": world * a.steps / dt_v, "ms_per_step": 1e3 * dt_v / a.steps, "bytes": eis_bytes,
+                    "achieved_GBs": eis_bytes / (dt_v / a.steps) / 1e9, "frac": eis_bytes / (dt_v / a.steps) / 1e9 / HBM_PEAK_GBS,
+                    "resid_after_steps": resid_v,
+                }
+    except Exception as e:      # an optional sub-record must never cost the headline line
+        variants["eisenstat_error"] = repr(e)
+        try:
+            ctx.set_option("FX_EISENSTAT", 0)
+        except Exception:
+            pass
 
     # roofline of the dominant kernel, timed live with HIP events on the solver stream: the variant the timed loop
     # launches (CG: SpMV with the fused p.q partial; BiCGSTAB: the plain product)

@@ -379,7 +379,7 @@ static bool relieve_oom() {
 static void free_precond(fx_context *c) {
   dev_free(c->diag.alu);
   bell_free(c->ssor.L); bell_free(c->ssor.U); bell_free(c->ssor.H);
-  dev_free(c->ssor.alu); dev_free(c->ssor.dblk); dev_free(c->ssor.slot_node); dev_free(c->ssor.zs); dev_free(c->ssor.zb);
+  dev_free(c->ssor.alu); dev_free(c->ssor.slot_node); dev_free(c->ssor.zs); dev_free(c->ssor.zb);
   dev_free(c->ssor.lu_D); dev_free(c->ssor.lu_AL); dev_free(c->ssor.lu_AU);
   c->ssor = SsorDev();
   c->precond_valid = false;
@@ -1511,8 +1511,6 @@ static int ssor_setup_numeric(fx_context *c, double sigma_diag) {
   S.sigma_diag = sigma_diag;
   S.values_epoch = c->values_epoch;  // the sweep layouts hold the values the SpMV layout holds (fx_precond_setup ran ensure_solver first)
   if (c->eisenstat) {  // Eisenstat form: the diagonal blocks themselves, next to their factors
-    if (!S.dblk && dev_alloc(&S.dblk, (size_t)(nslots / 64) * 576)) return FX_ERROR_RUNTIME;
-    hipLaunchKernelGGL(k_dblk_setup, dim3((nslots + 255) / 256), dim3(256), 0, c->stream, nslots, c->A.N, S.slot_node, c->A.D, S.dblk);
     if (c->halo.n_neighbor > 0 && c->ord.kind == 1) {  // subdomain: the halo-column blocks, in the same slot order, columns = Krylov vector slots
       if (S.H.nslices == 0) {
         const int e = bell_build_device(c, S.H, BV_HALO, nslots, S.slot_node, c->ord.d_slot_of, nullptr);
@@ -2042,8 +2040,8 @@ static int eis_refresh_t(fx_context *c, const int32_t *gate) {
   SsorDev &S = c->ssor;
   const int32_t ns = c->ord.nslots;
   if (eis_sweep_forward_solve(c, c->W[0], c->W[3], gate)) return FX_ERROR_RUNTIME;
-  hipLaunchKernelGGL((k_eis_update<0>), dim3((ns + FX_BLOCK - 1) / FX_BLOCK), dim3(FX_BLOCK), 0, c->stream, ns, c->st, S.dblk,
-                     S.sigma_diag - 1.0, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, (double *)nullptr,
+  hipLaunchKernelGGL((k_eis_update<0>), dim3((ns + FX_BLOCK - 1) / FX_BLOCK), dim3(FX_BLOCK), 0, c->stream, ns, c->st, S.alu,
+                     (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, (double *)nullptr,
                      (double *)nullptr, c->W[3], c->W[4], c->partials, c->partials + c->max_partials, gate);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -2060,7 +2058,7 @@ static int eis_cg_iteration(fx_context *c, int it) {
   double *R = c->W[0], *P = c->W[1], *PH = c->W[2], *T = c->W[3], *DT = c->W[4], *V = c->W[5], *WH = c->W[6], *Q = c->W[7];
   double *X = c->Xs, *B = c->Bs;
   const int RECOMPUTE = 50, vgrid = grid_for(n3, FX_BLOCK, 2048), ugrid = (ns + FX_BLOCK - 1) / FX_BLOCK;
-  const double sm1 = S.sigma_diag - 1.0;
+  const double esc = (S.sigma_diag - 1.0) / S.sigma_diag;  // (D~ - D) = esc * diag(D~)
   double *part_rho = c->partials + c->max_partials;
   // rho = r.M^-1 r = t.D~t (:168), beta (:193); ph = D~ t + beta ph  [= (D~+U)(z + beta p)]
   if (scalar_stage<OP_CG_RHO>(c, ugrid, 0, RECOMPUTE, part_rho)) return FX_ERROR_RUNTIME;
@@ -2105,13 +2103,13 @@ static int eis_cg_iteration(fx_context *c, int it) {
       if (s1 - s0 <= c->split_max_slices) {
         g = s1 - s0;
         hipLaunchKernelGGL((k_eis_forward_split<4>), dim3(g), dim3(256), 0, c->stream, s0, s1, S.L.pair_ptr, S.L.val2, S.L.col2, S.alu,
-                           S.dblk, sm1, PH, P, V, WH, Q, c->partials, off, gate_status(c), HP);
+                           esc, PH, P, V, WH, Q, c->partials, off, gate_status(c), HP);
       } else if (c->ssor_bs == 64)
-        hipLaunchKernelGGL((k_eis_forward<64>), dim3(g), dim3(64), 0, c->stream, s0, s1, S.L.pair_ptr, S.L.val2, S.L.col2, S.alu, S.dblk,
-                           sm1, PH, P, V, WH, Q, c->partials, off, gate_status(c), HP);
+        hipLaunchKernelGGL((k_eis_forward<64>), dim3(g), dim3(64), 0, c->stream, s0, s1, S.L.pair_ptr, S.L.val2, S.L.col2, S.alu,
+                           esc, PH, P, V, WH, Q, c->partials, off, gate_status(c), HP);
       else
-        hipLaunchKernelGGL((k_eis_forward<256>), dim3(g), dim3(256), 0, c->stream, s0, s1, S.L.pair_ptr, S.L.val2, S.L.col2, S.alu, S.dblk,
-                           sm1, PH, P, V, WH, Q, c->partials, off, gate_status(c), HP);
+        hipLaunchKernelGGL((k_eis_forward<256>), dim3(g), dim3(256), 0, c->stream, s0, s1, S.L.pair_ptr, S.L.val2, S.L.col2, S.alu,
+                           esc, PH, P, V, WH, Q, c->partials, off, gate_status(c), HP);
       off += g;
     }
     HIP_TRY(hipGetLastError());
@@ -2120,14 +2118,14 @@ static int eis_cg_iteration(fx_context *c, int it) {
   }
   int np;
   if (it % RECOMPUTE == 0) {  // x += alpha p ; r = b - A x (:232-233) ; t, dt, rho from the new r
-    hipLaunchKernelGGL((k_eis_update<2>), dim3(ugrid), dim3(FX_BLOCK), 0, c->stream, ns, c->st, S.dblk, sm1, P, Q, WH, X, R, T, DT,
+    hipLaunchKernelGGL((k_eis_update<2>), dim3(ugrid), dim3(FX_BLOCK), 0, c->stream, ns, c->st, S.alu, P, Q, WH, X, R, T, DT,
                        c->partials, part_rho, gate_status(c));
     if (spmv(c, 1, 2, X, B, R, gate_status(c), 0)) return FX_ERROR_RUNTIME;
     np = spmv_nparts(c);
     if (scalar_stage<OP_RESID>(c, np, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
     if (eis_refresh_t(c, gate_status(c))) return FX_ERROR_RUNTIME;  // overwrites region 0 after OP_RESID has consumed it
   } else {
-    hipLaunchKernelGGL((k_eis_update<1>), dim3(ugrid), dim3(FX_BLOCK), 0, c->stream, ns, c->st, S.dblk, sm1, P, Q, WH, X, R, T, DT,
+    hipLaunchKernelGGL((k_eis_update<1>), dim3(ugrid), dim3(FX_BLOCK), 0, c->stream, ns, c->st, S.alu, P, Q, WH, X, R, T, DT,
                        c->partials, part_rho, gate_status(c));
     if (scalar_stage<OP_RESID>(c, ugrid, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;  // converged by the recurrence: the loop parks, verify_stage() follows from the host
   }
@@ -2167,7 +2165,7 @@ static int krylov_begin(fx_context *c, int method, int maxit, double tol) {
   // Eisenstat's form: CG + multicolour SSOR(1) in the colour-major numbering, when asked for (subdomains: with the halo term H p)
   // ... and only while M was built from the very values A holds: a recycled preconditioner (hecmw_mat_recycle_precond_setting keeps
   // the old one for up to three changed matrices) is a different splitting, and the identity A = (D~+L) + (D~+U) + (D - 2D~) is gone
-  c->eis_active = c->eisenstat && method == 1 && c->precond_kind == 1 && c->ord.kind == 1 && c->iterpremax == 1 && c->ssor.dblk &&
+  c->eis_active = c->eisenstat && method == 1 && c->precond_kind == 1 && c->ord.kind == 1 && c->iterpremax == 1 &&
                   c->ssor.values_epoch == c->values_epoch && (!halo_active(c) || c->ssor.H.nslices > 0);
   if (c->eis_active) { c->k_graph = false; if (eis_begin(c)) return FX_ERROR_RUNTIME; }
   return 0;

@@ -90,7 +90,6 @@ struct SsorDev {
   Bell L, U;                         // strictly-lower / strictly-upper parts in colour-slot order
   Bell H;                            // Eisenstat form on a subdomain: the halo-column blocks (what the localized L / U drop)
   double *alu = nullptr;             // LU of the diagonal blocks, [slice][e][lane] layout
-  double *dblk = nullptr;            // Eisenstat form: the diagonal blocks themselves (unfactored, unscaled), same layout
   double sigma_diag = 1.0;           // SIGMA_DIAG the factors in alu were built with
   int64_t values_epoch = -1;         // fx_context::values_epoch the sweep layouts were filled at
   int32_t nslots = 0;                // colour-major slots (each colour padded to a 64 multiple)

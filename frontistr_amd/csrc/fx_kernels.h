@@ -261,6 +261,23 @@ __device__ __forceinline__ void lusolve33_dev(const double *u, double &x1, doubl
   x1 = u[0] * (x1 - u[2] * x3 - u[1] * x2);
 }
 
+// D~ x from the in-place LU factors of lu33_dev (unit lower L, upper U with the RECIPROCALS of its pivots on the diagonal):
+// y = U x, then L y.  Also returns the diagonal of D~ (what SIGMA_DIAG scaled).  Lets Eisenstat's form stream the factors only --
+// the unfactored diagonal blocks need no array of their own.
+__device__ __forceinline__ void lumul33_dev(const double *u, double x1, double x2, double x3, double &y1, double &y2, double &y3,
+                                            double &d1, double &d2, double &d3) {
+  const double p1 = 1.0 / u[0], p2 = 1.0 / u[4], p3 = 1.0 / u[8];
+  const double t1 = p1 * x1 + u[1] * x2 + u[2] * x3;
+  const double t2 = p2 * x2 + u[5] * x3;
+  const double t3 = p3 * x3;
+  y1 = t1;
+  y2 = u[3] * t1 + t2;
+  y3 = u[6] * t1 + u[7] * t2 + t3;
+  d1 = p1;
+  d2 = u[3] * u[1] + p2;
+  d3 = u[6] * u[2] + u[7] * u[5] + p3;
+}
+
 // ALU setup: slot_row (may be null = identity) maps slot -> 0-based node; D in reference layout.
 // Output layout [slice][e][lane].
 __global__ void k_alu_setup(int32_t nslots, int32_t nrows, const int32_t *__restrict__ slot_row,
@@ -395,11 +412,12 @@ __global__ __launch_bounds__(64 * WPS) void k_ssor_color_split(int32_t slice0, i
                                                                const double *__restrict__ r, double *__restrict__ zs,
                                                                double *__restrict__ z, double *__restrict__ partials,
                                                                const int32_t *__restrict__ gate) {
-  if (gate && *gate != 0) return;
   __shared__ double part[WPS][3][64];
   const int slice = slice0 + blockIdx.x;  // grid = slice1 - slice0
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int32_t gv = gate ? *gate : 0;  // one scalar round trip for the gate AND the slice's row pointers (the early return used to serialise them)
   const int h0 = pair_ptr[slice], h1 = pair_ptr[slice + 1];
+  if (gv != 0) return;
   const int np = (h1 - h0) >> 1;
   // the finishing wave fetches its diagonal factor and right-hand side up front: they do not depend on the sweep,
   // so their latency overlaps the block pairs instead of following the LDS exchange
@@ -553,26 +571,28 @@ __device__ __forceinline__ void bell_row_sweep_dual(int h0, int h1, const double
 }
 
 // the row's own part of the forward Eisenstat sweep, from the two block sums sv = (L v)_i, sp = (L p)_i; returns ph_i . w_i
+// esc = (SIGMA_DIAG - 1) / SIGMA_DIAG: (D~ - D) p = esc * diag(D~) p (SIGMA_DIAG scales the three scalar diagonal entries only).
 __device__ __forceinline__ double eis_forward_finish(int slice, int lane, const double (&sv)[3], const double (&sp)[3],
-                                                     const double *__restrict__ alu, const double *__restrict__ dblk, double sm1,
+                                                     const double *__restrict__ alu, double esc,
                                                      const double *__restrict__ ph, const double *__restrict__ p,
                                                      double *__restrict__ v, double *__restrict__ w, double *__restrict__ q,
                                                      const double *__restrict__ hp) {
   const int slot = slice * 64 + lane;
-  double u[9], D[9];
+  double u[9];
   const size_t base = (size_t)slice * 576 + lane;
 #pragma unroll
-  for (int e = 0; e < 9; e++) { u[e] = alu[base + (size_t)e * 64]; D[e] = dblk[base + (size_t)e * 64]; }
+  for (int e = 0; e < 9; e++) u[e] = alu[base + (size_t)e * 64];
   const double p0 = p[(size_t)3 * slot], p1 = p[(size_t)3 * slot + 1], p2 = p[(size_t)3 * slot + 2];
   double h0v = ph[(size_t)3 * slot], h1v = ph[(size_t)3 * slot + 1], h2v = ph[(size_t)3 * slot + 2];
   const double pd = h0v, pe = h1v, pf = h2v;  // ph itself (the dot product p.q = ph.w uses it without the halo term)
   if (hp) {  // subdomain: A = (D~+L) + (D~+U) + (D - 2D~) + H with H the halo columns; H p enters g and q alike
     h0v += hp[(size_t)3 * slot]; h1v += hp[(size_t)3 * slot + 1]; h2v += hp[(size_t)3 * slot + 2];
   }
-  const double Dp0 = D[0] * p0 + D[1] * p1 + D[2] * p2, Dp1 = D[3] * p0 + D[4] * p1 + D[5] * p2, Dp2 = D[6] * p0 + D[7] * p1 + D[8] * p2;
-  const double e0 = sm1 * D[0] * p0, e1 = sm1 * D[4] * p1, e2 = sm1 * D[8] * p2;  // (D~ - D) p: SIGMA_DIAG scales the three scalar diagonal entries only
-  // g = ph + H p + (D - 2 D~) p = ph + H p - D p - 2 (D~ - D) p ;  v = D~^-1 (g - L v)
-  double x1 = h0v - Dp0 - 2.0 * e0 - sv[0], x2 = h1v - Dp1 - 2.0 * e1 - sv[1], x3 = h2v - Dp2 - 2.0 * e2 - sv[2];
+  double Tp0, Tp1, Tp2, d0, d1, d2;   // D~ p and diag(D~) from the factors
+  lumul33_dev(u, p0, p1, p2, Tp0, Tp1, Tp2, d0, d1, d2);
+  const double e0 = esc * d0 * p0, e1 = esc * d1 * p1, e2 = esc * d2 * p2;  // (D~ - D) p
+  // g = ph + H p + (D - 2 D~) p = ph + H p - D~ p - (D~ - D) p ;  v = D~^-1 (g - L v)
+  double x1 = h0v - Tp0 - e0 - sv[0], x2 = h1v - Tp1 - e1 - sv[1], x3 = h2v - Tp2 - e2 - sv[2];
   lusolve33_dev(u, x1, x2, x3);
   v[(size_t)3 * slot] = x1; v[(size_t)3 * slot + 1] = x2; v[(size_t)3 * slot + 2] = x3;
   const double w0 = p0 + x1, w1 = p1 + x2, w2 = p2 + x3;
@@ -585,7 +605,7 @@ __device__ __forceinline__ double eis_forward_finish(int slice, int lane, const 
 template <int BS>
 __global__ __launch_bounds__(BS) void k_eis_forward(int32_t slice0, int32_t slice1, const int32_t *__restrict__ pair_ptr,
                                                     const double *__restrict__ val2, const int *__restrict__ col2,
-                                                    const double *__restrict__ alu, const double *__restrict__ dblk, double sm1,
+                                                    const double *__restrict__ alu, double esc,
                                                     const double *__restrict__ ph, const double *__restrict__ p,
                                                     double *__restrict__ v, double *__restrict__ w, double *__restrict__ q,
                                                     double *__restrict__ partials, int32_t part0, const int32_t *__restrict__ gate,
@@ -598,7 +618,7 @@ __global__ __launch_bounds__(BS) void k_eis_forward(int32_t slice0, int32_t slic
   if (slice < slice1) {
     double sv[3] = {0.0, 0.0, 0.0}, sp[3] = {0.0, 0.0, 0.0};
     bell_row_sweep_dual(pair_ptr[slice], pair_ptr[slice + 1], val2, col2, lane, v, p, sv, sp);
-    d[0] = eis_forward_finish(slice, lane, sv, sp, alu, dblk, sm1, ph, p, v, w, q, hp);
+    d[0] = eis_forward_finish(slice, lane, sv, sp, alu, esc, ph, p, v, w, q, hp);
   }
   block_sum_store<1, BS>(d, partials, 0, part0 + vb);
 }
@@ -607,16 +627,17 @@ __global__ __launch_bounds__(BS) void k_eis_forward(int32_t slice0, int32_t slic
 template <int WPS>
 __global__ __launch_bounds__(64 * WPS) void k_eis_forward_split(int32_t slice0, int32_t slice1, const int32_t *__restrict__ pair_ptr,
                                                                 const double *__restrict__ val2, const int *__restrict__ col2,
-                                                                const double *__restrict__ alu, const double *__restrict__ dblk,
-                                                                double sm1, const double *__restrict__ ph, const double *__restrict__ p,
+                                                                const double *__restrict__ alu,
+                                                                double esc, const double *__restrict__ ph, const double *__restrict__ p,
                                                                 double *__restrict__ v, double *__restrict__ w, double *__restrict__ q,
                                                                 double *__restrict__ partials, int32_t part0,
                                                                 const int32_t *__restrict__ gate, const double *__restrict__ hp) {
-  if (gate && *gate != 0) return;
   __shared__ double part[WPS][6][64];
   const int slice = slice0 + blockIdx.x;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int32_t gv = gate ? *gate : 0;  // one scalar round trip for the gate AND the slice's row pointers (the early return used to serialise them)
   const int h0 = pair_ptr[slice], h1 = pair_ptr[slice + 1];
+  if (gv != 0) return;
   const int np = (h1 - h0) >> 1;
   double sv[3] = {0.0, 0.0, 0.0}, sp[3] = {0.0, 0.0, 0.0};
   const double2 *vbase = (const double2 *)(val2 + (size_t)h0 * 576) + lane;
@@ -657,7 +678,7 @@ __global__ __launch_bounds__(64 * WPS) void k_eis_forward_split(int32_t slice0, 
     for (int j = 1; j < WPS; j++)
 #pragma unroll
       for (int k = 0; k < 3; k++) { sv[k] += part[j][k][lane]; sp[k] += part[j][3 + k][lane]; }
-    d = eis_forward_finish(slice, lane, sv, sp, alu, dblk, sm1, ph, p, v, w, q, hp);
+    d = eis_forward_finish(slice, lane, sv, sp, alu, esc, ph, p, v, w, q, hp);
     d = wave_sum(d);
     if (lane == 0) partials[part0 + blockIdx.x] = d;
   }
@@ -707,11 +728,12 @@ __global__ __launch_bounds__(64 * WPS) void k_eis_backward_split(int32_t slice0,
                                                                  const double *__restrict__ alu, const KrylovState *__restrict__ st,
                                                                  const double *__restrict__ dt, double *__restrict__ ph,
                                                                  double *__restrict__ p, const int32_t *__restrict__ gate) {
-  if (gate && *gate != 0) return;
   __shared__ double part[WPS][3][64];
   const int slice = slice0 + blockIdx.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int32_t gv = gate ? *gate : 0;  // one scalar round trip for the gate AND the slice's row pointers (the early return used to serialise them)
   const int h0 = pair_ptr[slice], h1 = pair_ptr[slice + 1];
+  if (gv != 0) return;
   const int np = (h1 - h0) >> 1;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
   const double2 *vbase = (const double2 *)(val2 + (size_t)h0 * 576) + lane;
@@ -757,11 +779,11 @@ __global__ __launch_bounds__(256) void k_eis_halo(int32_t nslices, const int32_t
   hp[o] = s0; hp[o + 1] = s1; hp[o + 2] = s2;
 }
 
-// dt = D~ t and the partial of rho = t.dt; MODE 1 also x += alpha p, r -= alpha q (+ partial ||r||^2), t -= alpha w first;
+// dt = D~ t (from the LU factors: lumul33_dev) and the partial of rho = t.dt; MODE 1 also x += alpha p, r -= alpha q (+ partial ||r||^2), t -= alpha w first;
 // MODE 2: x += alpha p only (the iterations that recompute r = b - A x).  One thread per slot, blocks in [slice][e][lane] layout.
 template <int MODE>
 __global__ __launch_bounds__(FX_BLOCK) void k_eis_update(int32_t nslots, const KrylovState *__restrict__ st,
-                                                         const double *__restrict__ dblk, double sm1, const double *__restrict__ p,
+                                                         const double *__restrict__ alu, const double *__restrict__ p,
                                                          const double *__restrict__ q, const double *__restrict__ w,
                                                          double *__restrict__ x, double *__restrict__ r, double *__restrict__ t,
                                                          double *__restrict__ dt, double *__restrict__ part_rr,
@@ -785,13 +807,12 @@ __global__ __launch_bounds__(FX_BLOCK) void k_eis_update(int32_t nslots, const K
         t0 -= alpha * w[o]; t1 -= alpha * w[o + 1]; t2 -= alpha * w[o + 2];
         t[o] = t0; t[o + 1] = t1; t[o + 2] = t2;
       }
-      double D[9];
+      double u[9];
       const size_t base = (size_t)(slot >> 6) * 576 + (slot & 63);
 #pragma unroll
-      for (int e = 0; e < 9; e++) D[e] = dblk[base + (size_t)e * 64];
-      const double y0 = D[0] * t0 + D[1] * t1 + D[2] * t2 + sm1 * D[0] * t0;
-      const double y1 = D[3] * t0 + D[4] * t1 + D[5] * t2 + sm1 * D[4] * t1;
-      const double y2 = D[6] * t0 + D[7] * t1 + D[8] * t2 + sm1 * D[8] * t2;
+      for (int e = 0; e < 9; e++) u[e] = alu[base + (size_t)e * 64];
+      double y0, y1, y2, dd0, dd1, dd2;
+      lumul33_dev(u, t0, t1, t2, y0, y1, y2, dd0, dd1, dd2);   // D~ t from the factors
       dt[o] = y0; dt[o + 1] = y1; dt[o + 2] = y2;
       d[1] = t0 * y0 + t1 * y1 + t2 * y2;
     }
@@ -809,22 +830,6 @@ __global__ __launch_bounds__(FX_BLOCK) void k_eis_update(int32_t nslots, const K
     if (MODE == 1) part_rr[blockIdx.x] = a;
     part_rho[blockIdx.x] = b;
   }
-}
-
-// the diagonal blocks themselves in the [slice][e][lane] layout of the factors (padding slots: identity)
-__global__ void k_dblk_setup(int32_t nslots, int32_t nrows, const int32_t *__restrict__ slot_row, const double *__restrict__ D,
-                             double *__restrict__ dblk) {
-  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot >= nslots) return;
-  const int row = slot_row ? slot_row[slot] : slot;
-  double a[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-  if (row >= 0 && row < nrows) {
-#pragma unroll
-    for (int e = 0; e < 9; e++) a[e] = D[(size_t)9 * row + e];
-  }
-  const size_t base = (size_t)(slot >> 6) * 576 + (slot & 63);
-#pragma unroll
-  for (int e = 0; e < 9; e++) dblk[base + (size_t)e * 64] = a[e];
 }
 
 // ------------------------------------------------------------------------

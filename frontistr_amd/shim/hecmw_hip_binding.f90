@@ -23,6 +23,7 @@ module hecmw_hip_binding
   public :: fx_mesh_view, fx_material_view, fx_nl_state_view
   public :: fx_upload, fx_solve_device_matrix, fx_nl_init_sections, fx_nl_stiffness_at, fx_nl_update_at, fx_nl_commit, fx_nl_get_state, &
             fx_nl_set_state
+  public :: fxb_values_owner, fxb_values_addr
   public :: fxb_matrix_on_device, fxb_defer_bc, fxb_solve_device_matrix, FX_UP_PROFILE
   public :: fxb_context, fxb_views, fxb_ensure_transport, fxb_error_text
 
@@ -189,6 +190,10 @@ module hecmw_hip_binding
   ! AU on the host are stale, hecmw_mat_ass_bc only records its prescribed dofs (fxb_defer_bc), hecmw_solve applies them to the resident
   ! matrix and solves it (fxb_solve_device_matrix).
   logical, save :: fxb_matrix_on_device = .false.
+  ! Whose matrix values the (single) device context of this rank holds: 0 nobody's, 1 the last hecmw_solve's, 2 the hecmw_matvec
+  ! binding's (HECMW_GPU_MATVEC=resident re-uses them only while they are still its own: same owner, same hecMAT%D).
+  integer, save :: fxb_values_owner = 0
+  type(c_ptr), save :: fxb_values_addr = c_null_ptr
   integer(c_int32_t), allocatable, save :: dbc_node(:), dbc_dof(:)
   real(c_double), allocatable, save :: dbc_val(:)
   integer, save :: n_dbc = 0

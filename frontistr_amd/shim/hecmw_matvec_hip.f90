@@ -24,7 +24,6 @@ module hecmw_matvec_hip
   private
   public :: hecmw_matvec_hip_enabled, hecmw_matvec_on_gpu
   integer, save :: mode = -1          ! -1 not read yet, 0 off, 1 upload every call, 2 resident after the first call
-  logical, save :: have_resident = .false.
 
 contains
 
@@ -65,7 +64,9 @@ contains
     call fxb_ensure_transport(hecMESH, nd)
     call fxb_views(hecMESH, hecMAT, mv, cv)
     mv%B = c_null_ptr; mv%X = c_null_ptr
-    if (mode == 2 .and. have_resident) then   ! "the resident values" (include/fistr_hip.h: mat->D == NULL)
+    ! "the resident values" (include/fistr_hip.h: mat->D == NULL) only while they are still the ones THIS binding uploaded for
+    ! THIS matrix: a hecmw_solve in between puts its own (boundary-condition-modified) matrix into the shared context
+    if (mode == 2 .and. fxb_values_owner == 2 .and. c_associated(fxb_values_addr, c_loc(hecMAT%D(1)))) then
       mv%D = c_null_ptr; mv%AL = c_null_ptr; mv%AU = c_null_ptr
     endif
     allocate(xs(nd * np), ys(nd * np))        ! contiguous images (X, Y are assumed-shape and may be sections)
@@ -77,7 +78,8 @@ contains
       write(*,'(a,a)') '#### libfistr_hip-E: hecmw_matvec failed: ', trim(fxb_error_text())
       call hecmw_abort(hecmw_comm_get_comm())
     endif
-    have_resident = .true.
+    fxb_values_owner = 2
+    fxb_values_addr = c_loc(hecMAT%D(1))
     Y(1:nd * n) = ys(1:nd * n)
     if (np > n) X(nd * n + 1:nd * np) = xs(nd * n + 1:nd * np)
     if (present(COMMtime)) COMMtime = COMMtime + tcomm

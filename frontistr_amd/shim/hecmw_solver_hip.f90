@@ -95,6 +95,7 @@ contains
     end select
     nhist = max(hecmw_mat_get_iter(hecMAT), 1) + 1   ! GMRES logs MAXIT+1 lines when it runs out
     allocate(hist(nhist))
+    fxb_values_owner = 1      ! the context's matrix values are this solve's from here on (hecmw_matvec's resident mode re-uploads)
     if (fxb_matrix_on_device .and. hecMAT%NDOF == 3) then   ! the matrix was assembled on the device (fstr_StiffMatrix binding): B, X and the prescribed dofs go up
       ierr = fxb_solve_device_matrix(ctx, mv, cv, hecMAT, info, hist, int(nhist, c_int32_t))
     else

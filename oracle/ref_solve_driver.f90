@@ -5,6 +5,7 @@
 !>   mode 1: hecmw_solve_iterative   (hecmw_solver_Iterative.f90:13)
 !>   mode 2: hecmw_matvec            (hecmw_solver_las.f90:57)
 !>   mode 3: hecmw_precond_setup + hecmw_precond_apply (hecmw_precond.f90:28,75)
+!>   mode 5: hecmw_matvec, hecmw_solve of a scaled matrix, hecmw_matvec again (out: the second product)
 !> stdout carries the reference's own ITERLOG / summary lines.
 !>
 !> usage: ref_solve in.bin out.bin
@@ -129,6 +130,21 @@ program ref_solve
       call hecmw_matvec(hecMESH, hecMAT, hecMAT%X, Y, tcomm)
     enddo
     Y(nd*N+1:) = hecMAT%X(nd*N+1:)     ! the halo part of X after the update, in the unused tail of Y
+  case (5)   ! hecmw_matvec, then a solve of ANOTHER matrix of the same shape (D scaled), then hecmw_matvec with the first one again:
+    tcomm = 0.d0   ! the external callers' pattern around a solve (a resident-values binding must notice whose values the device holds)
+    call hecmw_matvec(hecMESH, hecMAT, hecMAT%X, Y, tcomm)
+    WK = hecMAT%D
+    hecMAT%D = hecMAT%D * 2.d0
+    X0 = hecMAT%X
+#ifdef USE_SHIM
+    call hecmw_solve(hecMESH, hecMAT)
+#else
+    call hecmw_solve_iterative(hecMESH, hecMAT)
+#endif
+    hecMAT%D = WK(1:size(hecMAT%D))
+    hecMAT%X = X0
+    call hecmw_matvec(hecMESH, hecMAT, hecMAT%X, Y, tcomm)
+    Y(nd*N+1:) = hecMAT%X(nd*N+1:)
   case (3)
     tcomm = 0.d0
     call hecmw_precond_setup(hecMAT, hecMESH, 1)

@@ -168,6 +168,24 @@ def test_shim_stdout_is_the_references(meth, pc):
     assert pos == sorted(pos)
 
 
+def test_resident_matvec_binding_notices_a_solve_in_between():
+    """HECMW_GPU_MATVEC=resident re-uses the values the hecmw_matvec binding uploaded -- but the binding shares the rank's one
+    device context with hecmw_solve, and a solve in between puts ITS matrix there.  hecmw_matvec, a hecmw_solve of
+    another matrix of the same shape (D scaled by 2), hecmw_matvec with the first matrix again: the second product must be the
+    first matrix's (= the reference CPU product), not the solver's."""
+    from oracle import refrun
+    if not refrun.have_ref("shim_solve"):
+        pytest.skip("oracle/_ref/shim_solve not built")
+    A = golden_matrix(load_golden("cube3s"))
+    A.X = np.sin(0.37 * np.arange(3 * A.NP) + 0.1)
+    I, R = refrun.default_params(method=1, precond=3, iterlog=0, timelog=0)
+    cpu = refrun.run_solve(A, I, R, mode=2, exe_name="shim_solve")                       # the reference's own product
+    res = refrun.run_solve(A, I, R, mode=5, exe_name="shim_solve", extra_env={"HECMW_GPU_MATVEC": "resident"})
+    assert cpu["returncode"] == 0 and res["returncode"] == 0, res["stdout"][-2000:]
+    n3 = 3 * A.N
+    assert np.abs(res["X"][:n3] - cpu["X"][:n3]).max() < 1e-13 * np.abs(cpu["X"][:n3]).max()
+
+
 @pytest.mark.parametrize("k", [0, 5])
 def test_shim_stdout_of_the_retry_loop_is_the_references(k):
     """The auto-SIGMA_DIAG / METHOD2 loop (hecmw_solver_Iterative.f90:117-157) prints its banner before EVERY pass (:125), the

@@ -72,6 +72,11 @@ def assert_documented_breakdown(hip, ctx, m, maxit):
 
 
 def check_solve(info, h_gpu, x_gpu, it_ref, h_ref, x_ref, meth, printed, whole=True):
+    """Bounds = about twice the drift measured between the GPU path and the (bit-exact) oracle over 24 runs, profiles/r02_parity_drift.txt
+    (round 3 tightened them from 25 % / 15 % / 1e-8 / 1e-7): CG history lines 1-10 <= 6e-14 (printed golden lines: 7 digits), every later
+    line <= 6.3e-2 on the cube decks; CG count equal in 11 of 12 runs; BiCGSTAB count within 3 % on the cubes; converged field CG <= 1.7e-11,
+    BiCGSTAB <= 4.4e-9.  `whole = False` (the ill-conditioned exA cantilever: its recurrences run rounding-dominated from line ~25 on,
+    the reference's own two thread counts differ by 2x in BiCGSTAB iterations): head of the history, count within 10 %, field."""
     n = min(len(h_ref), len(h_gpu))
     k = min(10, n)
     head = np.abs(h_gpu[:k] - h_ref[:k]) / h_ref[:k]
@@ -79,14 +84,14 @@ def check_solve(info, h_gpu, x_gpu, it_ref, h_ref, x_ref, meth, printed, whole=T
     if meth == 1:
         if whole:
             assert abs(info.iterations - it_ref) <= 1
-            assert np.all(np.abs(h_gpu[:n] - h_ref[:n]) <= 0.25 * h_ref[:n])
+            assert np.all(np.abs(h_gpu[:n] - h_ref[:n]) <= 0.15 * h_ref[:n])
         else:
             assert abs(info.iterations - it_ref) <= 0.1 * it_ref
-        assert relerr(x_gpu, x_ref) < 1e-8
+        assert relerr(x_gpu, x_ref) < 1e-9
     else:
         if whole:
-            assert abs(info.iterations - it_ref) <= max(2, 0.15 * it_ref)
-        assert relerr(x_gpu, x_ref) < 1e-7
+            assert abs(info.iterations - it_ref) <= max(2, 0.08 * it_ref)
+        assert relerr(x_gpu, x_ref) < 5e-8
 
 
 @pytest.mark.parametrize("deck", DECKS)
