@@ -242,6 +242,14 @@ def build_variant(name, drivers, omp, jobs, provides, uses, overrides=None, defi
     return exes
 
 
+def stable_mtime(scratch, source):
+    """A patched scratch copy is a function of its reference file and of this recipe: give it the newer of their two modification
+    times instead of 'now', so that an unchanged patch does not recompile the file (and, through the module dependencies, half the
+    tree) on every build."""
+    t = max(os.path.getmtime(source), os.path.getmtime(os.path.abspath(__file__)))
+    os.utime(scratch, (t, t))
+
+
 def render_config_header(outdir):
     """FrontISTRConfig.h from the reference's template (CMakeLists.txt:98-101, :360-363 do this with configure_file):
     version numbers from the reference's CMakeLists.txt, every WITH_* option off, HECMW_SERIAL on."""
@@ -283,6 +291,7 @@ def fistr1_overrides(shimdir, gen):
         out = os.path.join(gen, name)
         with open(out, "w") as fh:
             fh.write(src)
+        stable_mtime(out, os.path.join(REF, rel))
         scratch.append(out)
         return out
 
@@ -399,6 +408,7 @@ def main():
                                        "    endif\n" + body_anchor, 1)
         with open(las, "w") as fh:
             fh.write(src)
+        stable_mtime(las, os.path.join(REF, "hecmw1/src/solver/las/hecmw_solver_las.f90"))
         over = {"hecmw_solver": shim, "hecmw_hip_binding": os.path.join(shimdir, "hecmw_hip_binding.f90"),
                 "hecmw_matvec_hip": os.path.join(shimdir, "hecmw_matvec_hip.f90"), "hecmw_solver_las": las}
         f1over, scratch = fistr1_overrides(shimdir, gen)
