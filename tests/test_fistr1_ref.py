@@ -56,3 +56,20 @@ def test_reference_program_on_the_plastic_cylinder():
     assert len(r["log"]) == len(want) == 9
     for a, c in zip(r["log"], want):
         assert f1.compare_step(a, c) == []
+
+
+def _static_models():
+    import json
+    with open(os.path.join(f1.DECKS, "static", "manifest.json")) as fh:
+        return [tuple(x) for x in json.load(fh)]
+
+
+@pytest.mark.parametrize("sub,model,mesh,cnt,ndof", _static_models(), ids=lambda v: str(v))
+def test_reference_program_on_its_static_regression_decks(sub, model, mesh, cnt, ndof):
+    """examples/static/exA ... exG + FbarElement (83 models: 2-D, solid, shell; linear, NLGEOM, F-bar): the unmodified program
+    against the shipped *_correct.log, the baseline tests/test_gpu_fistr1.py holds fistr1_hip to."""
+    _need("fistr1_ref")
+    r = f1.run_deck("fistr1_ref", os.path.join("static", sub), mesh, cnt)
+    assert r["returncode"] == 0 and "FrontISTR Completed !!" in r["stdout"], r["stdout"][-2000:]
+    correct = f1.read_log(os.path.join(f1.DECKS, "static", sub, model + "_correct.log"))
+    assert correct and r["log"] and f1.compare_step(r["log"][-1], correct[-1]) == []

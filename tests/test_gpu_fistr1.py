@@ -92,3 +92,23 @@ def test_fistr1_plastic_cylinder_on_the_gpu(assembly):
     assert len(r["log"]) == len(want) == 9
     for a, c in zip(r["log"], want):
         assert f1.compare_step(a, c) == []
+
+
+def _static_models():
+    import json
+    with open(os.path.join(f1.DECKS, "static", "manifest.json")) as fh:
+        return [tuple(x) for x in json.load(fh)]
+
+
+@pytest.mark.parametrize("sub,model,mesh,cnt,ndof", _static_models(), ids=lambda v: str(v))
+def test_fistr1_static_regression_decks_on_the_gpu(sub, model, mesh, cnt, ndof):
+    """The reference's static regression suite (examples/static/test_static.sh: exA ... exG, every element family -- 2-D 231 /
+    232 / 241 / 242, solids 341 / 342 / 351 / 352 / 361 / 362, shells 731 / 741 -- plus FbarElement's NLGEOM beams) through
+    fistr1_hip: NDOF 2, 3 and 6 behind the same hecmw_solve, every linear solve on the GPU, judged against the shipped
+    *_correct.log at the reference's own 1e-4 (tests/test_fistr1_ref.py holds the unmodified program to the same files)."""
+    r = _run(os.path.join("static", sub), mesh, cnt)
+    assert "FrontISTR Completed !!" in r["stdout"], r["stdout"][-2000:]
+    if "ITERLOG=YES" in open(os.path.join(f1.DECKS, "static", sub, cnt)).read().upper().replace(" ", ""):
+        assert "### %dx%d BLOCK CG" % (ndof, ndof) in r["stdout"], r["stdout"][:3000]
+    correct = f1.read_log(os.path.join(f1.DECKS, "static", sub, model + "_correct.log"))
+    assert correct and r["log"] and f1.compare_step(r["log"][-1], correct[-1]) == []
