@@ -155,6 +155,13 @@ contains
     if (hecMESH%my_rank == 0 .and. (iterlog == 1 .or. timelog >= 1)) then
       write(*,"(a,1pe12.5)") '### Relative residual =', info%rel_resid
     endif
+    ! HECMW_GPU_REPORT=1: one line per solve that ran on the device, also for decks with ITERLOG=NO / TIMELOG=NO (regression runs
+    ! use it to prove where the solve ran; off by default: the reference's stdout is otherwise reproduced line for line)
+    call get_environment_variable('HECMW_GPU_REPORT', env, elen, estat)
+    if (hecMESH%my_rank == 0 .and. estat == 0 .and. elen > 0 .and. env(1:1) == '1') then
+      write(*,'(a,i0,a,i0,a,i0,a,i0)') '### libfistr_hip: solved on the device: NDOF=', hecMAT%NDOF, ' METHOD=', &
+        hecmw_mat_get_method(hecMAT), ' PRECOND=', precond, ' ITER=', info%iterations
+    endif
     if (hecMESH%my_rank == 0 .and. timelog >= 1) then
       TR = (info%time_sol - info%time_comm) / (info%time_sol + 1.d-24) * 100.d0
       write (*,'(/a)')          '### summary of linear solver'

@@ -83,6 +83,7 @@ def run(binary, workdir, threads=1, env=None, timeout=600):
     out = {"returncode": r.returncode, "stdout": r.stdout}
     p = os.path.join(workdir, "0.log")
     out["log"] = read_log(p) if os.path.exists(p) else []
+    out["heat"] = read_heat_log(p) if os.path.exists(p) else []
     p = os.path.join(workdir, "FSTR.sta")
     out["sta"] = read_sta(p) if os.path.exists(p) else []
     return out
@@ -138,6 +139,23 @@ def compare_step(actual, correct, threshold=THRESHOLD):
                 if not abs(c[j] - v[j]) <= threshold:
                     bad.append((part, k, what, v[j], c[j]))
     return bad
+
+
+def read_heat_log(path):
+    """Heat analyses: the `Maximum Temperature` / `Minimum Temperature` lines of 0.log, what examples/heat/test_heat_sub.sh
+    (print_u) extracts -> [('Maximum', t), ('Minimum', t), ...] over the printed steps."""
+    out = []
+    with open(path, errors="replace") as fh:
+        for line in fh:
+            m = re.match(r"\s*(Maximum|Minimum) Temperature\s*:\s*(\S+)", line)
+            if m:
+                out.append((m.group(1), _to_float(m.group(2))))
+    return out
+
+
+def heat_matches(got, want):
+    """the logs print temperatures with three decimals: 1e-3 absolute (+ 1e-6 relative for the large ones)"""
+    return len(got) == len(want) > 0 and all(a[0] == b[0] and abs(a[1] - b[1]) <= 1e-3 + 1e-6 * abs(b[1]) for a, b in zip(got, want))
 
 
 def read_sta(path):

@@ -73,3 +73,18 @@ def test_reference_program_on_its_static_regression_decks(sub, model, mesh, cnt,
     assert r["returncode"] == 0 and "FrontISTR Completed !!" in r["stdout"], r["stdout"][-2000:]
     correct = f1.read_log(os.path.join(f1.DECKS, "static", sub, model + "_correct.log"))
     assert correct and r["log"] and f1.compare_step(r["log"][-1], correct[-1]) == []
+
+
+def _heat_models():
+    import json
+    with open(os.path.join(f1.DECKS, "heat", "manifest.json")) as fh:
+        return [tuple(x) for x in json.load(fh)]
+
+
+@pytest.mark.parametrize("sub,model,mesh,cnt,ndof", _heat_models(), ids=lambda v: str(v))
+def test_reference_program_on_its_heat_regression_decks(sub, model, mesh, cnt, ndof):
+    """examples/heat/exM ... exT (80 models, NDOF = 1, CG + SSOR): the unmodified program against the shipped *_correct.log."""
+    _need("fistr1_ref")
+    r = f1.run_deck("fistr1_ref", os.path.join("heat", sub), mesh, cnt)
+    assert r["returncode"] == 0, r["stdout"][-2000:]
+    assert f1.heat_matches(r["heat"], f1.read_heat_log(os.path.join(f1.DECKS, "heat", sub, model + "_correct.log")))

@@ -106,9 +106,31 @@ def test_fistr1_static_regression_decks_on_the_gpu(sub, model, mesh, cnt, ndof):
     232 / 241 / 242, solids 341 / 342 / 351 / 352 / 361 / 362, shells 731 / 741 -- plus FbarElement's NLGEOM beams) through
     fistr1_hip: NDOF 2, 3 and 6 behind the same hecmw_solve, every linear solve on the GPU, judged against the shipped
     *_correct.log at the reference's own 1e-4 (tests/test_fistr1_ref.py holds the unmodified program to the same files)."""
-    r = _run(os.path.join("static", sub), mesh, cnt)
+    r = _run(os.path.join("static", sub), mesh, cnt, env={"HECMW_GPU_REPORT": "1"})
     assert "FrontISTR Completed !!" in r["stdout"], r["stdout"][-2000:]
+    assert "### libfistr_hip: solved on the device: NDOF=%d METHOD=1" % ndof in r["stdout"]
     if "ITERLOG=YES" in open(os.path.join(f1.DECKS, "static", sub, cnt)).read().upper().replace(" ", ""):
         assert "### %dx%d BLOCK CG" % (ndof, ndof) in r["stdout"], r["stdout"][:3000]
     correct = f1.read_log(os.path.join(f1.DECKS, "static", sub, model + "_correct.log"))
     assert correct and r["log"] and f1.compare_step(r["log"][-1], correct[-1]) == []
+
+
+def _heat_models():
+    import json
+    with open(os.path.join(f1.DECKS, "heat", "manifest.json")) as fh:
+        return [tuple(x) for x in json.load(fh)]
+
+
+@pytest.mark.parametrize("sub,model,mesh,cnt,ndof", _heat_models(), ids=lambda v: str(v))
+def test_fistr1_heat_regression_decks_on_the_gpu(sub, model, mesh, cnt, ndof):
+    """The reference's heat regression suite (examples/heat/test_heat.sh: exM ... exT, steady and transient conduction on every
+    element family; NDOF = 1, `!SOLVER,METHOD=1,PRECOND=2` = CG + SSOR) through fistr1_hip -- the scalar-block path behind the
+    same hecmw_solve -- judged on what test_heat_sub.sh extracts: the Maximum / Minimum Temperature lines of 0.log against the
+    shipped *_correct.log (three printed decimals: 1e-3)."""
+    if not f1.have("fistr1_hip"):
+        pytest.skip("oracle/_ref/fistr1_hip not built (needs /root/reference at build time)")
+    r = f1.run_deck("fistr1_hip", os.path.join("heat", sub), mesh, cnt, env={"HECMW_GPU_REPORT": "1"})
+    assert r["returncode"] == 0, r["stdout"][-3000:]
+    assert "### libfistr_hip: solved on the device: NDOF=1 METHOD=1 PRECOND=" in r["stdout"], r["stdout"][-1500:]
+    assert "reference CPU solver used" not in r["stdout"]
+    assert f1.heat_matches(r["heat"], f1.read_heat_log(os.path.join(f1.DECKS, "heat", sub, model + "_correct.log"))), (r["heat"], r["stdout"][-1500:])
