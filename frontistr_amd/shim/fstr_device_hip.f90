@@ -21,15 +21,35 @@ module fstr_device_hip
   use hecmw_hip_binding
   implicit none
   private
-  public :: fsd_stiffness, fsd_update_newton, fsd_update_state, fsd_active
+  public :: fsd_stiffness, fsd_update_newton, fsd_update_state, fsd_active, fsd_report
 
   logical, save :: decided = .false., eligible = .false., ready = .false.
+  ! linear static decks: the stiffness loop only (the tangent is constant, the stress update stays the reference's)
+  logical, save :: lin_decided = .false., lin_eligible = .false., lin_ready = .false.
+  integer(c_int), save :: lin_elemopt = 0
+  real(c_double), allocatable, target, save :: lin_E(:), lin_nu(:)
+  integer(c_int32_t), allocatable, target, save :: lin_emat(:)
   integer(c_int32_t), save :: n_elem = 0
   real(c_double), allocatable, target, save :: tabs(:,:,:)       ! (2, ntab_max, n_mat): the MC_YIELD tables handed to the library
   real(c_double), allocatable, target, save :: b6(:,:,:), b1(:,:), b6b(:,:,:)
   integer(c_int32_t), allocatable, target, save :: bi(:,:)
 
 contains
+
+  !> HECMW_GPU_REPORT=1: where each element loop ran and how long it took (wall clock), one line per call
+  subroutine fsd_report(what, seconds)
+    character(len=*), intent(in) :: what
+    real(kind=kreal), intent(in) :: seconds
+    character(len=8) :: env
+    integer :: elen, estat
+    logical, save :: asked = .false., on = .false.
+    if (.not. asked) then
+      asked = .true.
+      call get_environment_variable('HECMW_GPU_REPORT', env, elen, estat)
+      on = (estat == 0 .and. elen > 0 .and. env(1:1) == '1')
+    endif
+    if (on .and. hecmw_comm_get_rank() == 0) write(*,'(a,a,a,f10.3,a)') '### libfistr_hip: ', what, ': ', seconds, ' s'
+  end subroutine fsd_report
 
   logical function fsd_active()
     fsd_active = ready
@@ -86,6 +106,98 @@ contains
     if (hecMESH%my_rank == 0) write(*,'(a)') '### libfistr_hip: stiffness assembly and stress update on the device (TYPE=361 B-bar); '// &
       'HECMW_GPU_ASSEMBLY=0 keeps them on the host'
   end function fsd_eligible
+
+  !> Linear static analysis (`!SOLUTION, TYPE=STATIC`, small strain) of TYPE=361 elements with isotropic ELASTIC materials: the
+  !> element loop of fstr_StiffMatrix runs on the device -- STF_C3D8IC (the default of 361), STF_C3D8Bbar or STF_C3, whichever
+  !> `!SECTION ... ELEMOPT361` selects, the same for every section -- and the matrix stays there for hecmw_solve; fstr_UpdateNewton
+  !> (strains, stresses, QFORCE from the solution vector) remains the reference's routine, it never reads the matrix.
+  logical function fsd_eligible_linear(hecMESH, hecMAT, fstrSOLID)
+    type(hecmwST_local_mesh), intent(in) :: hecMESH
+    type(hecmwST_matrix), intent(in) :: hecMAT
+    type(fstr_solid), intent(in) :: fstrSOLID
+    character(len=8) :: env
+    integer :: elen, estat, i, icel, cid, opt
+    if (lin_decided) then
+      fsd_eligible_linear = lin_eligible
+      return
+    endif
+    lin_decided = .true.
+    lin_eligible = .false.
+    fsd_eligible_linear = .false.
+    call get_environment_variable('HECMW_GPU_ASSEMBLY', env, elen, estat)
+    if (estat == 0 .and. elen > 0 .and. env(1:1) == '0') return
+    call get_environment_variable('HECMW_GPU', env, elen, estat)
+    if (estat == 0 .and. elen > 0 .and. env(1:1) == '0') return
+    if (hecMAT%NDOF /= 3 .or. hecMESH%n_dof /= 3) return
+    if (fstrPR%solution_type /= kstSTATIC .or. fstrPR%nlgeom) return
+    if (hecMAT%Iarray(99) /= 1) return
+    if (hecMESH%n_elem_type /= 1) return
+    if (hecMESH%elem_type_item(1) /= 361) return
+    if (hecMESH%mpc%n_mpc > 0) return
+    if (fstrSOLID%TEMP_ngrp_tot > 0 .or. fstrSOLID%TEMP_irres > 0) return      ! thermal strains enter the element routine
+    if (fstrSOLID%SPRING_ngrp_tot > 0) return
+    if (associated(fstrSOLID%contacts)) then
+      if (size(fstrSOLID%contacts) > 0) return
+    endif
+    if (fstrSOLID%n_fix_mpc > 0) return
+    opt = -1
+    do i = 1, hecMESH%section%n_sect
+      if (opt == -1) opt = fstrSOLID%sections(i)%elemopt361
+      if (fstrSOLID%sections(i)%elemopt361 /= opt) return
+      if (hecMESH%section%sect_orien_ID(i) > 0) return
+    enddo
+    select case (opt)
+      case (kel361IC);   lin_elemopt = 1
+      case (kel361BBAR); lin_elemopt = 2
+      case (kel361FI);   lin_elemopt = 3
+      case default; return
+    end select
+    do icel = 1, hecMESH%n_elem
+      if (hecMESH%elem_node_index(icel) - hecMESH%elem_node_index(icel-1) /= 8) return
+      cid = hecMESH%section%sect_mat_ID_item(hecMESH%section_ID(icel))
+      if (.not. associated(fstrSOLID%elements(icel)%gausses(1)%pMaterial, fstrSOLID%materials(cid))) return
+    enddo
+    do i = 1, size(fstrSOLID%materials)
+      if (fstrSOLID%materials(i)%mtype == -1) cycle
+      if (fstrSOLID%materials(i)%mtype /= ELASTIC) return
+      if (fstrSOLID%materials(i)%nlgeom_flag /= INFINITE) return
+      if (fetch_TableRow(MC_ISOELASTIC, fstrSOLID%materials(i)%dict) > 1) return     ! temperature-dependent constants
+    enddo
+    lin_eligible = .true.
+    fsd_eligible_linear = .true.
+    if (hecMESH%my_rank == 0) write(*,'(a)') '### libfistr_hip: stiffness assembly on the device (linear static, TYPE=361); '// &
+      'HECMW_GPU_ASSEMBLY=0 keeps it on the host'
+  end function fsd_eligible_linear
+
+  subroutine fsd_init_linear(hecMESH, hecMAT, fstrSOLID)
+    type(hecmwST_local_mesh), intent(in), target :: hecMESH
+    type(hecmwST_matrix), intent(in), target :: hecMAT
+    type(fstr_solid), intent(in) :: fstrSOLID
+    type(c_ptr) :: ctx
+    type(fx_matrix_view) :: mv
+    type(fx_comm_view) :: cv
+    integer(c_int) :: ierr
+    integer :: i, icel, nmat
+    ctx = fxb_context(hecMESH)
+    call fxb_ensure_transport(hecMESH, 3)
+    call fxb_views(hecMESH, hecMAT, mv, cv)
+    mv%D = c_null_ptr; mv%AL = c_null_ptr; mv%AU = c_null_ptr; mv%B = c_null_ptr; mv%X = c_null_ptr   ! profile only
+    ierr = fx_upload(ctx, mv, cv, FX_UP_PROFILE)
+    if (ierr /= 0) call fsd_fail('profile upload')
+    nmat = size(fstrSOLID%materials)
+    if (allocated(lin_E)) deallocate(lin_E, lin_nu, lin_emat)
+    allocate(lin_E(nmat), lin_nu(nmat), lin_emat(hecMESH%n_elem))
+    lin_E = 1.d0; lin_nu = 0.d0
+    do i = 1, nmat
+      if (fstrSOLID%materials(i)%mtype == -1) cycle
+      lin_E(i) = fstrSOLID%materials(i)%variables(M_YOUNGS)
+      lin_nu(i) = fstrSOLID%materials(i)%variables(M_POISSON)
+    enddo
+    do icel = 1, hecMESH%n_elem
+      lin_emat(icel) = hecMESH%section%sect_mat_ID_item(hecMESH%section_ID(icel))
+    enddo
+    lin_ready = .true.
+  end subroutine fsd_init_linear
 
   logical function material_covered(m)
     type(tMaterial), intent(in) :: m
@@ -219,9 +331,21 @@ contains
     type(fstr_solid), intent(inout), target :: fstrSOLID
     integer(c_int) :: ierr
     real(c_float) :: ms
+    type(fx_mesh_view) :: mesh
     fsd_stiffness = .false.
     fxb_matrix_on_device = .false.
-    if (.not. fsd_eligible(hecMESH, hecMAT, fstrSOLID)) return
+    if (.not. fsd_eligible(hecMESH, hecMAT, fstrSOLID)) then
+      if (.not. fsd_eligible_linear(hecMESH, hecMAT, fstrSOLID)) return
+      if (.not. lin_ready) call fsd_init_linear(hecMESH, hecMAT, fstrSOLID)
+      mesh%n_node = hecMESH%n_node; mesh%n_elem = hecMESH%n_elem
+      mesh%coord = c_loc(hecMESH%node(1)); mesh%conn = c_loc(hecMESH%elem_node_item(1))
+      ierr = fx_assemble_c3d8_sections(fxb_context(hecMESH), mesh, int(size(lin_E), c_int32_t), lin_E, lin_nu, lin_emat, lin_elemopt, &
+                                       c_null_ptr, 0_c_int32_t, c_null_ptr, c_null_ptr, c_null_ptr, ms)
+      if (ierr /= 0) call fsd_fail('fx_assemble_c3d8_sections')
+      fxb_matrix_on_device = .true.
+      fsd_stiffness = .true.
+      return
+    endif
     if (.not. ready) call fsd_init(hecMESH, hecMAT, fstrSOLID)
     ierr = fx_nl_stiffness_at(fxb_context(hecMESH), fstrSOLID%unode, fstrSOLID%dunode, ms)
     if (ierr /= 0) call fsd_fail('fx_nl_stiffness_at')

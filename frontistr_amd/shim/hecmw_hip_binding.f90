@@ -22,7 +22,7 @@ module hecmw_hip_binding
   ! device-side assembly / stress update driven by fistr1's own fstr_Newton (INTEGRATION.md section 5)
   public :: fx_mesh_view, fx_material_view, fx_nl_state_view
   public :: fx_upload, fx_solve_device_matrix, fx_nl_init_sections, fx_nl_stiffness_at, fx_nl_update_at, fx_nl_commit, fx_nl_get_state, &
-            fx_nl_set_state
+            fx_nl_set_state, fx_assemble_c3d8_sections
   public :: fxb_values_owner, fxb_values_addr
   public :: fxb_matrix_on_device, fxb_defer_bc, fxb_solve_device_matrix, FX_UP_PROFILE
   public :: fxb_context, fxb_views, fxb_ensure_transport, fxb_error_text
@@ -101,6 +101,20 @@ module hecmw_hip_binding
       real(c_double) :: hist(*)
       integer(c_int32_t), value :: hist_len
     end function fx_solve_device_matrix
+    integer(c_int) function fx_assemble_c3d8_sections(ctx, mesh, n_mat, E, nu, elem_mat, elemopt, load, n_bc, bc_node, bc_dof, bc_val, ms) &
+        bind(C, name='fx_assemble_c3d8_sections')
+      import :: c_int, c_ptr, c_int32_t, c_double, c_float, fx_mesh_view
+      type(c_ptr), value :: ctx
+      type(fx_mesh_view) :: mesh
+      integer(c_int32_t), value :: n_mat
+      real(c_double) :: E(*), nu(*)
+      integer(c_int32_t) :: elem_mat(*)
+      integer(c_int), value :: elemopt
+      type(c_ptr), value :: load                 ! NULL: B is not touched
+      integer(c_int32_t), value :: n_bc
+      type(c_ptr), value :: bc_node, bc_dof, bc_val
+      real(c_float) :: ms
+    end function fx_assemble_c3d8_sections
     integer(c_int) function fx_nl_init_sections(ctx, mesh, n_mat, mats, elem_mat) bind(C, name='fx_nl_init_sections')
       import :: c_int, c_ptr, c_int32_t, fx_mesh_view, fx_material_view
       type(c_ptr), value :: ctx

@@ -42,13 +42,14 @@ contains
     character(len=16) :: msg_method, msg_precond
     logical :: on_gpu
     integer :: elen, estat
-    real(kind=kreal) :: TR
+    real(kind=kreal) :: TR, t_call
 
     ! Explicit opt-out: HECMW_GPU=0 keeps the reference's own CPU solver for every call, and says so.
     ! Configurations outside the GPU hot path -- other block sizes, direct solvers, MPC / contact matrices,
     ! preconditioners other than SSOR / DIAG / ILU(0) -- are REFUSED (E-message + abort), unless the user has asked for
     ! the reference's CPU code for exactly those with HECMW_GPU_UNSUPPORTED=reference.  Nothing is routed silently and
     ! nothing is routed by default.
+    t_call = hecmw_Wtime()
     call get_environment_variable('HECMW_GPU', env, elen, estat)
     precond = hecMAT%Iarray(3)
     if (estat == 0 .and. elen > 0 .and. env(1:1) == '0') then
@@ -159,8 +160,8 @@ contains
     ! use it to prove where the solve ran; off by default: the reference's stdout is otherwise reproduced line for line)
     call get_environment_variable('HECMW_GPU_REPORT', env, elen, estat)
     if (hecMESH%my_rank == 0 .and. estat == 0 .and. elen > 0 .and. env(1:1) == '1') then
-      write(*,'(a,i0,a,i0,a,i0,a,i0)') '### libfistr_hip: solved on the device: NDOF=', hecMAT%NDOF, ' METHOD=', &
-        hecmw_mat_get_method(hecMAT), ' PRECOND=', precond, ' ITER=', info%iterations
+      write(*,'(a,i0,a,i0,a,i0,a,i0,a,f9.3,a)') '### libfistr_hip: solved on the device: NDOF=', hecMAT%NDOF, ' METHOD=', &
+        hecmw_mat_get_method(hecMAT), ' PRECOND=', precond, ' ITER=', info%iterations, ' (whole call ', hecmw_Wtime() - t_call, ' s)'
     endif
     if (hecMESH%my_rank == 0 .and. timelog >= 1) then
       TR = (info%time_sol - info%time_comm) / (info%time_sol + 1.d-24) * 100.d0

@@ -420,7 +420,9 @@ def main():
             if want_f1:
                 over1 = dict(over)
                 over1.update(f1over)
-                build_variant("f1hip", [fmain], False, a.jobs, provides, uses, overrides=over1,
+                # OpenMP like fistr1_ref: the host parts the binding leaves to the reference (element loops of decks outside the
+                # device assembly, output) keep their threading -- a serial build spent 24 s in them on a 3 M-DOF linear deck
+                build_variant("f1hipomp", [fmain], True, a.jobs, provides, uses, overrides=over1,
                               defines=("USE_SHIM",), exe_name="fistr1_hip", extra_link=link,
                               c_main=cmain, c_main_flags=("-I", gen_cfg))
         finally:

@@ -9,6 +9,9 @@ import sys
 
 import numpy as np
 
+linear = "--linear" in sys.argv      # !SOLUTION, TYPE=STATIC: bench.py's workload (z = 0 clamped, unit load in x on every top node, E = 210000, nu = 0.3)
+if linear:
+    sys.argv.remove("--linear")
 d, n = sys.argv[1], int(sys.argv[2])
 nsub = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 method = sys.argv[4] if len(sys.argv) > 4 else "CG"
@@ -30,8 +33,28 @@ with open(os.path.join(d, "cube.msh"), "w") as fh:
     fh.write("!MATERIAL,NAME=MAT1,ITEM=1\n!ITEM=1,SUBITEM=2\n 206900.0,0.29\n!SECTION,TYPE=SOLID,EGRP=E1,MATERIAL=MAT1\n")
     fh.write("!NGROUP, NGRP=FIX, GENERATE\n 1,%d,1\n" % (m * m))
     fh.write("!NGROUP, NGRP=TOP, GENERATE\n %d,%d,1\n!END\n" % (m * m * n + 1, m * m * m))
-with open(os.path.join(d, "cube.cnt"), "w") as fh:
-    fh.write("""!VERSION
+if linear:
+    with open(os.path.join(d, "cube.cnt"), "w") as fh:
+        fh.write("""!VERSION
+ 3
+!SOLUTION, TYPE=STATIC
+!WRITE,RESULT,FREQUENCY=100000
+!BOUNDARY
+ FIX, 1, 3, 0.0
+!CLOAD
+ TOP, 1, 1.0
+!MATERIAL, NAME=MAT1
+!ELASTIC
+ 210000.0, 0.3
+!RESTART, FREQUENCY=100000
+!SOLVER,METHOD=%s,PRECOND=%s,ITERLOG=NO,TIMELOG=YES
+ 10000, 1
+ 1.0e-8, 1.0, 0.0
+!END
+""" % (method, precond))
+with open(os.path.join(d, "cube.cnt"), "a" if linear else "w") as fh:
+    if not linear:
+      fh.write("""!VERSION
  3
 !SOLUTION, TYPE=NLSTATIC
 !WRITE,RESULT,FREQUENCY=100000

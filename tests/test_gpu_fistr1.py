@@ -47,7 +47,7 @@ def test_fistr1_exA_A361_on_the_gpu(method, precond, banner, iters):
     kw = {} if method is None else {"method": method, "precond": precond}
     r = _run("exA", "A361.msh", "A300.cnt", **kw)
     assert banner in r["stdout"], r["stdout"][:3000]
-    assert DEVICE_ASSEMBLY not in r["stdout"]          # linear STATIC: the incompatible-mode element, host element loops
+    assert DEVICE_ASSEMBLY not in r["stdout"] and LINEAR_DEVICE_ASSEMBLY in r["stdout"]   # linear STATIC, incompatible-mode element: the stiffness loop on the device, the stress update the reference's
     correct = f1.read_log(os.path.join(f1.DECKS, "exA", "A361_correct.log"))
     assert len(r["log"]) == 2 and f1.compare_step(r["log"][-1], correct[-1]) == []
     assert "### Relative residual =" in r["stdout"] and "### summary of linear solver" in r["stdout"]
@@ -59,6 +59,7 @@ def test_fistr1_exA_A361_on_the_gpu(method, precond, banner, iters):
 
 
 DEVICE_ASSEMBLY = "### libfistr_hip: stiffness assembly and stress update on the device"
+LINEAR_DEVICE_ASSEMBLY = "### libfistr_hip: stiffness assembly on the device (linear static, TYPE=361)"
 
 
 @pytest.mark.parametrize("assembly", ["device", "host"])
