@@ -12,6 +12,9 @@ import numpy as np
 linear = "--linear" in sys.argv      # !SOLUTION, TYPE=STATIC: bench.py's workload (z = 0 clamped, unit load in x on every top node, E = 210000, nu = 0.3)
 if linear:
     sys.argv.remove("--linear")
+form361 = None                       # --form361 FI|BBAR|IC: `!SECTION, SECNUM=1, FORM361=...` (fstr_ctrl_common.f90:303-320); default: the program's (IC)
+if "--form361" in sys.argv:
+    k = sys.argv.index("--form361"); form361 = sys.argv[k + 1]; del sys.argv[k:k + 2]
 d, n = sys.argv[1], int(sys.argv[2])
 nsub = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 method = sys.argv[4] if len(sys.argv) > 4 else "CG"
@@ -46,12 +49,12 @@ if linear:
 !MATERIAL, NAME=MAT1
 !ELASTIC
  210000.0, 0.3
-!RESTART, FREQUENCY=100000
+%s!RESTART, FREQUENCY=100000
 !SOLVER,METHOD=%s,PRECOND=%s,ITERLOG=NO,TIMELOG=YES
  10000, 1
  1.0e-8, 1.0, 0.0
 !END
-""" % (method, precond))
+""" % ("!SECTION, SECNUM=1, FORM361=%s\n" % form361 if form361 else "", method, precond))
 with open(os.path.join(d, "cube.cnt"), "a" if linear else "w") as fh:
     if not linear:
       fh.write("""!VERSION

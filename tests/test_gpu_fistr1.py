@@ -159,3 +159,33 @@ def test_fistr1_nonlinear_tutorials_on_the_gpu(deck, mesh, cnt, newton, what):
     assert len(r["log"]) == len(want) == len(newton) + 1
     for a, c in zip(r["log"], want):
         assert f1.compare_step(a, c) == []
+
+
+@pytest.mark.parametrize("form361", [None, "IC", "BBAR", "FI"])
+def test_fistr1_linear_static_stiffness_on_the_device(form361, tmp_path):
+    """Linear static decks (`!SOLUTION, TYPE=STATIC`): fstr_StiffMatrix on the device for each of the element formulations the
+    binding admits -- the default and `!SECTION, FORM361=IC` (STF_C3D8IC), BBAR (STF_C3D8Bbar), FI (STF_C3) -- against the same
+    program with HECMW_GPU_ASSEMBLY=0 (the reference's element loop + upload) and against the unmodified program's extrema
+    where it is built: an 8^3-element cube of scripts/fistr1_cube_deck.py (bench.py's workload in small)."""
+    import subprocess
+    import sys
+    if not f1.have("fistr1_hip"):
+        pytest.skip("oracle/_ref/fistr1_hip not built (needs /root/reference at build time)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = str(tmp_path / "deck")
+    cmd = [sys.executable, os.path.join(root, "scripts", "fistr1_cube_deck.py"), d, "8", "--linear"] + (["--form361", form361] if form361 else [])
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
+    runs = {}
+    for mode, env in (("device", {}), ("host", {"HECMW_GPU_ASSEMBLY": "0"})):
+        r = f1.run("fistr1_hip", d, env=dict(env, HECMW_GPU_REPORT="1"))
+        assert r["returncode"] == 0 and "FrontISTR Completed !!" in r["stdout"], r["stdout"][-2000:]
+        assert (LINEAR_DEVICE_ASSEMBLY in r["stdout"]) == (mode == "device")
+        assert ("fstr_StiffMatrix on the device" in r["stdout"]) == (mode == "device")
+        assert "### libfistr_hip: solved on the device: NDOF=3 METHOD=1 PRECOND=1" in r["stdout"]
+        runs[mode] = r
+    a, b = runs["device"]["log"][-1], runs["host"]["log"][-1]
+    assert a["Node"].keys() == b["Node"].keys() and len(a["Node"]) >= 10
+    assert f1.compare_step(a, b, threshold=1e-7) == []          # same solver and tolerance 1e-8; the assemblies differ in rounding only
+    if f1.have("fistr1_ref"):
+        ref = f1.run("fistr1_ref", d, threads=2)
+        assert f1.compare_step(a, ref["log"][-1]) == []
