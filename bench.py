@@ -25,8 +25,9 @@ The JSON line also carries
                  time, peak 8 TB/s (MI355X_MICROARCH.md)
   cpu_baseline : the REAL reference (oracle/_ref/ref_solve_omp_o3, HEC-MW compiled from
                  /root/reference with flang -O3 -fopenmp) timed on this box's host cores (all
-                 cores of the affinity mask, capped by the cgroup CPU quota) on a bounded sample of the same workload (rank 0,
-                 N=1 only); --cpu-full times it on the full workload instead (minutes).
+                 cores of the affinity mask, capped by the cgroup CPU quota) on the SAME full-size system for a bounded
+                 number of iterations (40: ~6 s + 3 s of its set-up; rank 0, N=1 only); --cpu-sample-n 69 times a
+                 1.03M-DOF sample instead and scales by the DOF ratio.
 """
 import argparse
 import glob
