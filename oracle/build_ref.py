@@ -29,7 +29,7 @@ import os
 import re
 import subprocess
 import sys
-from concurrent.futures import ThreadPoolExecutor
+from concurrent.futures import FIRST_COMPLETED, ThreadPoolExecutor, wait
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = os.environ.get("FISTR_REFERENCE", "/root/reference")
@@ -147,18 +147,39 @@ def build_variant(name, drivers, omp, jobs, provides, uses, overrides=None, defi
             extra[f] = scan_driver(f)
     order = closure(drivers, provides, uses, extra)
     # Fortran must be compiled in dependency order (module files).
-    fobjs = []
+    fobjs = [objname(objdir, f) for f in order]
+    # up to date = newer than its source AND than the object of every module it uses (flang checks the hash of a used
+    # module file: a dependent compiled against the previous version of a changed module no longer links); a file whose
+    # used modules are being recompiled is recompiled too.  Decided in dependency order, then compiled `jobs` at a time,
+    # each file as soon as the modules it uses are done.
+    in_order = set(order)
+    deps, dirty = {}, {}
     for f in order:
         o = objname(objdir, f)
-        fobjs.append(o)
-        # up to date = newer than its source AND than the object of every module it uses (flang checks the hash of a used
-        # module file: a dependent compiled against the previous version of a changed module no longer links)
-        deps = [provides[m] for m in (uses[f] if f in uses else extra[f]) if m in provides and provides[m] != f]
-        if os.path.exists(o) and os.path.getmtime(o) > os.path.getmtime(f) and \
-                all(os.path.exists(objname(objdir, d)) and os.path.getmtime(objname(objdir, d)) <= os.path.getmtime(o) for d in deps):
-            continue
+        deps[f] = [d for d in (provides[m] for m in (uses[f] if f in uses else extra[f]) if m in provides and provides[m] != f) if d in in_order]
+        dirty[f] = not (os.path.exists(o) and os.path.getmtime(o) > os.path.getmtime(f) and
+                        all(not dirty[d] and os.path.exists(objname(objdir, d)) and os.path.getmtime(objname(objdir, d)) <= os.path.getmtime(o)
+                            for d in deps[f]))
+
+    def fc(f):
         print(f"[{name}] flang {os.path.relpath(f, REF) if f.startswith(REF) else f}", flush=True)
-        run([FLANG] + fflags + ["-c", f, "-o", o])
+        run([FLANG] + fflags + ["-c", f, "-o", objname(objdir, f)])
+        return f
+
+    todo = [f for f in order if dirty[f]]
+    done, running = set(f for f in order if not dirty[f]), {}
+    with ThreadPoolExecutor(max(1, jobs)) as ex:
+        while todo or running:
+            ready = [f for f in todo if all(d in done for d in deps[f])]
+            for f in ready:
+                todo.remove(f)
+                running[ex.submit(fc, f)] = f
+            if not running:
+                raise RuntimeError("module dependency cycle among: " + ", ".join(os.path.basename(f) for f in todo[:8]))
+            finished, _ = wait(list(running), return_when=FIRST_COMPLETED)
+            for fu in finished:
+                done.add(fu.result())     # re-raises a failed compile
+                del running[fu]
 
     # C side of hecmw (timer, comm stubs, logging, ...): compile the common C
     # files into an archive; the linker pulls what the Fortran objects need.
