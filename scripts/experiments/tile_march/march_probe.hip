@@ -26,7 +26,19 @@ __device__ __forceinline__ void lds_barrier() {
 #endif
 }
 
+#if defined(PROBE_UNIFORM) && defined(PROBE_PUBLISHER)
+#define NTHR 512   // six pair waves + finishing wave + store-only publisher: 256 VGPRs per lane, prefetch depth 4 without spills
+#define NPW 6
+#define PUBW 7
+#elif defined(PROBE_UNIFORM)
+#define NTHR 512   // every wave stores anyway: wave 1 publishes, no ninth wave
+#define NPW 7
+#define PUBW 1
+#else
 #define NTHR 576
+#define NPW 7
+#define PUBW 8
+#endif
 template <int DEPTH>
 __global__ __launch_bounds__(NTHR) void k_march(int T, const double2 *__restrict__ val, const double *__restrict__ zext,
                                                const double *__restrict__ rhs, double *__restrict__ zout) {
@@ -43,6 +55,36 @@ __global__ __launch_bounds__(NTHR) void k_march(int T, const double2 *__restrict
   double RH[DEPTH][3];
   const bool ext = (w >= 1 && w <= 4);
   auto prefetch = [&](int t, int b) {
+#ifdef PROBE_NOLOADS   // the chain alone: LDS gathers, FMAs, two barriers, reduction, substitution, ring write -- nothing from memory
+    if (t < 2 * DEPTH) {
+#pragma unroll
+      for (int e = 0; e < 9; e++) A[b][e] = make_double2(1e-3 * (e + lane), 2e-3);
+#pragma unroll
+      for (int k = 0; k < 6; k++) XE[b][k] = 1e-3 * k;
+#pragma unroll
+      for (int k = 0; k < 3; k++) RH[b][k] = 1.0 + k;
+    }
+    return;
+#endif
+#ifdef PROBE_UNIFORM
+    // EVERY wave issues the same vector-memory instructions at every step (the finishing and the publishing wave load a pair they
+    // do not use, steps past the end re-load the last one): no join with different numbers of loads in flight, so the compiler's
+    // wait insertion can count, and the younger prefetches stay in flight
+    const int tt = t < T ? t : T - 1;
+    const int wp = (w >= 1 && w <= NPW) ? w - 1 : 0;
+#ifdef PROBE_ACTIVE   // a tile of PROBE_ACTIVE lines instead of 64: the other lanes re-read lane 0's words (no extra bytes, no divergence)
+    const double2 *v = vt + (size_t)tt * tstride + (size_t)wp * 9 * 64 - (lane < PROBE_ACTIVE ? 0 : lane);
+#else
+    const double2 *v = vt + (size_t)tt * tstride + (size_t)wp * 9 * 64;
+#endif
+#pragma unroll
+    for (int e = 0; e < 9; e++) A[b][e] = v[e * 64];
+    const int la = (lane + w) & 63, lb = (lane + 2 * w + 1) & 63;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { XE[b][k] = ld_sc1(ze + (size_t)tt * 192 + k * 64 + la); XE[b][3 + k] = ld_sc1(ze + (size_t)tt * 192 + k * 64 + lb); }
+#pragma unroll
+    for (int k = 0; k < 3; k++) RH[b][k] = rhs[((size_t)tile * T + tt) * 192 + k * 64 + lane];
+#else
     if (t >= T) return;
     if (w == 8) return;   // the publisher wave loads nothing
     if (w >= 1) {
@@ -58,6 +100,7 @@ __global__ __launch_bounds__(NTHR) void k_march(int T, const double2 *__restrict
 #pragma unroll
       for (int k = 0; k < 3; k++) RH[b][k] = rhs[((size_t)tile * T + t) * 192 + k * 64 + lane];
     }
+#endif
   };
 #pragma unroll
   for (int b = 0; b < DEPTH; b++) prefetch(b, b);
@@ -66,7 +109,7 @@ __global__ __launch_bounds__(NTHR) void k_march(int T, const double2 *__restrict
     for (int b = 0; b < DEPTH; b++) {
       const int t = t0 + b;
       if (t < T) {
-        if (w >= 1 && w <= 7) {
+        if (w >= 1 && w <= NPW) {
           double x[6];
           if (ext) {
 #pragma unroll
@@ -89,7 +132,7 @@ __global__ __launch_bounds__(NTHR) void k_march(int T, const double2 *__restrict
         if (w == 0) {
           double s0 = part[1][0][lane], s1v = part[1][1][lane], s2v = part[1][2][lane];
 #pragma unroll
-          for (int k = 2; k < 8; k++) { s0 += part[k][0][lane]; s1v += part[k][1][lane]; s2v += part[k][2][lane]; }
+          for (int k = 2; k <= NPW; k++) { s0 += part[k][0][lane]; s1v += part[k][1][lane]; s2v += part[k][2][lane]; }
           // a 3x3 substitution's worth of dependent arithmetic
           double x1 = (RH[b][0] - s0) * 0.25, x2 = (RH[b][1] - s1v - 0.125 * x1) * 0.25, x3 = (RH[b][2] - s2v - 0.125 * x1 - 0.125 * x2) * 0.25;
           x3 *= 0.5; x2 = (x2 - 0.125 * x3) * 0.5; x1 = (x1 - 0.125 * x2 - 0.125 * x3) * 0.5;
@@ -100,7 +143,15 @@ __global__ __launch_bounds__(NTHR) void k_march(int T, const double2 *__restrict
 #endif
         }
         lds_barrier();
-#ifndef PROBE_FINISHER_STORES
+#ifdef PROBE_UNIFORM
+#ifdef PROBE_PUBLISHER
+        if (w == PUBW)   // ONLY the ninth wave stores: it loads nothing that matters, so nobody's loads wait behind a write-through acknowledgement
+#endif
+        {  // every wave stores three words per step (the publisher the result, the others into the scratch tail of zout)
+          double *zo = (w == PUBW ? zout + ((size_t)tile * T + t) * 192 : zout + ((size_t)gridDim.x * T + (size_t)tile * 9 + w) * 192) + lane;
+          st_sc1(zo, ring[t & (RING - 1)][0][lane]); st_sc1(zo + 64, ring[t & (RING - 1)][1][lane]); st_sc1(zo + 128, ring[t & (RING - 1)][2][lane]);
+        }
+#elif !defined(PROBE_FINISHER_STORES)
         if (w == 8) {  // the publisher: the write-through stores (and their acknowledgements, which a wave's later loads queue behind) are nobody's critical path
           double *zo = zout + ((size_t)tile * T + t) * 192 + lane;
           st_sc1(zo, ring[t & (RING - 1)][0][lane]); st_sc1(zo + 64, ring[t & (RING - 1)][1][lane]); st_sc1(zo + 128, ring[t & (RING - 1)][2][lane]);
@@ -131,7 +182,7 @@ int main(int argc, char **argv) {
   const int NT = argc > 1 ? atoi(argv[1]) : 256, T = argc > 2 ? atoi(argv[2]) : 276;
   const size_t nval = (size_t)NT * T * 7 * 9 * 64, nvec = (size_t)NT * T * 192;
   double2 *val; double *zext, *rhs, *zout;
-  CHECK(hipMalloc(&val, nval * 16)); CHECK(hipMalloc(&zext, nvec * 8)); CHECK(hipMalloc(&rhs, nvec * 8)); CHECK(hipMalloc(&zout, nvec * 8));
+  CHECK(hipMalloc(&val, nval * 16)); CHECK(hipMalloc(&zext, nvec * 8)); CHECK(hipMalloc(&rhs, nvec * 8)); CHECK(hipMalloc(&zout, (nvec + (size_t)NT * 9 * 192) * 8));
   std::vector<double> h(1 << 20);
   for (size_t i = 0; i < h.size(); i++) h[i] = 1e-3 * (double)((i * 2654435761u) % 1000);
   for (size_t off = 0; off < nval * 2; off += h.size()) CHECK(hipMemcpy((double *)val + off, h.data(), std::min(h.size(), nval * 2 - off) * 8, hipMemcpyHostToDevice));
