@@ -1991,7 +1991,7 @@ static int poll_state(fx_context *c, KrylovState *out) {
 }
 
 // ---------------------------------------------------------------------------
-// Eisenstat's form of CG + multicolour SSOR (opt-in, fx_context::eisenstat; kernels and recurrences: fx_kernels.h).
+// Eisenstat's form of CG + multicolour SSOR (the default where it is exact, fx_context::eisenstat; kernels and recurrences: fx_kernels.h).
 // Vectors: R W[0], P W[1], PH W[2] (= (D~+U) p), T W[3] (= (D~+L)^-1 r), DT W[4] (= D~ t), V W[5], WH W[6] (= (D~+L)^-1 A p), Q W[7].
 // Partial sums: ||r||^2 and ph.w in region 0 of c->partials, rho = t.dt in region 1 (it is consumed one scalar stage later).
 // ---------------------------------------------------------------------------
@@ -2167,7 +2167,7 @@ static int krylov_begin(fx_context *c, int method, int maxit, double tol) {
   // the old one for up to three changed matrices) is a different splitting, and the identity A = (D~+L) + (D~+U) + (D - 2D~) is gone
   c->eis_active = c->eisenstat && method == 1 && c->precond_kind == 1 && c->ord.kind == 1 && c->iterpremax == 1 &&
                   c->ssor.values_epoch == c->values_epoch && (!halo_active(c) || c->ssor.H.nslices > 0);
-  if (c->eis_active) { c->k_graph = false; if (eis_begin(c)) return FX_ERROR_RUNTIME; }
+  if (c->eis_active && eis_begin(c)) return FX_ERROR_RUNTIME;  // (graph replay serves this form too: its arguments are as constant over a solve as the standard loop's)
   return 0;
 }
 
@@ -2344,6 +2344,20 @@ extern "C" int fx_krylov_steps(fx_context *c, int32_t nsteps, int32_t *iter, int
   if (iter) *iter = s.iter;
   if (status) *status = s.status;
   if (resid) *resid = s.resid;
+  return 0;
+}
+
+// The ITERLOG channel of the staged loop (hecmw_solver_CG.f90:245, '(i7,1pe16.6)'): RESID of the iterations executed since
+// fx_krylov_begin, line i = iteration i.  *n_lines = lines the device has written, at most `cap` of them are copied.
+extern "C" int fx_krylov_history(fx_context *c, double *hist, int32_t cap, int32_t *n_lines) {
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->st || !c->hist) { g_fx_error = "fx_krylov_history: no Krylov loop was started on this context"; return FX_ERROR_RUNTIME; }
+  KrylovState s;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipMemcpy(&s, c->st, sizeof s, hipMemcpyDeviceToHost));
+  const int32_t n = std::max(0, std::min(s.n_hist, c->hist_cap));
+  if (n_lines) *n_lines = n;
+  if (hist && cap > 0 && n > 0) HIP_TRY(hipMemcpy(hist, c->hist, (size_t)std::min(cap, n) * 8, hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -2845,3 +2859,4 @@ extern "C" int fx_get_ssor_ordering(fx_context *c, int32_t *perm, int32_t *color
 
 #include "fx_assemble_host.h"
 #include "fx_nonlinear_host.h"
+#include "fx_debug_host.h"

@@ -278,13 +278,14 @@ struct fx_context {
   // non-temporal stream loads): SpMV 1.14-1.17 -> 1.105-1.11 ms; colour sweeps 1.685 -> 1.61 ms per apply.
   // (With the earlier padded layout it cost the SpMV 1.19 -> 1.30 ms: re-measure when the layout changes.)
   bool pipe_spmv = true, pipe_ssor = true;  // FX_PIPE_SPMV / FX_PIPE_SSOR override
-  // Eisenstat's form of CG + SSOR (opt-in, FX_EISENSTAT=1): with M = (D~+L) D~^-1 (D~+U) and A = (D~+L) + (D~+U) + (D - 2D~),
-  // one backward and one forward triangular sweep per iteration deliver p, q = A p and w = (D~+L)^-1 q -- the matrix is
-  // streamed ONCE instead of twice (SpMV + the two half sweeps).  Same x_k, r_k, rho_k, alpha_k in exact arithmetic; the
-  // summation order of q and of the dot products differs, so histories agree to rounding, not bit for bit: hence opt-in.
-  // Multicolour SSOR with iterPREmax = 1, colour-major numbering, preconditioner built from the resident values (subdomains: plus
-  // the halo term H p); anything else runs the standard loop.
-  bool eisenstat = false, eis_active = false;
+  // Eisenstat's form of CG + SSOR (the default since round 4; FX_EISENSTAT=0 runs hecmw_solve_CG's loop as written): with
+  // M = (D~+L) D~^-1 (D~+U) and A = (D~+L) + (D~+U) + (D - 2D~), one backward and one forward triangular sweep per iteration deliver
+  // p, q = A p and w = (D~+L)^-1 q -- the matrix is streamed ONCE instead of twice (SpMV + the two half sweeps).  Same x_k, r_k,
+  // rho_k, alpha_k in exact arithmetic; the summation order of q and of the dot products differs, so histories agree to rounding
+  // (the parity bounds of tests/test_gpu_parity.py hold in both modes), not bit for bit.  It is taken only where it is exact:
+  // multicolour SSOR with iterPREmax = 1, colour-major numbering, preconditioner built from the resident values (subdomains: plus
+  // the halo term H p); anything else -- a recycled preconditioner, iterPREmax != 1, BiCGSTAB -- runs the standard loop on its own.
+  bool eisenstat = true, eis_active = false;
   bool dbg_onecolor = false; // measurement only (FX_DEBUG_ONECOLOR): the half sweeps as one launch each, dependencies ignored
   bool eis_fuse = true;      // direction update fused into the backward sweep (FX_EIS_FUSE=0: k_cg_update_p + the plain sweep)
   int64_t values_epoch = 0;  // counts the refreshes of the SpMV layout's values

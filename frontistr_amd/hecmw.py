@@ -285,6 +285,14 @@ class SolverContext:
         _chk(lib().fx_krylov_steps(self.h, int(nsteps), C.byref(it), C.byref(st), C.byref(rs)))
         return it.value, st.value, rs.value
 
+    def krylov_history(self):
+        """RESID per iteration of the staged loop since krylov_begin (the reference's ITERLOG lines, hecmw_solver_CG.f90:245)."""
+        n = C.c_int32(0)
+        _chk(lib().fx_krylov_history(self.h, None, 0, C.byref(n)))
+        h = np.zeros(max(n.value, 1))
+        _chk(lib().fx_krylov_history(self.h, _ptr(h), n.value, C.byref(n)))
+        return h[:n.value]
+
     def precond_apply(self, r):
         r = np.ascontiguousarray(r, dtype=np.float64)
         z = np.zeros_like(r)

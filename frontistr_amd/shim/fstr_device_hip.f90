@@ -75,7 +75,7 @@ contains
     if (estat == 0 .and. elen > 0 .and. env(1:1) == '0') return
     if (hecMAT%NDOF /= 3 .or. hecMESH%n_dof /= 3) return
     if (fstrPR%solution_type /= kstSTATIC .or. .not. fstrPR%nlgeom) return
-    if (hecMAT%Iarray(99) /= 1) return                                       ! iterative solvers only (hecmw_solve on the GPU)
+    if (.not. fxb_on_gpu_path(hecMESH, hecMAT)) return                       ! the solve must run on the device too: same predicate as hecmw_solve (method, preconditioner, no MPC / contact)
     if (hecMESH%n_elem_type /= 1) return
     if (hecMESH%elem_type_item(1) /= 361) return
     if (hecMESH%mpc%n_mpc > 0) return
@@ -130,7 +130,7 @@ contains
     if (estat == 0 .and. elen > 0 .and. env(1:1) == '0') return
     if (hecMAT%NDOF /= 3 .or. hecMESH%n_dof /= 3) return
     if (fstrPR%solution_type /= kstSTATIC .or. fstrPR%nlgeom) return
-    if (hecMAT%Iarray(99) /= 1) return
+    if (.not. fxb_on_gpu_path(hecMESH, hecMAT)) return
     if (hecMESH%n_elem_type /= 1) return
     if (hecMESH%elem_type_item(1) /= 361) return
     if (hecMESH%mpc%n_mpc > 0) return

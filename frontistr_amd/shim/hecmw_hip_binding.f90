@@ -25,7 +25,7 @@ module hecmw_hip_binding
             fx_nl_set_state, fx_assemble_c3d8_sections
   public :: fxb_values_owner, fxb_values_addr
   public :: fxb_matrix_on_device, fxb_defer_bc, fxb_solve_device_matrix, FX_UP_PROFILE
-  public :: fxb_context, fxb_views, fxb_ensure_transport, fxb_error_text
+  public :: fxb_context, fxb_views, fxb_ensure_transport, fxb_error_text, fxb_on_gpu_path, fx_get_stats
 
   type, bind(C) :: fx_matrix_view
     integer(c_int32_t) :: N, NP, NPL, NPU, NDOF
@@ -170,6 +170,11 @@ module hecmw_hip_binding
       real(c_double) :: x(*), y(*)
       real(c_double) :: commtime
     end function fx_matvec
+    integer(c_int) function fx_get_stats(ctx, out) bind(C, name='fx_get_stats')
+      import :: c_ptr, c_int, c_int64_t
+      type(c_ptr), value :: ctx
+      integer(c_int64_t) :: out(16)
+    end function fx_get_stats
     function fx_last_error() bind(C, name='fx_last_error') result(p)
       import :: c_ptr
       type(c_ptr) :: p
@@ -218,6 +223,24 @@ module hecmw_hip_binding
 
 contains
 
+  !> ONE predicate for "this hecmw_solve call runs on the device": iterative solver, no MPC / contact matrix, a preconditioner and
+  !> method the library has for this block size (include/fistr_hip.h).  hecmw_solve routes by it, and the fistr1-side binding of the
+  !> element loops (fsd_eligible / fsd_eligible_linear) assembles on the device only when it holds -- a matrix assembled on the
+  !> device can be solved nowhere else (the host D / AL / AU are never filled).
+  logical function fxb_on_gpu_path(hecMESH, hecMAT)
+    type(hecmwST_local_mesh), intent(in) :: hecMESH
+    type(hecmwST_matrix), intent(in) :: hecMAT
+    integer(kind=kint) :: precond
+    precond = hecMAT%Iarray(3)
+    fxb_on_gpu_path = hecMAT%Iarray(99) == 1 .and. hecMESH%mpc%n_mpc == 0 .and. hecMAT%cmat%n_val == 0
+    if (hecMAT%NDOF == 3) then
+      fxb_on_gpu_path = fxb_on_gpu_path .and. (precond == 1 .or. precond == 2 .or. precond == 3 .or. precond == 10)
+    else   ! generic block sizes: METHOD 1-4 with SSOR / DIAG
+      fxb_on_gpu_path = fxb_on_gpu_path .and. hecMAT%NDOF >= 1 .and. hecMAT%NDOF <= 6 .and. (precond >= 1 .and. precond <= 3) .and. &
+                        (hecMAT%Iarray(2) >= 1 .and. hecMAT%Iarray(2) <= 4)
+    endif
+  end function fxb_on_gpu_path
+
   !> hecmw_mat_ass_bc's hook (three-line patch of hecmw_mat_ass.f90:292, INTEGRATION.md section 5): while the matrix lives on the
   !> device the prescribed dof is recorded for the solve instead of being eliminated from the (stale) host arrays.
   logical function fxb_defer_bc(inode, idof, rhs)
@@ -260,6 +283,7 @@ contains
       ierr = fx_solve_device_matrix(ctx, mv, cv, 0_c_int32_t, none_i, none_i, none_r, hecMAT%Iarray, hecMAT%Rarray, info, hist, nhist)
     endif
     n_dbc = 0
+    fxb_matrix_on_device = .false.     ! consumed: the next fstr_StiffMatrix on the device raises it again; any other hecmw_mat_ass_bc / hecmw_solve sees host arrays
   end function fxb_solve_device_matrix
 
   !> The device context of this rank, created on first use (device = local rank: fx_create(-1)).

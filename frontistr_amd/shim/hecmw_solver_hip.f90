@@ -35,6 +35,7 @@ contains
     integer(kind=kint) :: ierr, i, k, nhist, precond, iterlog, timelog, iterpremax
     integer(c_int32_t) :: natt, att_method(16), att_nhist(16)
     real(c_double) :: att_sigma(16)
+    integer(c_int64_t) :: fxstats(16)
     real(kind=kreal), allocatable, target :: hist_k(:)
     real(kind=kreal) :: SIGMA_DIAG
     character(len=8) :: env
@@ -57,12 +58,12 @@ contains
       call hecmw_solve_iterative(hecMESH, hecMAT)
       return
     endif
-    on_gpu = hecMAT%Iarray(99) == 1 .and. hecMESH%mpc%n_mpc == 0 .and. hecMAT%cmat%n_val == 0
-    if (hecMAT%NDOF == 3) then
-      on_gpu = on_gpu .and. (precond == 1 .or. precond == 2 .or. precond == 3 .or. precond == 10)
-    else   ! generic block sizes: METHOD 1-4 with SSOR / DIAG (include/fistr_hip.h)
-      on_gpu = on_gpu .and. hecMAT%NDOF >= 1 .and. hecMAT%NDOF <= 6 .and. (precond >= 1 .and. precond <= 3) .and. &
-               (hecMAT%Iarray(2) >= 1 .and. hecMAT%Iarray(2) <= 4)
+    on_gpu = fxb_on_gpu_path(hecMESH, hecMAT)     ! the same predicate the device-assembly binding consulted (fstr_device_hip.f90)
+    if (.not. on_gpu .and. fxb_matrix_on_device) then
+      ! cannot happen through fsd_eligible*, which ask the same predicate; a solver card changed between assembly and solve would get here
+      if (hecMESH%my_rank == 0) write(*,'(a,i0,a,i0,a)') '#### libfistr_hip-E: the matrix of this solve was assembled on the device, but the call (PRECOND=', &
+        precond, ', solver type=', hecMAT%Iarray(99), ') is not on the GPU path: the host matrix is empty. Set HECMW_GPU_ASSEMBLY=0 for this deck.'
+      call hecmw_abort(hecmw_comm_get_comm())
     endif
     if (.not. on_gpu) then
       call get_environment_variable('HECMW_GPU_UNSUPPORTED', envu, elen, estat)
@@ -162,6 +163,15 @@ contains
     if (hecMESH%my_rank == 0 .and. estat == 0 .and. elen > 0 .and. env(1:1) == '1') then
       write(*,'(a,i0,a,i0,a,i0,a,i0,a,f9.3,a)') '### libfistr_hip: solved on the device: NDOF=', hecMAT%NDOF, ' METHOD=', &
         hecmw_mat_get_method(hecMAT), ' PRECOND=', precond, ' ITER=', info%iterations, ' (whole call ', hecmw_Wtime() - t_call, ' s)'
+      ! which recurrence the CG loop ran in: Eisenstat's one-pass form (the default for CG + multicolour SSOR, FX_EISENSTAT=0 opts out) or hecmw_solve_CG's as written
+      if (hecMAT%NDOF == 3 .and. hecmw_mat_get_method(hecMAT) == 1 .and. (precond == 1 .or. precond == 2)) then
+        i = fx_get_stats(ctx, fxstats)
+        if (iand(fxstats(16), 1_c_int64_t) /= 0) then
+          write(*,'(a)') '### libfistr_hip: CG + SSOR recurrence: eisenstat'
+        else
+          write(*,'(a)') '### libfistr_hip: CG + SSOR recurrence: standard'
+        endif
+      endif
     endif
     if (hecMESH%my_rank == 0 .and. timelog >= 1) then
       TR = (info%time_sol - info%time_comm) / (info%time_sol + 1.d-24) * 100.d0

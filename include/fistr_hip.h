@@ -126,6 +126,9 @@ int fx_solve_resident(fx_context *ctx, int32_t *Iarray, double *Rarray, fx_solve
  * (iter = Fortran ITER, status 0 = still running, 1 = converged, else an fx_status). */
 int fx_krylov_begin(fx_context *ctx, const int32_t *Iarray, const double *Rarray);
 int fx_krylov_steps(fx_context *ctx, int32_t nsteps, int32_t *iter, int32_t *status, double *resid);
+/* The ITERLOG lines of the staged loop (hecmw_solver_CG.f90:245: RESID per iteration, line i = iteration i) executed since
+ * fx_krylov_begin: *n_lines = lines written so far, at most cap of them copied to hist. */
+int fx_krylov_history(fx_context *ctx, double *hist, int32_t cap, int32_t *n_lines);
 int fx_download_x(fx_context *ctx, double *X, int32_t n);          /* 3*NP doubles */
 int fx_download_matrix(fx_context *ctx, double *D, double *AL, double *AU, double *B);
 /* Resident single operations (tests, roofline timing). */
@@ -143,7 +146,7 @@ int fx_precond_apply_resident(fx_context *ctx, int nrepeat, float *ms_per_call);
 int fx_precond_apply_host(fx_context *ctx, const double *r, double *z);   /* z = M^-1 r, 3*NP doubles */
 /* out[0..14]: N NP NPL NPU | M pairs, blocks, slices | ncolor | L pairs, blocks | U pairs, blocks | slices |
  * SpMV workgroups overlapped with the halo exchange (interior), ordered after it (boundary) | [15] bit 0: the last Krylov
- * loop ran in Eisenstat's form (FX_EISENSTAT=1); bit 1: the ILU(0) sweeps are chain sweeps (FX_DATAFLOW=3) */
+ * loop ran in Eisenstat's form (the default for CG + multicolour SSOR, FX_EISENSTAT=0 opts out); bit 1: the ILU(0) sweeps are chain sweeps (FX_DATAFLOW=3) */
 int fx_get_stats(fx_context *ctx, int64_t out[16]);
 /* wall time (s) this context's set-ups have spent on measured tuning so far -- the placement searches of the value arrays
  * (candidate allocations: 10 ms each from recycled memory, ~200 ms each when the driver has to clear fresh VRAM) and the role

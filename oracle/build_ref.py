@@ -324,8 +324,11 @@ def fistr1_overrides(shimdir, gen):
                                          ("end module m_fstr_Update", "end module m_fstr_Update_ref")], "fstr_Update_ref.f90")
     over["hecmw_matrix_ass"] = patched("hecmw1/src/solver/matrix/hecmw_mat_ass.f90",
                                        [("\nmodule hecmw_matrix_ass\n  use hecmw_util\n", "\nmodule hecmw_matrix_ass\n  use hecmw_util\n  use hecmw_hip_binding, only: fxb_defer_bc\n"),
+                                        # the hook sits AFTER `hecMAT%B(row) = RHS`: fstr_AddBC (fstr_AddBC.f90:124) reads hecMAT%B at the rotation-centre
+                                        # nodes of a ROT_CENTER boundary, so the host B must record the prescribed value on the device path too
+                                        # (the device overwrites B(row) with the same value when it eliminates the dof)
                                         ("    NDOF = hecMAT%NDOF\n    if( NDOF < idof ) return\n\n    !C-- DIAGONAL block\n\n    hecMAT%B(NDOF*inode-(NDOF-idof)) = RHS\n",
-                                         "    NDOF = hecMAT%NDOF\n    if( NDOF < idof ) return\n    if (.not. present(conMAT)) then\n      if (fxb_defer_bc(inode, idof, RHS)) return\n    endif\n\n    !C-- DIAGONAL block\n\n    hecMAT%B(NDOF*inode-(NDOF-idof)) = RHS\n")],
+                                         "    NDOF = hecMAT%NDOF\n    if( NDOF < idof ) return\n\n    !C-- DIAGONAL block\n\n    hecMAT%B(NDOF*inode-(NDOF-idof)) = RHS\n    if (.not. present(conMAT)) then\n      if (fxb_defer_bc(inode, idof, RHS)) return\n    endif\n")],
                                        "hecmw_mat_ass.f90")
     over["m_fstr_stiffmatrix"] = os.path.join(shimdir, "fstr_StiffMatrix_hip.f90")
     over["m_fstr_update"] = os.path.join(shimdir, "fstr_Update_hip.f90")

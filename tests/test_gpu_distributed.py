@@ -322,7 +322,10 @@ def test_bench_self_launch(ngpu):
     assert len(lines) == 1, p.stdout
     out = json.loads(lines[0])
     assert out["ranks"] == ngpu and out["n_gpus"] == 1 and out["config"]["rehearsal_ranks"] == ngpu
-    assert out["steps"] == 6 and out["scaling"] == "weak" and "eisenstat" in out["variants"]
+    assert out["steps"] == 6 and out["scaling"] == "weak"
+    # the headline is the library's default path -- Eisenstat's form, on subdomains with the halo term -- and says so; hecmw_solve_CG's loop beside it
+    assert out["config"]["recurrence"].startswith("eisenstat") and "standard" in out["variants"], (out["config"], out["variants"])
+    assert out["variants"]["standard"]["it_per_s"] > 0
     assert out["config"]["decomposition"] == {2: "2x1x1", 4: "2x2x1"}[ngpu]
     assert out["value"] > 0 and np.isfinite(out["resid_after_steps"])
     assert "cpu_baseline" not in out          # rank 0 at N = 1 only
@@ -432,8 +435,8 @@ def test_eisenstat_form_on_subdomains(tmp_path, monkeypatch, world, m):
         assert np.abs(a["X"] - b["X"]).max() < 1e-8 * np.abs(a["X"]).max()
 
 
-@pytest.mark.parametrize("meth,pc", [(1, 1), (2, 10), (1, 3)])
-def test_bench_decomposition_2x2x2_eight_contexts(oracle, meth, pc):
+@pytest.mark.parametrize("meth,pc,form", [(1, 1, "eisenstat"), (1, 1, "standard"), (2, 10, None), (1, 3, None)])
+def test_bench_decomposition_2x2x2_eight_contexts(oracle, meth, pc, form):
     """bench.py's own 8-rank decomposition (bench.py:decomposition -> cube_subdomain(m, (2, 2, 2), r): 7 neighbours per rank,
     face / edge / corner messages; hecmw_solver_SR_33.F90:42-124) on the one GPU of the test box: 8 contexts + 8
     threads, CG + SSOR and BiCGSTAB + ILU(0) (and CG + block-Jacobi, which must equal the serial solve).  The interior / boundary
@@ -453,6 +456,8 @@ def test_bench_decomposition_2x2x2_eight_contexts(oracle, meth, pc):
             mat = hip.hecmw_mat_con(hm, hip.hecmwST_matrix())
             ctx = hip.SolverContext(device=0)
             ctx.set_option("FX_OVERLAP", overlap)
+            if form is not None:     # CG + SSOR in both recurrences: Eisenstat's form with the halo term H p (the default) and hecmw_solve_CG's loop
+                ctx.set_option("FX_EISENSTAT", 1 if form == "eisenstat" else 0)
             cbs = world.callbacks(r, sub)
             assert hip.lib().fx_comm_set_host_callbacks(ctx.h, r, 8, cbs[0], cbs[1], None) == 0
             ctx.upload(mat, hm, what=hip.FX_UP_PROFILE)
@@ -461,6 +466,8 @@ def test_bench_decomposition_2x2x2_eight_contexts(oracle, meth, pc):
             code = ctx.solve_resident(mat)
             ctx.download_x(mat)
             st = ctx.stats()
+            if form is not None:
+                assert st["eisenstat"] == (1 if form == "eisenstat" else 0)
             res = dict(X=mat.X.copy(), it=ctx.info.iterations, hist=ctx.history.copy(), code=code, gid=sub.global_id,
                        conv=int(mat.Iarray[80]), wg=(st["wg_interior"], st["wg_boundary"]), nnb=len(sub.neighbor_pe))
             ctx.close()

@@ -36,17 +36,41 @@ def _iterlog(stdout):
     return solves
 
 
-@pytest.mark.parametrize("method,precond,banner,iters", [
-    (None, None, "### 3x3 BLOCK CG, DIAG, 1", 70),            # the deck as shipped (A300.cnt: CG, PRECOND=3)
-    ("CG", 1, "### 3x3 BLOCK CG, SSOR, 1", None),
-    ("CG", 10, "### 3x3 BLOCK CG, ILU(0), 1", 75),
-    ("BiCGSTAB", 10, "### 3x3 BLOCK BiCGSTAB, ILU(0), 1", 93)])
-def test_fistr1_exA_A361_on_the_gpu(method, precond, banner, iters):
+CG_FORMS = ["eisenstat", "standard"]       # CG + multicolour SSOR: Eisenstat's one-pass form (the default) / hecmw_solve_CG as written (FX_EISENSTAT=0)
+
+
+def _form_env(form, **env):
+    env = dict(env, HECMW_GPU_REPORT="1")
+    if form is not None:
+        env["FX_EISENSTAT"] = "1" if form == "eisenstat" else "0"
+    return env
+
+
+def _assert_form(r, form, nsolves=None):
+    """every CG + SSOR solve of the run says which recurrence it ran in (HECMW_GPU_REPORT=1)"""
+    line = "### libfistr_hip: CG + SSOR recurrence: "
+    if form is None:
+        assert line not in r["stdout"]
+        return
+    other = "standard" if form == "eisenstat" else "eisenstat"
+    assert line + form in r["stdout"] and line + other not in r["stdout"], r["stdout"][-2000:]
+    if nsolves is not None:
+        assert r["stdout"].count(line + form) == nsolves
+
+
+@pytest.mark.parametrize("method,precond,banner,iters,form", [
+    (None, None, "### 3x3 BLOCK CG, DIAG, 1", 70, None),            # the deck as shipped (A300.cnt: CG, PRECOND=3)
+    ("CG", 1, "### 3x3 BLOCK CG, SSOR, 1", None, "eisenstat"),
+    ("CG", 1, "### 3x3 BLOCK CG, SSOR, 1", None, "standard"),
+    ("CG", 10, "### 3x3 BLOCK CG, ILU(0), 1", 75, None),
+    ("BiCGSTAB", 10, "### 3x3 BLOCK BiCGSTAB, ILU(0), 1", 93, None)])
+def test_fistr1_exA_A361_on_the_gpu(method, precond, banner, iters, form):
     """examples/static/exA: A361.msh + A300.cnt against A361_correct.log; iteration counts of the full fistr1 runs recorded in
     SURVEY section 0 (CG+DIAG 70, CG+ILU(0) 75, BiCGSTAB+ILU(0) 93; CG+SSOR's 85 is the 1-thread natural order)."""
     kw = {} if method is None else {"method": method, "precond": precond}
-    r = _run("exA", "A361.msh", "A300.cnt", **kw)
+    r = _run("exA", "A361.msh", "A300.cnt", env=_form_env(form), **kw)
     assert banner in r["stdout"], r["stdout"][:3000]
+    _assert_form(r, form, 1)
     assert DEVICE_ASSEMBLY not in r["stdout"] and LINEAR_DEVICE_ASSEMBLY in r["stdout"]   # linear STATIC, incompatible-mode element: the stiffness loop on the device, the stress update the reference's
     correct = f1.read_log(os.path.join(f1.DECKS, "exA", "A361_correct.log"))
     assert len(r["log"]) == 2 and f1.compare_step(r["log"][-1], correct[-1]) == []
@@ -68,7 +92,7 @@ def test_fistr1_exI_nlgeom_on_the_gpu(assembly):
     exI/A361_correct.log.  `device`: fstr_StiffMatrix / fstr_UpdateNewton / fstr_UpdateState run on the GPU too (the fistr1-side
     binding of INTEGRATION.md section 5: the matrix never crosses PCIe); `host` (HECMW_GPU_ASSEMBLY=0): the reference's element loops,
     only hecmw_solve on the GPU."""
-    r = _run("exI", "A361.msh", "I300.cnt", env={} if assembly == "device" else {"HECMW_GPU_ASSEMBLY": "0"})
+    r = _run("exI", "A361.msh", "I300.cnt", env={} if assembly == "device" else {"HECMW_GPU_ASSEMBLY": "0"})     # CG + DIAG (I300.cnt): one recurrence
     assert (DEVICE_ASSEMBLY in r["stdout"]) == (assembly == "device")
     correct = f1.read_log(os.path.join(f1.DECKS, "exI", "A361_correct.log"))
     got = r["log"][1:]
@@ -78,14 +102,21 @@ def test_fistr1_exI_nlgeom_on_the_gpu(assembly):
     assert [x[3] for x in r["sta"]] == [2] * 10
 
 
+@pytest.mark.parametrize("form", CG_FORMS)
 @pytest.mark.parametrize("assembly", ["device", "host"])
-def test_fistr1_plastic_cylinder_on_the_gpu(assembly):
+def test_fistr1_plastic_cylinder_on_the_gpu(assembly, form):
     """tutorial/05_plastic_cylinder (configs[4]'s deck; multilinear Mises, updated Lagrange, CG + SSOR 1e-8, CONVERG 1e-3):
     Newton counts 36, 5, 5, 5, 5, 5, 5, 5 and the stop at sub-step 9 exactly as the unmodified program (FSTR.sta), every
     step's displacement / strain / stress extrema against the unmodified program's 0.log (tests/golden/decks/t05/, generator
     make_fistr1_golden.py; the reference ships no correct-log for this deck).  121 linear solves through hecmw_solve."""
-    r = _run("t05", "necking.msh", "necking.cnt", env={} if assembly == "device" else {"HECMW_GPU_ASSEMBLY": "0"})
+    r = _run("t05", "necking.msh", "necking.cnt", env=_form_env(form) if assembly == "device" else _form_env(form, HECMW_GPU_ASSEMBLY="0"))
     assert (DEVICE_ASSEMBLY in r["stdout"]) == (assembly == "device")
+    # fstr_Newton raises Iarray(97) from its second iteration on and the reference recycles the preconditioner up to three times
+    # (hecmw_mat_recycle_precond_setting): those solves run the standard loop on their own (a recycled M is a different splitting),
+    # the others Eisenstat's form when it is on
+    line = "### libfistr_hip: CG + SSOR recurrence: "
+    assert r["stdout"].count(line + "eisenstat") + r["stdout"].count(line + "standard") == 121
+    assert (r["stdout"].count(line + "eisenstat") > 0) == (form == "eisenstat")
     assert [x[3] for x in r["sta"][:8]] == [36, 5, 5, 5, 5, 5, 5, 5], r["sta"]
     assert r["sta"][8][2] == "1F" and "MAXITER" in r["sta"][8][4]
     assert r["stdout"].count("### 3x3 BLOCK CG, SSOR, 1") == 121
@@ -93,6 +124,37 @@ def test_fistr1_plastic_cylinder_on_the_gpu(assembly):
     assert len(r["log"]) == len(want) == 9
     for a, c in zip(r["log"], want):
         assert f1.compare_step(a, c) == []
+
+
+def _compare_rel(actual, correct, rel=1e-4):
+    """every extremum within `rel` of the larger magnitude of its pair (decks whose values are far below the harness' 1e-4 absolute)"""
+    bad = []
+    for part in ("Node", "Element"):
+        for k, v in actual[part].items():
+            c = correct[part].get(k)
+            if c is None:
+                continue
+            scale = max(abs(c[0]), abs(c[1]), 1e-300)
+            for j in (0, 1):
+                if not abs(c[j] - v[j]) <= rel * scale:
+                    bad.append((part, k, j, v[j], c[j]))
+    return bad
+
+
+@pytest.mark.parametrize("assembly", ["device", "host"])
+@pytest.mark.parametrize("name,mesh,cnt", [("rot", "rot_disp.msh", "rot_disp.cnt"), ("torque", "torque_load.msh", "torque_load.cnt")])
+def test_fistr1_rotation_centre_decks_on_the_gpu(name, mesh, cnt, assembly):
+    """examples/static/torque_rot: `!BOUNDARY, ROT_CENTER=` (a rotation prescribed about a centre node: fstr_AddBC.f90:69-160 reads
+    hecMAT%B at the centre node and calls hecmw_mat_ass_bc for the torque group afterwards -- ADVICE r03: the hook of the device
+    path must leave `hecMAT%B(row) = RHS` in place) and `!CLOAD, ROT_CENTER=` (a torque), linear static TYPE=361, CG + SSOR.
+    Device assembly against HECMW_GPU_ASSEMBLY=0 and both against the unmodified program's 0.log (make_torque_rot_golden.py)."""
+    r = _run(os.path.join("torque_rot", name), mesh, cnt, env={"HECMW_GPU_REPORT": "1"} if assembly == "device" else {"HECMW_GPU_REPORT": "1", "HECMW_GPU_ASSEMBLY": "0"})
+    assert "FrontISTR Completed !!" in r["stdout"], r["stdout"][-2000:]
+    assert (LINEAR_DEVICE_ASSEMBLY in r["stdout"]) == (assembly == "device")
+    assert "### libfistr_hip: solved on the device: NDOF=3 METHOD=1 PRECOND=1" in r["stdout"]
+    want = f1.read_log(os.path.join(f1.DECKS, "torque_rot", name, cnt[:-4] + "_fistr1_ref_0.log"))
+    assert len(r["log"]) == len(want) == 2
+    assert _compare_rel(r["log"][-1], want[-1], rel=2e-4) == []      # solver tolerance 1e-6 (the deck's), 5 printed digits
 
 
 def _static_models():

@@ -34,6 +34,29 @@ def hip():
     return hecmw
 
 
+def with_cg_forms(configs):
+    """CG + multicolour SSOR has two recurrences on the GPU: Eisenstat's one-pass form (the default) and hecmw_solve_CG's loop as
+    written (FX_EISENSTAT=0).  Every (method, precond, ...) tuple with METHOD=1, PRECOND=1 is run in BOTH; the others once."""
+    out = []
+    for c in configs:
+        if c[0] == 1 and c[1] == 1:
+            out.append(pytest.param(*c, "eisenstat", id="-".join(map(str, c)) + "-eisenstat"))
+            out.append(pytest.param(*c, "standard", id="-".join(map(str, c)) + "-standard"))
+        else:
+            out.append(pytest.param(*c, None, id="-".join(map(str, c))))
+    return out
+
+
+def select_cg_form(monkeypatch, form):
+    if form is not None:
+        monkeypatch.setenv("FX_EISENSTAT", "1" if form == "eisenstat" else "0")     # read by fx_create
+
+
+def assert_cg_form(ctx, form):
+    if form is not None:
+        assert ctx.stats()["eisenstat"] == (1 if form == "eisenstat" else 0)        # the recurrence asked for is the one that ran
+
+
 def to_hecmat(hip, A):
     return hip.hecmwST_matrix.from_arrays(A.N, A.NP, A.indexL, A.itemL, A.indexU, A.itemU, A.D, A.AL, A.AU, A.B.copy())
 
@@ -127,14 +150,16 @@ def test_precond_apply(hip, oracle, deck, pc):
 
 
 @pytest.mark.parametrize("deck", DECKS)
-@pytest.mark.parametrize("meth,pc,thr", GPU_CONFIGS)
-def test_solve_matches_reference_golden(hip, deck, meth, pc, thr):
+@pytest.mark.parametrize("meth,pc,thr,form", with_cg_forms(GPU_CONFIGS))
+def test_solve_matches_reference_golden(hip, deck, meth, pc, thr, form, monkeypatch):
     g = load_golden(deck)
     A = golden_matrix(g)
     m = to_hecmat(hip, A)
     m.Iarray[0] = 10000; m.Iarray[1] = meth; m.Iarray[2] = pc
+    select_cg_form(monkeypatch, form)
     ctx = hip.SolverContext()
     code = hip.hecmw_solve(None, m, ctx=ctx)
+    assert_cg_form(ctx, form)
     tag = "sol_m%d_p%d_t%d_" % (meth, pc, thr)
     it_ref, h_ref, x_ref = int(g[tag + "iter"]), g[tag + "hist"], g[tag + "X"]
     if deck == "exA_A361" and meth == 2 and code == hip.HECMW_SOLVER_ERROR_NOCONV_MAXIT:
@@ -159,8 +184,8 @@ def test_solve_matches_reference_golden(hip, deck, meth, pc, thr):
     ctx.close()
 
 
-@pytest.mark.parametrize("meth,pc", [(1, 3), (1, 1), (2, 3), (2, 1), (1, 10), (2, 10)])
-def test_solve_larger_cube_vs_oracle(hip, oracle, meth, pc):
+@pytest.mark.parametrize("meth,pc,form", with_cg_forms([(1, 3), (1, 1), (2, 3), (2, 1), (1, 10), (2, 10)]))
+def test_solve_larger_cube_vs_oracle(hip, oracle, meth, pc, form, monkeypatch):
     """20^3-element cube (27.8k DOF): iteration-for-iteration against the oracle with the
     reference's multicolour ordering."""
     from frontistr_amd.mesh import CubeMesh
@@ -171,8 +196,10 @@ def test_solve_larger_cube_vs_oracle(hip, oracle, meth, pc):
     o = oracle.solve_iterative(A, I, R, nthreads=4)
     m = to_hecmat(hip, A)
     m.Iarray[0] = 10000; m.Iarray[1] = meth; m.Iarray[2] = pc
+    select_cg_form(monkeypatch, form)
     ctx = hip.SolverContext()
     assert hip.hecmw_solve(None, m, ctx=ctx) == 0
+    assert_cg_form(ctx, form)
     check_solve(ctx.info, ctx.history, m.X, o["iter"], o["history"], o["X"], meth, printed=False)
     ctx.close()
 
@@ -493,11 +520,12 @@ def test_one_context_many_configurations(hip):
     ctx.close()
 
 
-@pytest.mark.parametrize("meth,pc", [(1, 1), (2, 10), (1, 3)])
-def test_graph_replay_is_bit_identical(meth, pc, tmp_path):
+@pytest.mark.parametrize("meth,pc,eis", [(1, 1, "1"), (1, 1, "0"), (2, 10, "1"), (1, 3, "1")])
+def test_graph_replay_is_bit_identical(meth, pc, eis, tmp_path):
     """The hipGraph replay of the Krylov iteration (auto for small SSOR / ILU systems) enqueues the same kernels in the
     same order as the plain launches: iteration count, history and solution must be bit-identical (FX_GRAPH=0 vs 2,
-    fresh processes because the switch is read when the context is created)."""
+    fresh processes because the switch is read when the context is created).  CG + SSOR in both recurrences (Eisenstat's
+    form, the default, and FX_EISENSTAT=0)."""
     import os
     import subprocess
     import sys
@@ -518,7 +546,7 @@ np.savez(sys.argv[1], X=m.X, hist=ctx.history, it=ctx.info.iterations)
     outs = []
     for g in ("0", "2"):
         out = str(tmp_path / ("g%s.npz" % g))
-        p = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, FX_GRAPH=g), stdout=subprocess.PIPE,
+        p = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, FX_GRAPH=g, FX_EISENSTAT=eis), stdout=subprocess.PIPE,
                            stderr=subprocess.STDOUT, text=True, timeout=600)
         assert p.returncode == 0, p.stdout[-2000:]
         outs.append(np.load(out))
