@@ -129,6 +129,29 @@ def launch_ranks(a):
     return 0
 
 
+def check_ledgers(leds):
+    """Cross-rank consistency of the communication ledgers (SolverContext.comm_ledger of every rank, rank order)."""
+    errors = []
+    ref = leds[0]
+    for r, g in enumerate(leds):
+        for k in ("ops", "seq_hash", "allreduces", "allreduce_bytes", "halos"):
+            if g[k] != ref[k]:
+                errors.append("rank %d %s = %r, rank 0 has %r" % (r, k, g[k], ref[k]))
+        for p, (ns, bs, nr, br) in g["peers"].items():
+            if not 0 <= p < len(leds):
+                errors.append("rank %d lists neighbour %d outside the world" % (r, p))
+                continue
+            back = leds[p]["peers"].get(r)
+            if back is None:
+                errors.append("rank %d exchanges with %d, which does not list it" % (r, p))
+            elif (ns, bs) != (back[2], back[3]) or (nr, br) != (back[0], back[1]):
+                errors.append("rank %d -> %d: %d messages / %d bytes sent, %d / %d received there; %d <- %d: %d / %d received, %d / %d sent there"
+                              % (r, p, ns, bs, back[2], back[3], r, p, nr, br, back[0], back[1]))
+    return {"errors": errors, "ops_per_rank": ref["ops"], "allreduces": ref["allreduces"], "halo_exchanges": ref["halos"],
+            "allreduce_bytes": ref["allreduce_bytes"], "own_halo_comm": ref["own_halo_comm"],
+            "halo_bytes_sent_per_rank": [sum(v[1] for v in g["peers"].values()) for g in leds]}
+
+
 def host_cores():
     """Cores this process may actually use: the affinity mask capped by the cgroup CPU quota (on the GPU boxes of this
     pool: 256 cores in the mask, cpu.max = 16 CPUs; 256 OpenMP threads on a 16-CPU quota ran the reference 12x slower)."""
@@ -259,29 +282,67 @@ def main():
     if two_forms and a.standard:
         ctx.set_option("FX_EISENSTAT", 0)   # --standard: the headline loop is the reference's recurrence as written
     t_pre = time.time() - t0
-    t_tune = ctx.tune_seconds()     # of which: placement checks + role timing of the work vectors
-    placement = ctx.placement_report()
+    placement = ctx.placement_report()   # the value arena: nothing is timed or searched at set-up since round 4
     st = ctx.stats()
     N, nb = st["N"], st["M_blocks"]
 
+    # A step that does not come back (ranks that disagree on the sequence of RCCL operations wait for each other for ever) must end
+    # as a message, not as a silent hang: the watchdog prints this rank's communication ledger -- how many operations it has issued,
+    # the hash of their sequence, messages per neighbour -- and ends the process.  FX_BENCH_WATCHDOG seconds per phase (0 = off).
+    import threading
+    wd_s = float(os.environ.get("FX_BENCH_WATCHDOG", "600"))
+    wd_phase = {"name": None, "t0": 0.0}
+
+    def _watch():
+        while True:
+            time.sleep(1.0)
+            nm = wd_phase["name"]
+            if nm and wd_s > 0 and time.time() - wd_phase["t0"] > wd_s:
+                try:
+                    led = ctx.comm_ledger()
+                except Exception as e:
+                    led = repr(e)
+                sys.stderr.write("bench.py: rank %d: phase '%s' did not finish within %.0f s -- communication ledger of this rank: %r\n"
+                                 "bench.py: compare `ops` / `seq_hash` across ranks: the first rank that differs issued a different sequence of "
+                                 "all-reduces / halo exchanges (DESIGN.md section 6)\n" % (rank, nm, wd_s, led))
+                sys.stderr.flush()
+                os._exit(3)
+
+    threading.Thread(target=_watch, daemon=True).start()
+
+    def phase(name):
+        wd_phase["t0"] = time.time()
+        wd_phase["name"] = name
+
+    phase("krylov_begin + warm-up")
     ctx.krylov_begin(m)
     it, status, resid = ctx.krylov_steps(a.warmup)
     barrier()
+    phase("timed iterations")
     t0 = time.perf_counter()
     it, status, resid = ctx.krylov_steps(a.steps)
     barrier()
     dt = time.perf_counter() - t0
+    phase(None)
     assert status == 0 and it == a.warmup + a.steps + 1, (status, it)
     assert np.isfinite(resid)
     headline_eis = bool(ctx.stats()["eisenstat"])       # the recurrence the timed loop really ran in (read before anything else touches the context)
     hist_gpu = ctx.krylov_history()                     # its ITERLOG lines 1 .. warmup + steps (outside the timed region)
     devices_used = 1
+    ledger_check = None
     if world > 1:
         t = torch.tensor([dt, float(dev)], dtype=torch.float64)
         g = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
         dist.all_gather(g, t)
         dt = max(float(x[0]) for x in g)
         devices_used = len(set(int(x[1]) for x in g))
+        # every rank's communication ledger over the control plane: same operation count and sequence hash everywhere, and what r
+        # sent to p is what p received from r (messages and bytes) -- checked on every rank, so that every rank fails together
+        leds = [None] * world
+        dist.all_gather_object(leds, ctx.comm_ledger())
+        ledger_check = check_ledgers(leds)
+        if ledger_check["errors"]:
+            raise SystemExit("bench.py: the ranks disagree on their communication: " + "; ".join(ledger_check["errors"][:8]))
 
     # The OTHER recurrence of CG + SSOR in the same line: same context, data and placement, timed exactly like the headline
     # (W untimed + K timed iterations between barriers, max over ranks).  Bytes of one iteration:
@@ -412,18 +473,21 @@ def main():
                          "ms": ms_asm, "ms_first_call": ms_asm_first, "algorithmic_bytes": asm_bytes,
                          "achieved_GBs": asm_bytes / (ms_asm * 1e-3) / 1e9, "frac": asm_bytes / (ms_asm * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "traffic": asm_traffic, "traffic_source": asm_traffic_src},
-            # which speed class of the value array's placement this process got: ms of the first allocation
-            # and of the one kept, candidates timed (1 = the first power-of-two request was in the fast class)
-            "placement": placement["spmv"],
+            # where the value arrays live: ONE arena taken before anything else of the system, every array at a fixed offset in it
+            # (what makes the speed class of this kernel the same in every process)
+            "placement": placement,
         },
-        "setup_s": {"mat_con": t_con, "assemble_ms": ms_asm, "precond_setup": t_pre - t_tune, "placement_tuning": t_tune,
-                    "placement": placement,
-                    "note": "precond_setup = ordering + colouring + layouts + factors; placement_tuning = timing the first allocation of each "
-                            "value array and, only if it streams below its class, ONE second candidate (released at the end of the set-up: "
-                            "held_bytes = 0); placement.spmv.candidates = 1 means the first power-of-two request landed in the fast class"},
+        "setup_s": {"mat_con": t_con, "assemble_ms": ms_asm, "precond_setup": t_pre,
+                    "note": "precond_setup = ordering + colouring + layouts + factors (no placement search, no timing of candidates: the value arena "
+                            "is taken at fx_upload, before the CSR arrays)"},
         "resid_after_steps": resid,
         "variants": variants,
     }
+    if ledger_check is not None:
+        # what the ranks exchanged up to the end of the timed iterations (set-up + warm-up + K iterations), cross-checked rank against rank
+        out["comm_ledger"] = {k: v for k, v in ledger_check.items() if k != "errors"}
+        out["comm_ledger"]["consistent"] = True
+
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cores = host_cores()     # every core this process may run on (affinity mask capped by the cgroup quota)
         n_cpu = a.n if (a.cpu_full or a.cpu_sample_n <= 0 or a.cpu_sample_n >= a.n) else a.cpu_sample_n

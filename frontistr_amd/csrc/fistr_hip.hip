@@ -60,6 +60,7 @@ struct RcclApi {
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
   ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
   ncclResult_t (*CommCuDevice)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t *, void *) = nullptr;  // optional (RCCL >= 2.18)
 };
 static RcclApi g_rccl;
 
@@ -86,6 +87,7 @@ static int rccl_load() {
   RCCL_SYM(CommCount, "ncclCommCount")
   RCCL_SYM(CommCuDevice, "ncclCommCuDevice")
 #undef RCCL_SYM
+  g_rccl.CommSplit = (decltype(g_rccl.CommSplit))dlsym(g_rccl.h, "ncclCommSplit");
   return 0;
 }
 
@@ -136,22 +138,11 @@ static void parallel_for(int64_t n, F f) {
   for (auto &t : th) t.join();
 }
 
-// Losing candidates of a placement search stay allocated until the set-up that made them ends (tune_placement).  If anything
-// in this process runs out of device memory meanwhile, they go first: every context that holds some is known here.
-static std::mutex g_held_mu;
-static std::vector<fx_context *> g_held_ctx;
-static bool relieve_oom();
-
 template <class T>
 static int dev_alloc(T **p, size_t count) {
   *p = nullptr;
   if (count == 0) count = 1;
-  hipError_t e = hipMalloc((void **)p, count * sizeof(T));
-  if (e == hipErrorOutOfMemory && relieve_oom()) {  // held candidates of a placement search released: once more
-    (void)hipGetLastError();
-    e = hipMalloc((void **)p, count * sizeof(T));
-  }
-  HIP_TRY(e);
+  HIP_TRY(hipMalloc((void **)p, count * sizeof(T)));
   return 0;
 }
 template <class T>
@@ -249,7 +240,7 @@ static int context_init(fx_context *c) {
 // ---------------------------------------------------------------------------
 struct FxOption { const char *name; void (*set)(fx_context *, double); };
 static const FxOption g_fx_options[] = {
-    {"FX_TUNE_PLACEMENT", [](fx_context *c, double v) { c->tune_tries = std::max(0, (int)v); }},
+    {"FX_ARENA_GB", [](fx_context *c, double v) { c->arena_min_gb = std::max(0, (int)v); }},
     {"FX_BFS_DEVICE_MIN", [](fx_context *c, double v) { c->bfs_device_min = (int)v; }},
     {"FX_MC_DEVICE_MIN", [](fx_context *c, double v) { c->mc_device_min = (int)v; }},
     {"FX_BFS_BATCH", [](fx_context *c, double v) { c->bfs_batch = std::max(1, (int)v); }},
@@ -268,6 +259,7 @@ static const FxOption g_fx_options[] = {
     {"FX_OVERLAP", [](fx_context *c, double v) { c->overlap = (int)v != 0; }},
     {"FX_EISENSTAT", [](fx_context *c, double v) { c->eisenstat = (int)v != 0; }},
     {"FX_EIS_FUSE", [](fx_context *c, double v) { c->eis_fuse = (int)v != 0; }},
+    {"FX_EIS_MERGE", [](fx_context *c, double v) { c->eis_merge = (int)v != 0; }},
     {"FX_SPLIT_MAX_SLICES", [](fx_context *c, double v) { c->split_max_slices = (int)v; }},
     {"FX_DATAFLOW", [](fx_context *c, double v) {
        c->df_mode = (int)v;
@@ -328,7 +320,51 @@ extern "C" int fx_create(int device, fx_context **out) {
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// The value arena (DevArena, fx_internal.h): one large allocation taken before anything else of a large system, the BELL value
+// arrays placed in it by a bump pointer at 2 MiB-aligned offsets.
+// ---------------------------------------------------------------------------
+static void arena_destroy(fx_context *c) {
+  if (c->arena.base) (void)hipFree(c->arena.base);
+  c->arena = DevArena();
+}
+// Called when the size of a system becomes known (fx_upload of a profile, before the CSR arrays are allocated): `need` = estimated
+// bytes of the value arrays of M, L and U.  Keeps a large enough arena, replaces an empty smaller one, does nothing for small
+// systems, with FX_ARENA_GB=0 or when the device cannot spare the memory (the arrays then get their own allocations as before).
+static void arena_reserve(fx_context *c, size_t need) {
+  DevArena &a = c->arena;
+  if (c->arena_min_gb <= 0 || need < c->arena_threshold) return;
+  need += (size_t)8 << 21;  // alignment slack of a few arrays
+  if (a.base && a.bytes >= need) return;
+  if (a.base && a.live > 0) return;  // in use and too small: the new arrays fall back to their own allocations
+  arena_destroy(c);
+  size_t want = (size_t)1 << 30;
+  while (want < need || want < ((size_t)c->arena_min_gb << 30)) want <<= 1;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
+  // what else this system will allocate is about 2.5x the value arrays (CSR arrays, column ids, source maps, vectors): leave it room
+  while (want > need && want + 3 * need > free_b) want >>= 1;
+  if (want < need || want + 2 * need > free_b) return;
+  char *p = nullptr;
+  if (hipMalloc((void **)&p, want) != hipSuccess) { (void)hipGetLastError(); return; }
+  a.base = p; a.bytes = want; a.used = 0; a.live = 0;
+}
+static char *arena_alloc(fx_context *c, size_t bytes) {
+  DevArena &a = c->arena;
+  if (!a.base) return nullptr;
+  const size_t off = (a.used + (((size_t)2 << 20) - 1)) & ~(((size_t)2 << 20) - 1);
+  if (off + bytes > a.bytes) return nullptr;
+  a.used = off + bytes;
+  a.live++;
+  return a.base + off;
+}
+static void arena_release(fx_context *c) {
+  DevArena &a = c->arena;
+  if (a.live > 0 && --a.live == 0) a.used = 0;
+}
+
 static void bell_free(Bell &b) {
+  if (b.arena_owner) { arena_release(b.arena_owner); b.val2_base = nullptr; }
   dev_free(b.pair_ptr); dev_free(b.val2_base); dev_free(b.col2); dev_free(b.slot_row); dev_free(b.src2); dev_free(b.slice_order);
   dev_free(b.wg_interior); dev_free(b.wg_boundary);
   b.val2 = nullptr;
@@ -357,25 +393,6 @@ static void free_matrix(fx_context *c) {
   c->asm_colors = ElemColors();
 }
 
-static void release_held(fx_context *c) {
-  std::lock_guard<std::mutex> lk(g_held_mu);
-  for (void *q : c->held) (void)hipFree(q);
-  c->held.clear();
-  c->held_bytes = 0;
-  g_held_ctx.erase(std::remove(g_held_ctx.begin(), g_held_ctx.end(), c), g_held_ctx.end());
-}
-static bool relieve_oom() {
-  std::lock_guard<std::mutex> lk(g_held_mu);
-  bool any = false;
-  for (fx_context *h : g_held_ctx) {
-    for (void *q : h->held) { (void)hipFree(q); any = true; }
-    h->held.clear();
-    h->held_bytes = 0;
-  }
-  g_held_ctx.clear();
-  return any;
-}
-
 static void free_precond(fx_context *c) {
   dev_free(c->diag.alu);
   bell_free(c->ssor.L); bell_free(c->ssor.U); bell_free(c->ssor.H);
@@ -398,13 +415,14 @@ extern "C" void fx_destroy(fx_context *c) {
   c->asm_colors = ElemColors();
   free_precond(c);
   free_matrix(c);
-  release_held(c);
+  arena_destroy(c);
   dev_free(c->halo.export_item); dev_free(c->halo.import_item);
   dev_free(c->halo.sendbuf); dev_free(c->halo.recvbuf);
   dev_free(c->st); dev_free(c->red_out); dev_free(c->hist); dev_free(c->extra); dev_free(c->df_err);
   if (c->st_host) (void)hipHostFree(c->st_host);
   if (c->h_send) (void)hipHostFree(c->h_send);
   if (c->h_recv) (void)hipHostFree(c->h_recv);
+  if (c->nccl_halo && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)c->nccl_halo);
   if (c->nccl && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)c->nccl);
   for (hipEvent_t e : c->clock.ev) (void)hipEventDestroy(e);
   if (c->comm_stream) { (void)hipStreamSynchronize(c->comm_stream); (void)hipStreamDestroy(c->comm_stream); }
@@ -427,30 +445,31 @@ extern "C" int fx_device_synchronize(fx_context *c) {
 // ---------------------------------------------------------------------------
 struct BellEntry { int32_t src, col; };
 
-// Bytes to ask hipMalloc for when a BELL value array needs `bytes`.  A multi-gigabyte request is served from several
-// power-of-two blocks of the driver's VRAM allocator (6.5 GB = 4 + 2 + 0.5), and where those blocks lie decides the speed class
-// of the SpMV (fx_context::tune_tries).  Measured inside one 15 GB allocation: the array runs at 1.04 ms while it lies in the
-// leading 8 GB block and slows to 1.18 ms as it moves out of it.  Rounding the request up to a power of two asks for ONE block.
-static size_t val2_alloc_bytes(const fx_context *c, size_t bytes) {
-  if (!c->val2_pow2 || bytes < ((size_t)1 << 30)) return bytes;
-  size_t p = (size_t)1 << 30;
-  while (p < bytes) p <<= 1;
-  return p;
-}
-static int val2_alloc(const fx_context *c, char **base, size_t bytes, size_t *got = nullptr) {  // the rounded request first, the exact one when memory does not allow it
-  *base = nullptr;
-  const size_t want = val2_alloc_bytes(c, bytes);
-  if (got) *got = bytes;
-  if (want > bytes) {
+// Memory of a BELL value array: its place in the context's arena when there is one with room; otherwise an allocation of its own --
+// for arrays of a gigabyte or more the next power of two (ONE block of the driver's VRAM allocator instead of 4 + 2 + 0.5 GB pieces:
+// more often the fast class than the exact request, scripts/r4/placement_probe.py), the exact size when memory does not allow it.
+static int val2_alloc(fx_context *c, Bell &b, size_t bytes) {
+  b.val2_base = nullptr; b.val2 = nullptr; b.arena_owner = nullptr; b.val2_bytes = bytes;
+  if (char *p = arena_alloc(c, bytes)) {
+    b.val2_base = p; b.val2 = (double *)p; b.arena_owner = c;
+    return 0;
+  }
+  char *base = nullptr;
+  if (c->val2_pow2 && bytes >= ((size_t)1 << 30)) {
+    size_t want = (size_t)1 << 30;
+    while (want < bytes) want <<= 1;
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > want + ((size_t)8 << 30) && hipMalloc((void **)base, want) == hipSuccess) {
-      if (got) *got = want;
+    if (want > bytes && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > want + ((size_t)8 << 30) &&
+        hipMalloc((void **)&base, want) == hipSuccess) {
+      b.val2_base = base; b.val2 = (double *)base; b.val2_bytes = want;
       return 0;
     }
     (void)hipGetLastError();
-    *base = nullptr;
+    base = nullptr;
   }
-  return dev_alloc(base, bytes);
+  if (dev_alloc(&base, bytes)) return FX_ERROR_RUNTIME;
+  b.val2_base = base; b.val2 = (double *)base;
+  return 0;
 }
 
 template <class CountFn, class FillFn>
@@ -509,13 +528,7 @@ static int bell_build2(fx_context *c, Bell &b, int32_t nslots, const std::vector
   if (dev_alloc(&b.pair_ptr, (size_t)b.nslices + 1)) return FX_ERROR_RUNTIME;
   if (dev_alloc(&b.col2, (size_t)tot * 64)) return FX_ERROR_RUNTIME;
   if (dev_alloc(&b.src2, (size_t)tot * 64)) return FX_ERROR_RUNTIME;
-  {
-    size_t pad = 0;
-    char *base = nullptr;
-    if (val2_alloc(c, &base, (size_t)tot * 576 * 8 + pad, &b.val2_bytes)) return FX_ERROR_RUNTIME;
-    b.val2_base = base;
-    b.val2 = (double *)(base + pad);
-  }
+  if (val2_alloc(c, b, (size_t)tot * 576 * 8)) return FX_ERROR_RUNTIME;
   HIP_TRY(hipMemcpyAsync(b.pair_ptr, pair_ptr.data(), pair_ptr.size() * 4, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(b.col2, col2.data(), col2.size() * 4, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(b.src2, src2.data(), src2.size() * 4, hipMemcpyHostToDevice, c->stream));
@@ -561,13 +574,7 @@ static int bell_build_device(fx_context *c, Bell &b, int variant, int32_t nslots
   b.npairs = (int64_t)h_tot[1];
   const size_t tot = (size_t)b.npairs;
   if (dev_alloc(&b.col2, tot * 64) || dev_alloc(&b.src2, tot * 64)) return FX_ERROR_RUNTIME;
-  {
-    size_t pad = 0;
-    char *base = nullptr;
-    if (val2_alloc(c, &base, tot * 576 * 8 + pad, &b.val2_bytes)) return FX_ERROR_RUNTIME;
-    b.val2_base = base;
-    b.val2 = (double *)(base + pad);
-  }
+  if (val2_alloc(c, b, tot * 576 * 8)) return FX_ERROR_RUNTIME;
   BELL_VAR(k_bell_map, dim3(b.nslices), dim3(64), 0, c->stream, nslots, b.nslices, d_slot_row, A.N, A.indexL, A.itemL, A.indexU,
            A.itemU, d_slot_of, d_newpos, b.pair_ptr, b.col2, b.src2)
 #undef BELL_VAR
@@ -697,86 +704,6 @@ static int build_full_bell(fx_context *c) {
 
 static int ensure_work(fx_context *c);
 
-static int spmv_launch(fx_context *c, int mode, int dot, double *x, const double *b, double *y, const int32_t *gate,
-                       int32_t gate_val, const int32_t *wg_list, int nwg);
-static inline int spmv_nparts(fx_context *c);
-
-struct TuneClock {  // wall time of the tuning steps of the set-up (fx_tune_seconds)
-  fx_context *c;
-  double t0;
-  explicit TuneClock(fx_context *cc) : c(cc), t0(now_s()) {}
-  ~TuneClock() { c->tune_spent_s += now_s() - t0; }
-};
-// Placement check of a BELL value array (fx_context::tune_tries).  Round 2 searched up to 20 candidate allocations and kept the
-// losers for the life of the context; since large value arrays are requested as ONE power-of-two block of the driver's allocator
-// (val2_alloc) the first allocation lands in the fast class four times in five, so the search is now a safety net: the first
-// allocation is timed, and only if it streams below `good_gbs` ONE more candidate is allocated, filled and timed; the faster of
-// the two is kept.  The loser stays allocated until the END of the set-up (fx_precond_setup releases it: freeing it at once would
-// hand the same physical block to the next hipMalloc of this set-up) -- nothing is held afterwards.  What happened is kept for
-// fx_placement_report.
-template <class Fill, class Time>
-static int tune_placement(fx_context *c, Bell &B, const char *what, double stream_bytes, double good_gbs, Fill fill, Time time_ms,
-                          PlacementReport *rep) {
-  B.placed = true;
-  if (c->tune_tries <= 1 || B.nslices < c->tune_min_slices) return 0;
-  TuneClock tclock(c);
-  const size_t bytes = (size_t)B.npairs * 576 * 8;
-  float t0 = 0.f, t1 = 1e30f;
-  if (time_ms(&t0)) return FX_ERROR_RUNTIME;
-  if (rep) { rep->first_ms = rep->kept_ms = t0; rep->candidates = 1; rep->gbs = stream_bytes / (1e-3 * t0) / 1e9; }
-  if (stream_bytes / (1e-3 * t0) / 1e9 >= good_gbs) return 0;
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + (bytes >> 1) + ((size_t)4 << 30)) return 0;  // keep headroom
-  char *base = nullptr;
-  size_t got = 0;
-  void *first_base = B.val2_base;
-  const size_t first_bytes = B.val2_bytes;
-  const double w0 = now_s();
-  if (val2_alloc(c, &base, bytes, &got)) { (void)hipGetLastError(); g_fx_error.clear(); return 0; }
-  B.val2_base = base; B.val2 = (double *)base; B.val2_bytes = got;
-  int err = fill();
-  if (!err) err = time_ms(&t1);
-  c->tune_cand_s += now_s() - w0;
-  void *loser = nullptr;
-  size_t loser_bytes = 0;
-  if (err || t1 >= t0) {  // the first allocation stays (it is filled)
-    loser = base; loser_bytes = got;
-    B.val2_base = first_base; B.val2 = (double *)first_base; B.val2_bytes = first_bytes;
-  } else {
-    loser = first_base; loser_bytes = first_bytes;
-  }
-  {
-    std::lock_guard<std::mutex> lk(g_held_mu);
-    c->held.push_back(loser);
-    c->held_bytes += loser_bytes;
-    if (std::find(g_held_ctx.begin(), g_held_ctx.end(), c) == g_held_ctx.end()) g_held_ctx.push_back(c);
-  }
-  if (rep) { rep->candidates = 2; rep->kept_ms = std::min(t0, t1); rep->gbs = stream_bytes / (1e-3 * rep->kept_ms) / 1e9; }
-  if (getenv("FX_TIMING") && atoi(getenv("FX_TIMING")))
-    fprintf(stderr, "[fx timing] %s value-array placement: first %.3f ms, second %.3f ms\n", what, t0, t1);
-  return err ? FX_ERROR_RUNTIME : 0;
-}
-
-static int tune_value_placement(fx_context *c) {
-  Bell &M = c->M;
-  auto time_spmv = [&](float *ms) -> int {
-    const int nwg = spmv_nparts(c);
-    if (spmv_launch(c, 0, 0, c->Bs, nullptr, c->W[7], nullptr, 0, nullptr, nwg)) return FX_ERROR_RUNTIME;  // untimed
-    HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    for (int i = 0; i < 3; i++)
-      if (spmv_launch(c, 0, 0, c->Bs, nullptr, c->W[7], nullptr, 0, nullptr, nwg)) return FX_ERROR_RUNTIME;
-    HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    HIP_TRY(hipEventSynchronize(c->ev1));
-    HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
-    *ms /= 3.f;
-    return 0;
-  };
-  const double bytes = (double)M.npairs * 64 * 76 + 48.0 * c->ord.nslots;
-  // (The vector the product writes was tried as a second knob -- scripts/experiments/ab_vectors.py showed 1.066 against 1.11 ms
-  // between work vectors in one context -- but at set-up time the ten candidates lie within 0.5 % of each other: not kept.)
-  return tune_placement(c, M, "SpMV", bytes, 6400.0, [&]() { return bell_fill_values(c, M); }, time_spmv, &c->place_spmv);
-}
-
 // Make the ordering, M (symbolic + values) and the work vectors current.
 static int ensure_solver(fx_context *c) {
   if (c->ord.kind < 0 && set_ordering(c, 0, nullptr)) return FX_ERROR_RUNTIME;
@@ -786,7 +713,6 @@ static int ensure_solver(fx_context *c) {
     if (bell_fill_values(c, c->M)) return FX_ERROR_RUNTIME;
     c->bell_valid = true;
     c->values_epoch++;  // the SpMV layout holds new values from here on
-    if (!c->M.placed && tune_value_placement(c)) return FX_ERROR_RUNTIME;
   }
   return 0;
 }
@@ -816,8 +742,6 @@ static int ensure_work(fx_context *c) {
       if (dev_alloc(&w, (size_t)len)) return FX_ERROR_RUNTIME;
       HIP_TRY(hipMemsetAsync(w, 0, (size_t)len * 8, c->stream));
     }
-    for (int k = 0; k < 10; k++) c->W0[k] = c->W[k];  // allocation order (placement experiments)
-    c->w_tuned = false;
     if (dev_alloc(&c->Bs, (size_t)len) || dev_alloc(&c->Xs, (size_t)len)) return FX_ERROR_RUNTIME;
     HIP_TRY(hipMemsetAsync(c->Bs, 0, (size_t)len * 8, c->stream));
     HIP_TRY(hipMemsetAsync(c->Xs, 0, (size_t)len * 8, c->stream));
@@ -871,6 +795,9 @@ extern "C" int fx_upload(fx_context *c, const fx_matrix_view *m, const fx_comm_v
     free_matrix(c);
     nl_free(c);  // the nonlinear state (and its scatter map) belongs to the old profile: fx_nl_init again
     A.N = m->N; A.NP = m->NP; A.NPL = m->NPL; A.NPU = m->NPU;
+    // the value arena first, while nothing of this system has been allocated: the value arrays of M (every block) and of the
+    // sweep layouts L + U (the off-diagonal blocks once more), 72 bytes per block, 3 % of slice padding
+    arena_reserve(c, (size_t)(74.2 * ((double)A.NP + 2.0 * ((double)A.NPL + (double)A.NPU))));
     if (dev_alloc(&A.indexL, (size_t)A.NP + 1) || dev_alloc(&A.indexU, (size_t)A.NP + 1) ||
         dev_alloc(&A.itemL, (size_t)A.NPL) || dev_alloc(&A.itemU, (size_t)A.NPU) ||
         dev_alloc(&A.D, (size_t)9 * A.NP) || dev_alloc(&A.AL, (size_t)9 * A.NPL) ||
@@ -948,6 +875,31 @@ extern "C" int fx_comm_init(fx_context *c, const unsigned char id[128], int rank
   c->nccl = comm;
   c->rank = rank;
   c->nranks = nranks;
+  c->ledger = CommLedger();
+  // The halo exchange (grouped ncclSend / ncclRecv on comm_stream) gets a communicator of its own, the scalar all-reduces (solver
+  // stream) keep `comm`: two streams never share a communicator.  Order across ranks does not depend on that split: on every rank
+  // halo k is enqueued, the solver stream waits for its event (halo_end) before the boundary rows, and the next all-reduce is
+  // enqueued behind those -- at most one RCCL operation of a rank is in flight at any time, in the same program order on all ranks.
+  // FX_HALO_COMM=0 (or an RCCL without ncclCommSplit): both use `comm`, which RCCL permits for operations that are ordered like this.
+  const char *hc = getenv("FX_HALO_COMM");
+  if (g_rccl.CommSplit && nranks > 1 && !(hc && atoi(hc) == 0)) {
+    ncclComm_t halo = nullptr;
+    if (g_rccl.CommSplit(comm, 0, rank, &halo, nullptr) == ncclSuccess && halo) c->nccl_halo = halo;
+  }
+  return 0;
+}
+
+// The communication ledger of this context (CommLedger, fx_internal.h): out[0] ops, [1] sequence hash, [2] all-reduces, [3] their
+// bytes, [4] halo exchanges, [5] neighbours, [6] 1 = the halo exchange has its own communicator; then 5 per neighbour: rank, sends,
+// send bytes, receives, receive bytes.  *n_out = entries the ledger holds, at most cap are written.
+extern "C" int fx_comm_ledger(fx_context *c, int64_t *out, int32_t cap, int32_t *n_out) {
+  if (!c) { g_fx_error = "fx_comm_ledger: null context"; return FX_ERROR_RUNTIME; }
+  const CommLedger &g = c->ledger;
+  std::vector<int64_t> v = {g.n_ops, (int64_t)g.seq_hash, g.n_allreduce, g.allreduce_bytes, g.n_halo, (int64_t)(g.peer.size() / 5),
+                            c->nccl_halo ? 1 : 0};
+  v.insert(v.end(), g.peer.begin(), g.peer.end());
+  if (n_out) *n_out = (int32_t)v.size();
+  for (int32_t k = 0; k < cap && k < (int32_t)v.size(); k++) out[k] = v[k];
   return 0;
 }
 
@@ -955,6 +907,7 @@ extern "C" int fx_comm_set_host_callbacks(fx_context *c, int rank, int nranks, f
                                           void *user) {
   c->cb_halo = halo; c->cb_allreduce = allreduce; c->cb_user = user;
   c->rank = rank; c->nranks = nranks;
+  c->ledger = CommLedger();
   return 0;
 }
 
@@ -998,6 +951,7 @@ static inline bool multi_rank(const fx_context *c) {
 // SUM over ranks of n (<= 8) doubles living at device address v, on the solver stream.
 static int allreduce_dev(fx_context *c, double *v, int n) {
   ClockScope cs(c, 2);
+  { CommLedger &g = c->ledger; g.n_ops++; g.n_allreduce++; g.allreduce_bytes += 8 * n; g.mix(0xA11ull << 32 | (uint64_t)n); }
   if (c->nccl) {
     NCCL_TRY(g_rccl.AllReduce(v, v, n, ncclDouble, ncclSum, (ncclComm_t)c->nccl, c->stream));
     return 0;
@@ -1040,6 +994,19 @@ static int halo_exchange(fx_context *c, double *x) {  // after halo_pack; everyt
   HaloDev &h = c->halo;
   if (!halo_active(c)) return 0;
   hipStream_t cs = c->comm_stream;
+  {
+    CommLedger &g = c->ledger;
+    g.n_ops++; g.n_halo++; g.mix(0x4A10ull << 32);
+    if (g.peer.size() != (size_t)5 * h.n_neighbor) {
+      g.peer.assign((size_t)5 * h.n_neighbor, 0);
+      for (int k = 0; k < h.n_neighbor; k++) g.peer[5 * k] = h.neighbor[k];
+    }
+    for (int k = 0; k < h.n_neighbor; k++) {
+      const int64_t ns = h.export_index[k + 1] - h.export_index[k], nr = h.import_index[k + 1] - h.import_index[k];
+      if (ns > 0) { g.peer[5 * k + 1]++; g.peer[5 * k + 2] += 24 * ns; }
+      if (nr > 0) { g.peer[5 * k + 3]++; g.peer[5 * k + 4] += 24 * nr; }
+    }
+  }
   if (!c->nccl) {  // host-staged transport: the host blocks on comm_stream only; what is queued on the solver stream keeps running
     if (!c->h_send) {
       HIP_TRY(hipHostMalloc((void **)&c->h_send, (size_t)3 * std::max(h.n_export, 1) * 8, hipHostMallocDefault));
@@ -1050,13 +1017,14 @@ static int halo_exchange(fx_context *c, double *x) {  // after halo_pack; everyt
     c->cb_halo(c->h_send, c->h_recv, c->cb_user);
     HIP_TRY(hipMemcpyAsync(h.recvbuf, c->h_recv, (size_t)3 * h.n_import * 8, hipMemcpyHostToDevice, cs));
   } else {
+    const ncclComm_t hcomm = (ncclComm_t)(c->nccl_halo ? c->nccl_halo : c->nccl);
     NCCL_TRY(g_rccl.GroupStart());
     for (int k = 0; k < h.n_neighbor; k++) {
       const int32_t ns = h.export_index[k + 1] - h.export_index[k], nr = h.import_index[k + 1] - h.import_index[k];
       if (ns > 0)
-        NCCL_TRY(g_rccl.Send(h.sendbuf + (size_t)3 * h.export_index[k], (size_t)3 * ns, ncclDouble, h.neighbor[k], (ncclComm_t)c->nccl, cs));
+        NCCL_TRY(g_rccl.Send(h.sendbuf + (size_t)3 * h.export_index[k], (size_t)3 * ns, ncclDouble, h.neighbor[k], hcomm, cs));
       if (nr > 0)
-        NCCL_TRY(g_rccl.Recv(h.recvbuf + (size_t)3 * h.import_index[k], (size_t)3 * nr, ncclDouble, h.neighbor[k], (ncclComm_t)c->nccl, cs));
+        NCCL_TRY(g_rccl.Recv(h.recvbuf + (size_t)3 * h.import_index[k], (size_t)3 * nr, ncclDouble, h.neighbor[k], hcomm, cs));
     }
     NCCL_TRY(g_rccl.GroupEnd());
   }
@@ -1472,36 +1440,6 @@ static int ssor_setup_symbolic(fx_context *c, int ncolor_in) {
 
 static int precond_apply_once(fx_context *c, const double *r, double *z, bool want_dot, int *nparts);
 
-// Placement search of the sweep layouts' value arrays (L, then U), timed on the whole apply.
-static int tune_sweep_placement(fx_context *c, const double *lu_D, const double *lu_AL, const double *lu_AU) {
-  SsorDev &S = c->ssor;
-  if (S.L.placed && S.U.placed) return 0;
-  if (c->tune_tries <= 1 || S.L.nslices < c->tune_min_slices) { S.L.placed = S.U.placed = true; return 0; }
-  if (ensure_work(c)) return FX_ERROR_RUNTIME;
-  KrylovState st0;
-  memset(&st0, 0, sizeof st0);
-  HIP_TRY(hipMemcpyAsync(c->st, &st0, sizeof st0, hipMemcpyHostToDevice, c->stream));  // status 0: the gated sweeps run
-  auto time_apply = [&](float *ms) -> int {
-    int np;
-    if (precond_apply_once(c, c->Bs, c->W[7], false, &np)) return FX_ERROR_RUNTIME;  // untimed
-    HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    for (int i = 0; i < 2; i++)
-      if (precond_apply_once(c, c->Bs, c->W[7], false, &np)) return FX_ERROR_RUNTIME;
-    HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    HIP_TRY(hipEventSynchronize(c->ev1));
-    HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
-    *ms /= 2.f;
-    return 0;
-  };
-  const double bytes = 76.0 * 64 * (double)(S.L.npairs + S.U.npairs) + (2 * 72.0 + 120.0) * S.nslots;
-  const double good = level_sched(c) ? 1e9 : 5450.0;  // level-scheduled ILU(0) is latency-bound: placement does not show
-  if (level_sched(c)) { S.L.placed = S.U.placed = true; return 0; }
-  // the sweeps gain 1-3 % at best (their speed classes lie closer together than the SpMV's): four candidates each
-  if (tune_placement(c, S.L, "sweep L", bytes, good, [&]() { return bell_fill_values(c, S.L, lu_D, lu_AL, lu_AU); }, time_apply, &c->place_sweep)) return FX_ERROR_RUNTIME;
-  if (c->place_sweep.candidates >= 2) return 0;  // the apply was slow and L got its second chance; U keeps its allocation
-  return tune_placement(c, S.U, "sweep U", bytes, good, [&]() { return bell_fill_values(c, S.U, lu_D, lu_AL, lu_AU); }, time_apply, &c->place_sweep);
-}
-
 static int ssor_setup_numeric(fx_context *c, double sigma_diag) {
   SsorDev &S = c->ssor;
   if (bell_fill_values(c, S.L) || bell_fill_values(c, S.U)) return FX_ERROR_RUNTIME;
@@ -1646,60 +1584,6 @@ static int ilu_setup_numeric(fx_context *c, double sigma_diag, bool factor) {
 // (scripts/experiments/ab_wperm.py) -- the run-to-run spread of the bench line.  The ten buffers are interchangeable, so
 // each is timed as the sweep vector of the preconditioner, as the output and as the gathered input of the SpMV, and the
 // fastest take the roles the loops hammer: z/q, p, r of CG; p~, s~, v, t of BiCGSTAB.  Large systems, once per allocation.
-static int tune_work_vectors(fx_context *c) {
-  if (c->w_tuned || c->tune_tries <= 1 || c->M.nslices < c->tune_min_slices || !c->have_values || !c->bell_valid) return 0;
-  c->w_tuned = true;
-  TuneClock tclock(c);
-  const int nwg = spmv_nparts(c);
-  KrylovState st0;
-  memset(&st0, 0, sizeof st0);
-  HIP_TRY(hipMemcpyAsync(c->st, &st0, sizeof st0, hipMemcpyHostToDevice, c->stream));  // status 0: the gated sweeps run
-  for (int k = 0; k < 10; k++) HIP_TRY(hipMemcpyAsync(c->W[k], c->Bs, (size_t)c->wlen * 8, hipMemcpyDeviceToDevice, c->stream));
-  auto timed = [&](auto &&launch, float *ms) -> int {  // one launch each: the effect looked for is 5-10 %, the noise of one launch 1 %
-    HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    if (launch()) return FX_ERROR_RUNTIME;
-    HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    HIP_TRY(hipEventSynchronize(c->ev1));
-    HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
-    return 0;
-  };
-  const bool sweeps = (c->precond_kind == 1 && c->precond_valid_sweeps);
-  std::vector<std::pair<float, int>> score;
-  float stream_ms[10];
-  for (int k = 0; k < 10; k++) {
-    double *b = c->W[k], *other = c->W[(k + 5) % 10];
-    float t = 0.f, acc = 0.f;
-    int np;
-    if (timed([&]() { return spmv_launch(c, 0, 1, other, nullptr, b, nullptr, 0, nullptr, nwg); }, &t)) return FX_ERROR_RUNTIME;  // written
-    acc += t;
-    if (timed([&]() { return spmv_launch(c, 0, 1, b, nullptr, other, nullptr, 0, nullptr, nwg); }, &t)) return FX_ERROR_RUNTIME;  // gathered
-    acc += t;
-    if (sweeps) {
-      if (timed([&]() { return precond_apply_once(c, other, b, false, &np); }, &t)) return FX_ERROR_RUNTIME;  // swept
-      acc += t;
-    }
-    if (timed([&]() {  // streamed: what the vector updates of the loop do to it (read + write, contiguous)
-          hipLaunchKernelGGL(k_axpy_plain, dim3(grid_for((int64_t)c->wlen)), dim3(256), 0, c->stream, (int64_t)c->wlen, 0.0, other, b);
-          return 0;
-        }, &t)) return FX_ERROR_RUNTIME;
-    acc += 4.f * t;  // an iteration streams each hot vector 3-5 times
-    stream_ms[k] = t;
-    score.push_back({acc, k});
-  }
-  std::stable_sort(score.begin(), score.end());
-  const int priority[10] = {1, 2, 0, 3, 6, 5, 4, 7, 8, 9};  // z/q, p, r (CG); p~ (BiCGSTAB), v, t, s, ...
-  double *old[10];
-  for (int k = 0; k < 10; k++) old[k] = c->W[k];
-  for (int q = 0; q < 10; q++) c->W[priority[q]] = old[score[q].second];
-  for (int k = 0; k < 10; k++) HIP_TRY(hipMemsetAsync(c->W[k], 0, (size_t)c->wlen * 8, c->stream));
-  if (getenv("FX_TIMING") && atoi(getenv("FX_TIMING"))) {
-    fprintf(stderr, "[fx timing] work vectors (written + gathered%s + 4 x streamed, ms; [streamed alone]):", sweeps ? " + swept" : "");
-    for (auto &sc : score) fprintf(stderr, " %d:%.3f[%.3f]", sc.second, sc.first, stream_ms[sc.second]);
-    fprintf(stderr, "\n");
-  }
-  return 0;
-}
-
 extern "C" int fx_precond_setup(fx_context *c, const int32_t *Iarray, const double *Rarray) {
   HIP_TRY(hipSetDevice(c->device));
   if (!c->have_values) { g_fx_error = "fx_precond_setup: no matrix values resident"; return FX_ERROR_RUNTIME; }
@@ -1741,34 +1625,27 @@ extern "C" int fx_precond_setup(fx_context *c, const int32_t *Iarray, const doub
     }
     pt.lap("symbolic");
     if (ensure_solver(c)) return FX_ERROR_RUNTIME;
-    pt.lap("solver layout values + SpMV placement");
+    pt.lap("solver layout values");
     if (ssor_setup_numeric(c, sigma_diag)) return FX_ERROR_RUNTIME;
     if (pt.on) HIP_TRY(hipStreamSynchronize(c->stream));
     pt.lap("numeric");
-    if (tune_sweep_placement(c, nullptr, nullptr, nullptr)) return FX_ERROR_RUNTIME;
-    pt.lap("sweep placement");
     c->precond_valid_sweeps = true;
   }
-  {
-    PhaseTimer pt("precond setup");
-    if (tune_work_vectors(c)) return FX_ERROR_RUNTIME;
-    pt.lap("work vectors");
-  }
   HIP_TRY(hipStreamSynchronize(c->stream));
-  release_held(c);  // the losers of this set-up's placement checks: nothing stays allocated beyond the set-up
   c->precond_valid = true;
   return 0;
 }
 
-// What the placement checks of the set-ups found (see tune_placement): out[0..3] SpMV value array {ms of the first allocation,
-// ms of the kept one, candidates timed (0 = not checked: small system), GB/s of the kept one over the streamed bytes},
-// out[4..7] the same for the sweep layouts of SSOR (timed on the whole apply), out[8] device bytes currently held by losing
-// candidates (0 outside a set-up).
+// Where the BELL value arrays of this context live (DevArena, fx_internal.h): out[0] bytes of the arena (0: none -- small system,
+// FX_ARENA_GB=0, or no memory to spare), [1] bytes in use, [2] arrays placed in it, [3..5] 1 if the value array of M / L / U lies in
+// it, [6] bytes of M's value array.  Nothing is measured or searched at set-up: the arena makes the placement the same in every
+// process (rounds 2-3 timed candidate allocations here; scripts/r4/region_probe.py has the evidence for what replaced them).
 extern "C" int fx_placement_report(fx_context *c, double out[9]) {
   if (!c || !out) { g_fx_error = "fx_placement_report: null argument"; return FX_ERROR_RUNTIME; }
-  const PlacementReport *r[2] = {&c->place_spmv, &c->place_sweep};
-  for (int k = 0; k < 2; k++) { out[4 * k] = r[k]->first_ms; out[4 * k + 1] = r[k]->kept_ms; out[4 * k + 2] = r[k]->candidates; out[4 * k + 3] = r[k]->gbs; }
-  out[8] = (double)c->held_bytes;
+  for (int k = 0; k < 9; k++) out[k] = 0.0;
+  out[0] = (double)c->arena.bytes; out[1] = (double)c->arena.used; out[2] = c->arena.live;
+  out[3] = c->M.arena_owner ? 1 : 0; out[4] = c->ssor.L.arena_owner ? 1 : 0; out[5] = c->ssor.U.arena_owner ? 1 : 0;
+  out[6] = (double)c->M.npairs * 576 * 8;
   return 0;
 }
 
@@ -2047,6 +1924,7 @@ static int eis_refresh_t(fx_context *c, const int32_t *gate) {
   return 0;
 }
 static int eis_begin(fx_context *c) {  // after the standard begin (r0 = b - A x0 in W[0], ||b||^2)
+  c->eis_rho_done = false;
   for (int k : {1, 2, 5, 6, 7}) HIP_TRY(hipMemsetAsync(c->W[k], 0, (size_t)c->wlen * 8, c->stream));
   HIP_TRY(hipMemsetAsync(c->W[3], 0, (size_t)c->wlen * 8, c->stream));
   return eis_refresh_t(c, nullptr);
@@ -2061,7 +1939,9 @@ static int eis_cg_iteration(fx_context *c, int it) {
   const double esc = (S.sigma_diag - 1.0) / S.sigma_diag;  // (D~ - D) = esc * diag(D~)
   double *part_rho = c->partials + c->max_partials;
   // rho = r.M^-1 r = t.D~t (:168), beta (:193); ph = D~ t + beta ph  [= (D~+U)(z + beta p)]
-  if (scalar_stage<OP_CG_RHO>(c, ugrid, 0, RECOMPUTE, part_rho)) return FX_ERROR_RUNTIME;
+  // (already done by the previous iteration's OP_RESID_RHO stage unless t was refreshed since)
+  if (!c->eis_rho_done && scalar_stage<OP_CG_RHO>(c, ugrid, 0, RECOMPUTE, part_rho)) return FX_ERROR_RUNTIME;
+  c->eis_rho_done = false;
   if (c->eis_fuse) {  // p = (D~+U)^-1 ph with ph = D~ t + beta ph formed by each row's own lane on the way (k_eis_backward)
     ClockScope cs(c, 1);
     const int spb = c->ssor_bs / 64;
@@ -2127,7 +2007,12 @@ static int eis_cg_iteration(fx_context *c, int it) {
   } else {
     hipLaunchKernelGGL((k_eis_update<1>), dim3(ugrid), dim3(FX_BLOCK), 0, c->stream, ns, c->st, S.alu, P, Q, WH, X, R, T, DT,
                        c->partials, part_rho, gate_status(c));
-    if (scalar_stage<OP_RESID>(c, ugrid, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;  // converged by the recurrence: the loop parks, verify_stage() follows from the host
+    // converged by the recurrence: the loop parks, verify_stage() follows from the host.  ||r||^2 (region 0) and the next iteration's
+    // rho = t.D~t (region 1, max_partials further) left k_eis_update together: one stage, one 2-double all-reduce
+    if (c->eis_merge) {
+      if (scalar_stage<OP_RESID_RHO>(c, ugrid, c->max_partials, RECOMPUTE)) return FX_ERROR_RUNTIME;
+      c->eis_rho_done = true;
+    } else if (scalar_stage<OP_RESID>(c, ugrid, 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
   }
   HIP_TRY(hipGetLastError());
   return 0;
@@ -2212,6 +2097,7 @@ static int verify_stage(fx_context *c) {
   if (spmv(c, 1, 2, c->Xs, c->Bs, c->W[0], gate_verify(c), 1)) return FX_ERROR_RUNTIME;
   if (scalar_stage<OP_VERIFY>(c, spmv_nparts(c), 0, RECOMPUTE)) return FX_ERROR_RUNTIME;
   if (c->eis_active && eis_refresh_t(c, &c->st->t_current)) return FX_ERROR_RUNTIME;  // runs only if the loop goes on (t_current == 0)
+  c->eis_rho_done = false;  // ... and then leaves new rho partials: the next iteration reduces them itself
   return 0;
 }
 
@@ -2255,9 +2141,10 @@ static int bicgstab_iteration(fx_context *c, int it) {
 // every `chunk` iterations only; once the device has left the RUNNING state the already
 // enqueued kernels are no-ops.  *st_out is the state after the last poll.
 static void graphs_destroy(fx_context *c) {
-  if (c->g_normal) (void)hipGraphExecDestroy(c->g_normal);
-  if (c->g_recompute) (void)hipGraphExecDestroy(c->g_recompute);
-  c->g_normal = c->g_recompute = nullptr;
+  for (auto &g : c->g_iter) {
+    if (g) (void)hipGraphExecDestroy(g);
+    g = nullptr;
+  }
 }
 
 // Capture one iteration (the kernels it enqueues on the solver stream) into an executable graph.
@@ -2288,8 +2175,12 @@ static int krylov_steps(fx_context *c, int n, KrylovState *st_out) {
     const int it = c->k_it;
     int e = 0;
     if (c->k_graph) {
-      hipGraphExec_t &g = (it % recompute == 0) ? c->g_recompute : c->g_normal;
-      if (!g) e = capture_iteration(c, it, &g);
+      // what an iteration enqueues depends on two things only: whether it recomputes the true residual, and (Eisenstat's form)
+      // whether it starts with its own rho stage; eis_rho_done after it follows from the first alone
+      const bool own_rho = c->eis_active && !c->eis_rho_done, recomp = (it % recompute == 0);
+      hipGraphExec_t &g = c->g_iter[(recomp ? 1 : 0) | (own_rho ? 2 : 0)];
+      if (!g) e = capture_iteration(c, it, &g);  // (the capture runs the host side of the iteration: eis_rho_done is updated by it)
+      else if (c->eis_active) c->eis_rho_done = c->eis_merge && !recomp;
       if (!e) HIP_TRY(hipGraphLaunch(g, c->stream));
     } else {
       e = (c->k_method == 1) ? cg_iteration(c, it) : bicgstab_iteration(c, it);
@@ -2831,7 +2722,6 @@ extern "C" int fx_stream_ceiling(fx_context *c, int nrepeat, double *gbs) {
 // out[0] N, [1] NP, [2] NPL, [3] NPU, [4] M.npairs, [5] M.nblocks, [6] M.nslices,
 // [7] ssor.ncolor, [8] L.npairs, [9] L.nblocks, [10] U.npairs, [11] U.nblocks, [12] ssor slices,
 // [13] interior / [14] boundary workgroups of the SpMV (domain-decomposed systems)
-extern "C" double fx_tune_seconds(fx_context *c) { return c ? c->tune_spent_s : 0.0; }
 
 extern "C" int fx_get_stats(fx_context *c, int64_t out[16]) {
   memset(out, 0, 16 * sizeof(int64_t));

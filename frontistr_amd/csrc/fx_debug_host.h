@@ -70,6 +70,15 @@ static int dbg_alloc(fx_context *c, size_t bytes, int how, int64_t arg, char **o
   }
 }
 
+// Take the arena NOW (before the library has allocated anything else, when called right after fx_create).
+extern "C" int fx_debug_arena(fx_context *c, int gib) {
+  HIP_TRY(hipSetDevice(c->device));
+  if (g_dbg_arena.base) return 0;
+  g_dbg_arena.bytes = (size_t)gib << 30;
+  HIP_TRY(hipMalloc((void **)&g_dbg_arena.base, g_dbg_arena.bytes));
+  return 0;
+}
+
 static double **dbg_vector(fx_context *c, int sel) {
   if (sel == -1) return &c->Bs;
   if (sel == -2) return &c->Xs;
@@ -88,7 +97,9 @@ extern "C" int fx_debug_replace(fx_context *c, int what, int how, int64_t arg, u
   if (what == 0) {
     const size_t bytes = (size_t)M.npairs * 576 * 8;
     if (dbg_alloc(c, bytes, how, arg, &p)) return FX_ERROR_RUNTIME;
-    g_dbg_leak.push_back(M.val2_base);
+    if (!M.arena_owner) g_dbg_leak.push_back(M.val2_base);
+    else arena_release(M.arena_owner);
+    M.arena_owner = nullptr;
     M.val2_base = p; M.val2 = (double *)p; M.val2_bytes = bytes;
     if (bell_fill_values(c, M)) return FX_ERROR_RUNTIME;
   } else if (what == 1) {
@@ -115,7 +126,6 @@ extern "C" int fx_debug_replace(fx_context *c, int what, int how, int64_t arg, u
     if (dbg_alloc(c, bytes, how, arg, &p)) return FX_ERROR_RUNTIME;
     HIP_TRY(hipMemcpy(p, *v, bytes, hipMemcpyDeviceToDevice));
     g_dbg_leak.push_back(*v);
-    for (auto &w0 : c->W0) if (w0 == *v) w0 = (double *)p;
     *v = (double *)p;
   } else {
     g_fx_error = "fx_debug_replace: unknown array";

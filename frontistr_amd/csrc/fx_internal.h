@@ -60,8 +60,8 @@ struct Bell {
   int32_t *wg_interior = nullptr, *wg_boundary = nullptr;
   int32_t n_wg_interior = 0, n_wg_boundary = 0;
   int64_t nblocks = 0;          // real (non padding) blocks
-  size_t val2_bytes = 0;        // bytes val2_base was allocated with (the power-of-two request, or the exact size)
-  bool placed = false;          // the value array went through the placement search (once per symbolic build)
+  size_t val2_bytes = 0;        // bytes val2_base was allocated with (its share of the arena, the power-of-two request, or the exact size)
+  struct fx_context *arena_owner = nullptr;  // val2_base lies in this context's value arena (DevArena): released there, not with hipFree
   size_t bytes() const { return (size_t)npairs * 64 * (9 * 8 + 4) + (size_t)(nslices + 1) * 4; }
 };
 
@@ -195,7 +195,22 @@ struct PhaseClock {
   double acc[3] = {0.0, 0.0, 0.0};  // seconds
 };
 
-struct PlacementReport { float first_ms = 0.f, kept_ms = 0.f; int candidates = 0; double gbs = 0.0; };  // tune_placement
+// The value arena (round 4).  Where hipMalloc puts a BELL value array PHYSICALLY decides the speed class of the sweep that streams it:
+// the identical SpMV on identical data runs at 1.03-1.05 ms or at 1.18 ms (10.1M DOF), and a fresh power-of-two request is a
+// lottery between the two (scripts/r4/region_probe.py: 5 of 14 consecutive 8 GiB blocks slow on one box, the first allocation of
+// the process among them).  What was ruled out with measurements of ONE context whose arrays were moved between allocations
+// (scripts/r4/*.py, profiles/r04_placement_evidence.txt): the vectors x / y (twelve choices within 0.3 %), the column ids, the
+// row pointers, the workgroup -> XCD map (eight maps within 1 %), the slice order, address translation (TCP_UTCL1 misses equal
+// in both classes: 47.6k of 171M requests).  What holds on every box measured: inside ONE large allocation taken before anything
+// else every offset runs in the same fast class (1.044-1.048 ms at sixteen offsets of a 64 GiB block on a box whose first
+// power-of-two block ran at 1.180).  So the context takes one arena when it first learns the size of a large system -- before the
+// CSR arrays, the layouts and the vectors -- and the value arrays of M, L and U live in it at fixed 2 MiB-aligned offsets.
+// FX_ARENA_GB: 0 = off (every array its own hipMalloc), n = arena of at least n GiB (default 32), always a power of two.
+struct DevArena {
+  char *base = nullptr;
+  size_t bytes = 0, used = 0;
+  int live = 0;  // arrays currently placed in it; the bump pointer returns to 0 when the last one goes
+};
 
 // One pass of the auto-SIGMA_DIAG / METHOD2 loop of hecmw_solve_iterative (hecmw_solver_Iterative.f90:117-157): what the reference
 // prints per pass (banner, ITERLOG lines, 'Increasing SIGMA_DIAG to') is replayed by the binding from this log.
@@ -205,7 +220,21 @@ struct AttemptLog {
   std::vector<double> hist;      // its residual-history lines
 };
 
+// What this rank asked of the transport, in program order: every all-reduce and every halo exchange (per neighbour: messages and
+// bytes each way) since the communicator was set up.  All ranks of a correct run hold the same op count and the same sequence hash
+// (the kinds and sizes of the collectives and the positions of the halo exchanges between them), and rank r's sends to p equal p's
+// receives from r: bench.py --gpus N compares the ledgers over its gloo control plane (fx_comm_ledger), and its watchdog prints the
+// local one when a step does not come back -- a mismatch shows as a message with the op index, not only as a hang.
+struct CommLedger {
+  int64_t n_ops = 0, n_allreduce = 0, allreduce_bytes = 0, n_halo = 0;
+  uint64_t seq_hash = 1469598103934665603ull;  // FNV-1a over (kind, size) of the ops in order
+  std::vector<int64_t> peer;                   // 5 per neighbour: rank, sends, send bytes, receives, receive bytes
+  void mix(uint64_t v) { for (int k = 0; k < 8; k++) { seq_hash ^= (v >> (8 * k)) & 0xff; seq_hash *= 1099511628211ull; } }
+};
+
 struct fx_context {
+  CommLedger ledger;
+  void *nccl_halo = nullptr;  // the halo exchange's own communicator (ncclCommSplit of nccl; null: the exchanges share nccl)
   std::vector<AttemptLog> attempts;  // of the last fx_solve / fx_solve_resident (fx_solve_attempts)
   int device = 0;
   int n_cu = 256;  // compute units of the device
@@ -286,32 +315,25 @@ struct fx_context {
   // multicolour SSOR with iterPREmax = 1, colour-major numbering, preconditioner built from the resident values (subdomains: plus
   // the halo term H p); anything else -- a recycled preconditioner, iterPREmax != 1, BiCGSTAB -- runs the standard loop on its own.
   bool eisenstat = true, eis_active = false;
+  // Eisenstat's form: rho of the NEXT iteration was already reduced together with ||r||^2 of the last one (OP_RESID_RHO: one scalar
+  // stage -- on a decomposed system one 2-double all-reduce -- instead of two).  False after a begin, after an iteration that
+  // recomputed the true residual and after a true-residual check: those refresh t and leave new rho partials (FX_EIS_MERGE=0: never).
+  bool eis_rho_done = false, eis_merge = true;
   bool dbg_onecolor = false; // measurement only (FX_DEBUG_ONECOLOR): the half sweeps as one launch each, dependencies ignored
   bool eis_fuse = true;      // direction update fused into the backward sweep (FX_EIS_FUSE=0: k_cg_update_p + the plain sweep)
   int64_t values_epoch = 0;  // counts the refreshes of the SpMV layout's values
-  // Placement search of the SpMV's value array.  The identical kernel on identical data runs at 1.03-1.19 ms (10.1M DOF)
-  // depending on WHERE hipMalloc put the 6.5 GB value array physically: same virtual layout, same alignment, different speed
-  // (scripts/experiments/ab_ssor.py with FX_DUMMY_MB / FX_PLACEMENT_DEBUG).  So the library measures: up to tune_tries
-  // candidate allocations are filled and timed (3 SpMV launches each), the fastest is kept, the others are released.
-  // Large systems only (>= tune_min_slices), once per symbolic build, bounded by free device memory.  FX_TUNE_PLACEMENT=0 off.
   bool layout_device = true;        // BELL source maps built by k_bell_count / k_bell_map (FX_LAYOUT_DEVICE=0: host threads)
   int32_t mc_batch = 32;            // rounds of the device multicolouring between two looks at the queue length by the host (FX_MC_BATCH)
   int32_t mc_device_min = 100000;   // block rows from which the multicolouring of the SSOR set-up runs on the device (FX_MC_DEVICE_MIN)
-  bool val2_pow2 = true;            // BELL value arrays of a gigabyte or more: ask hipMalloc for the next power of two -- ONE block of the driver's allocator, the fast placement class (FX_VAL2_POW2=0: the exact size)
-  double tune_spent_s = 0.0;        // wall time of all tuning steps of this context's set-ups (placement searches, work-vector roles): fx_tune_seconds
-  double tune_cand_s = 0.0;         // of which: allocating, filling and timing extra candidates (what the budget caps)
-  std::vector<void *> held;         // losing candidates of the placement searches, released with the context
-  size_t held_bytes = 0;            // bytes of the losing candidates (released at the end of the set-up that made them, or earlier under memory pressure)
+  bool val2_pow2 = true;            // BELL value arrays of a gigabyte or more that do not fit the arena: ask hipMalloc for the next power of two (FX_VAL2_POW2=0: the exact size)
+  DevArena arena;                   // the value arena of this context (see DevArena)
+  int arena_min_gb = 32;            // FX_ARENA_GB
+  size_t arena_threshold = (size_t)1 << 30;  // estimated value-array bytes from which a system gets an arena
   int32_t bfs_batch = 16;           // levels of the device level ordering between two looks at the level state by the host (FX_BFS_BATCH)
   int32_t bfs_device_min = 100000;  // block rows from which the level ordering of the SSOR set-up runs on the device (FX_BFS_DEVICE_MIN)
-  int tune_tries = 2;               // 2: a slow first allocation gets ONE second candidate; <= 1: no check (FX_TUNE_PLACEMENT)
-  PlacementReport place_spmv, place_sweep;
-  int32_t tune_min_slices = 8192;
   // work vectors (3*NP each)
   double *W[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  double *W0[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // the work vectors in allocation order
-  bool w_tuned = false;               // the roles of the work vectors went through tune_work_vectors
-  bool precond_valid_sweeps = false;  // multicolour SSOR layouts filled (tune_work_vectors may time a sweep)
+  bool precond_valid_sweeps = false;  // multicolour SSOR layouts filled
   int iterpremax = 1;  // additive-Schwarz sweeps of hecmw_precond_33_apply
   int32_t wlen = 0;
   double *scale_vec = nullptr;  // SCALING=YES: 1/sqrt|diag|, reference numbering, 3*NP (+ slack)
@@ -330,13 +352,13 @@ struct fx_context {
   int k_method_last = 1;       // METHOD of the last fx_solve_resident attempt
   double host_dbg[16] = {0};   // scalars of the host-driven recurrences (fx_debug_state)
   // Launch-bound sizes (<= graph_max_rows block rows, single rank): one CG / BiCGSTAB iteration is captured once per
-  // solve into two hipGraphs (ordinary iteration; the one that recomputes r = b - A x) and replayed -- every kernel
+  // solve into hipGraphs (ordinary iteration; the one that recomputes r = b - A x; in Eisenstat's form each with / without its own rho stage) and replayed -- every kernel
   // argument is constant over a solve, what changes lives in the device-resident KrylovState.
   // FX_GRAPH=0 off, 1 auto (default: SSOR / ILU(0) only, where an iteration is 40+ launches), 2 always.
   int graph_mode = 1;
   int32_t graph_max_rows = 1 << 19;
   bool k_graph = false;
-  hipGraphExec_t g_normal = nullptr, g_recompute = nullptr;
+  hipGraphExec_t g_iter[4] = {nullptr, nullptr, nullptr, nullptr};  // by kind of iteration: bit 0 = recomputes the true residual, bit 1 = starts with its own rho stage
   // communication
   int rank = 0, nranks = 1;
   int view_petot = 1;        // PETOT of the comm view the profile came with (require_transport)

@@ -1391,7 +1391,9 @@ enum ScalarOp {
   OP_BI_RHO,       // hecmw_solver_BiCGSTAB.f90:152, :161
   OP_BI_C2,        // :188-190
   OP_BI_OMEGA,     // :217-226
-  OP_PLAIN         // just the sum(s) -> red[]
+  OP_PLAIN,        // just the sum(s) -> red[]
+  OP_RESID_RHO     // Eisenstat's form: ||r||^2 of iteration k (:240-267) and rho of iteration k+1 (:168-193) in ONE stage -- both partial
+                   // sets leave k_eis_update together, so a decomposed run needs one 2-double all-reduce for them instead of two
 };
 
 __device__ __forceinline__ double reduce_partials(const double *partials, int n) {
@@ -1426,7 +1428,7 @@ __global__ void k_scalar(const double *__restrict__ partials, int32_t nparts, in
   double v0 = 0.0, v1 = 0.0;
   if (phase != 2) {
     v0 = reduce_partials(partials, nparts);
-    if (OP == OP_BI_OMEGA || (OP == OP_PLAIN && stride > 0)) v1 = reduce_partials(partials + stride, nparts);
+    if (OP == OP_BI_OMEGA || OP == OP_RESID_RHO || (OP == OP_PLAIN && stride > 0)) v1 = reduce_partials(partials + stride, nparts);
     if (phase == 1 || OP == OP_PLAIN) {
       if (threadIdx.x == 0) { red[0] = v0; red[1] = v1; }
       return;
@@ -1450,7 +1452,7 @@ __global__ void k_scalar(const double *__restrict__ partials, int32_t nparts, in
     st->c1 = v0;
     if (!(v0 > 0.0)) { st->status = FX_ERROR_DIVERGE_MAT; return; }  // `C1 <= 0` (NaN falls here too)
     st->alpha = st->rho / v0;
-  } else if (OP == OP_RESID || OP == OP_VERIFY) {
+  } else if (OP == OP_RESID || OP == OP_VERIFY || OP == OP_RESID_RHO) {
     st->dnrm2 = v0;
     const double resid = sqrt(v0 / st->bnrm2);
     st->resid = resid;
@@ -1462,7 +1464,7 @@ __global__ void k_scalar(const double *__restrict__ partials, int32_t nparts, in
       st->error = FX_ERROR_NOCONV_MAXIT; st->status = FX_ERROR_NOCONV_MAXIT; st->need_verify = 0;
       return;
     }
-    if (OP == OP_RESID) {
+    if (OP == OP_RESID || OP == OP_RESID_RHO) {
       if (hist) hist[it - 1] = resid;
       st->n_hist = it;
       if (resid <= st->tol) {
@@ -1480,6 +1482,16 @@ __global__ void k_scalar(const double *__restrict__ partials, int32_t nparts, in
     if (it == st->maxit) { st->error = FX_ERROR_NOCONV_MAXIT; st->status = FX_ERROR_NOCONV_MAXIT; st->iter = it + 1; return; }
     st->rho1 = st->rho;
     st->iter = it + 1;
+    if (OP == OP_RESID_RHO) {  // the loop goes on: OP_CG_RHO of iteration it + 1, literally
+      st->t_current = 1;
+      st->rho = v1;
+      if (v1 == 0.0) { st->status = 1; return; }
+      if (v1 * st->rho1 <= 0.0) {
+        st->n_indef++;
+        if (st->n_indef >= 3) { st->status = FX_ERROR_DIVERGE_PC; return; }
+      }
+      st->beta = v1 / st->rho1;
+    }
   } else if (OP == OP_BI_RHO) {
     st->rho = v0;
     st->beta = (st->iter > 1) ? (v0 / st->rho1) * (st->alpha / st->omega) : 0.0;

@@ -211,17 +211,12 @@ class SolverContext:
         _chk(f(self.h, name.encode(), float(value)))
 
     def placement_report(self):
+        """Where the value arrays of the sliced layouts live (fx_placement_report): the context's value arena."""
         out = (C.c_double * 9)()
         _chk(lib().fx_placement_report(self.h, out))
-        return {"spmv": {"first_ms": out[0], "kept_ms": out[1], "candidates": int(out[2]), "GBs": out[3]},
-                "sweeps": {"first_ms": out[4], "kept_ms": out[5], "candidates": int(out[6]), "GBs": out[7]},
-                "held_bytes": int(out[8])}
-
-    def tune_seconds(self):
-        """Wall time of the measured tuning steps of this context's set-ups so far (placement searches, work-vector roles)."""
-        f = lib().fx_tune_seconds
-        f.restype = C.c_double
-        return float(f(self.h))
+        return {"arena_bytes": int(out[0]), "arena_used_bytes": int(out[1]), "arrays_in_arena": int(out[2]),
+                "spmv_values_in_arena": bool(out[3]), "lower_values_in_arena": bool(out[4]), "upper_values_in_arena": bool(out[5]),
+                "spmv_value_bytes": int(out[6])}
 
     def solve_resident(self, hecMAT, want_history=True):
         info = _SolveInfo()
@@ -284,6 +279,18 @@ class SolverContext:
         it, st, rs = C.c_int32(0), C.c_int32(0), C.c_double(0)
         _chk(lib().fx_krylov_steps(self.h, int(nsteps), C.byref(it), C.byref(st), C.byref(rs)))
         return it.value, st.value, rs.value
+
+    def comm_ledger(self):
+        """What this rank asked of the transport since it was set up (fx_comm_ledger): dict with ops, seq_hash, allreduces,
+        allreduce_bytes, halos, own_halo_comm and peers = {rank: (sends, send_bytes, recvs, recv_bytes)}."""
+        n = C.c_int32(0)
+        _chk(lib().fx_comm_ledger(self.h, None, 0, C.byref(n)))
+        out = (C.c_int64 * max(n.value, 1))()
+        _chk(lib().fx_comm_ledger(self.h, out, n.value, C.byref(n)))
+        v = list(out)[:n.value]
+        peers = {int(v[7 + 5 * k]): tuple(int(x) for x in v[8 + 5 * k:12 + 5 * k]) for k in range(int(v[5]))}
+        return {"ops": int(v[0]), "seq_hash": int(v[1]) & 0xFFFFFFFFFFFFFFFF, "allreduces": int(v[2]), "allreduce_bytes": int(v[3]),
+                "halos": int(v[4]), "own_halo_comm": bool(v[6]), "peers": peers}
 
     def krylov_history(self):
         """RESID per iteration of the staged loop since krylov_begin (the reference's ITERLOG lines, hecmw_solver_CG.f90:245)."""

@@ -148,14 +148,10 @@ int fx_precond_apply_host(fx_context *ctx, const double *r, double *z);   /* z =
  * SpMV workgroups overlapped with the halo exchange (interior), ordered after it (boundary) | [15] bit 0: the last Krylov
  * loop ran in Eisenstat's form (the default for CG + multicolour SSOR, FX_EISENSTAT=0 opts out); bit 1: the ILU(0) sweeps are chain sweeps (FX_DATAFLOW=3) */
 int fx_get_stats(fx_context *ctx, int64_t out[16]);
-/* wall time (s) this context's set-ups have spent on measured tuning so far -- the placement searches of the value arrays
- * (candidate allocations: 10 ms each from recycled memory, ~200 ms each when the driver has to clear fresh VRAM) and the role
- * timing of the work vectors -- as opposed to building the preconditioner (no reference counterpart: the reference has no
- * such step; FX_TUNE_PLACEMENT=0 switches the searches off) */
-double fx_tune_seconds(fx_context *ctx);
-/* Placement checks of the set-ups: out[0..3] SpMV value array {ms of the first allocation, ms of the kept
- * one, candidates timed (0: not checked), GB/s of the kept one}, out[4..7] the same for the SSOR sweep layouts (timed on the whole
- * apply), out[8] device bytes still held by losing candidates (0 outside a set-up).  No counterpart in the reference. */
+/* Where the value arrays of the sliced layouts live: out[0] bytes of the context's value arena (one large allocation taken when the
+ * size of a large system first becomes known, before anything else of it: 0 = none), [1] bytes in use, [2] arrays placed in it,
+ * [3..5] 1 if the value array of the SpMV layout / the lower / the upper sweep layout lies in it, [6] bytes of the SpMV layout's
+ * value array.  FX_ARENA_GB (0 = off, default 32 = at least 32 GiB).  Nothing is timed or searched at set-up. */
 int fx_placement_report(fx_context *ctx, double out[9]);
 /* The passes of the auto-SIGMA_DIAG / METHOD2 loop of the last solve on this context (hecmw_solver_Iterative.f90:117-157: banner
  * :125 before every pass, 'Increasing SIGMA_DIAG to' :149 before a retry): METHOD, the SIGMA_DIAG in effect and the number of
@@ -307,6 +303,12 @@ int fx_comm_init(fx_context *ctx, const unsigned char id[128], int rank, int nra
 /* Ranks the transport itself reports (ncclCommCount of the RCCL communicator, or the count given with the host
  * callbacks; 1 without either) and the device the communicator / context is bound to. */
 int fx_comm_size(fx_context *ctx, int32_t *nranks, int32_t *device);
+/* What this rank asked of the transport since it was set up, for a cross-rank consistency check (bench.py --gpus N compares the
+ * ledgers of all ranks over its control plane; hecmw_solver_SR_33.F90:42-124 and hecmw_comm_f.F90:346-379 are the calls counted):
+ * out[0] operations, [1] hash of their sequence (kind and size of every all-reduce, position of every halo exchange: equal on all
+ * ranks), [2] all-reduces, [3] their bytes, [4] halo exchanges, [5] neighbours, [6] 1 = the halo exchange has a communicator of its
+ * own, then 5 per neighbour: rank, messages sent, bytes sent, messages received, bytes received.  *n_out = entries available. */
+int fx_comm_ledger(fx_context *ctx, int64_t *out, int32_t cap, int32_t *n_out);
 typedef void (*fx_halo_fn)(const double *send, double *recv, void *user);
 typedef void (*fx_allreduce_fn)(double *v, int n, void *user);
 int fx_comm_set_host_callbacks(fx_context *ctx, int rank, int nranks, fx_halo_fn halo, fx_allreduce_fn allreduce,

@@ -48,3 +48,24 @@ def test_decomposition_and_parser():
     assert a.gpus == 1 and a.n == 149 and a.method == 1 and a.precond == 1
     # 7.009 GB per SpMV at 10.125M DOF
     assert bench.spmv_algorithmic_bytes(3375000, 89915392) == 7009069800
+
+
+def test_ledger_cross_check_names_the_rank_that_differs():
+    """bench.py's cross-rank check of the communication ledgers (fx_comm_ledger): consistent ledgers pass; a rank with one more
+    all-reduce, or a message nobody received, is named."""
+    import bench
+
+    def led(ops, h, ar, peers):
+        return {"ops": ops, "seq_hash": h, "allreduces": ar, "allreduce_bytes": 16 * ar, "halos": ops - ar, "own_halo_comm": True, "peers": peers}
+
+    good = [led(10, 77, 6, {1: (4, 960, 4, 480)}), led(10, 77, 6, {0: (4, 480, 4, 960)})]
+    chk = bench.check_ledgers(good)
+    assert chk["errors"] == [] and chk["allreduces"] == 6 and chk["halo_exchanges"] == 4 and chk["halo_bytes_sent_per_rank"] == [960, 480]
+    bad = [led(10, 77, 6, {1: (4, 960, 4, 480)}), led(11, 78, 7, {0: (4, 480, 4, 960)})]
+    e = bench.check_ledgers(bad)["errors"]
+    assert any("rank 1 ops = 11" in x for x in e) and any("seq_hash" in x for x in e)
+    lost = [led(10, 77, 6, {1: (5, 1200, 4, 480)}), led(10, 77, 6, {0: (4, 480, 4, 960)})]
+    e = bench.check_ledgers(lost)["errors"]
+    assert e and "rank 0 -> 1" in e[0]
+    alone = [led(10, 77, 6, {1: (4, 960, 4, 480)}), led(10, 77, 6, {})]
+    assert any("does not list it" in x for x in bench.check_ledgers(alone)["errors"])

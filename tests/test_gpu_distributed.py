@@ -469,7 +469,8 @@ def test_bench_decomposition_2x2x2_eight_contexts(oracle, meth, pc, form):
             if form is not None:
                 assert st["eisenstat"] == (1 if form == "eisenstat" else 0)
             res = dict(X=mat.X.copy(), it=ctx.info.iterations, hist=ctx.history.copy(), code=code, gid=sub.global_id,
-                       conv=int(mat.Iarray[80]), wg=(st["wg_interior"], st["wg_boundary"]), nnb=len(sub.neighbor_pe))
+                       conv=int(mat.Iarray[80]), wg=(st["wg_interior"], st["wg_boundary"]), nnb=len(sub.neighbor_pe),
+                       led=ctx.comm_ledger())
             ctx.close()
             return res
         return ThreadWorld(8).run(rank_main)
@@ -480,6 +481,18 @@ def test_bench_decomposition_2x2x2_eight_contexts(oracle, meth, pc, form):
         assert a["it"] == b["it"] and np.array_equal(a["hist"], b["hist"]) and np.array_equal(a["X"], b["X"])
         assert b["wg"][1] > 0
     assert len(set(int(r["it"]) for r in ovl)) == 1
+    # the communication ledgers of the 8 ranks (fx_comm_ledger, what bench.py --gpus N cross-checks before it prints its line): same
+    # operation count and sequence everywhere, every message sent is a message received, 7 neighbours each
+    from bench import check_ledgers
+    for res in (ser, ovl):
+        chk = check_ledgers([r["led"] for r in res])
+        assert chk["errors"] == [], chk["errors"][:4]
+        assert all(len(r["led"]["peers"]) == 7 for r in res) and chk["halo_exchanges"] > 0
+    it, n_ar = int(ovl[0]["it"]), ovl[0]["led"]["allreduces"]
+    if form == "eisenstat":      # ||r||^2 and the next rho share one 2-double all-reduce: 2 per iteration + the few of begin / every 50th / the end
+        assert n_ar <= 2 * it + 12 and ovl[0]["led"]["allreduce_bytes"] == 16 * n_ar, (n_ar, it)
+    elif form == "standard":     # rho, p.q, ||r||^2: hecmw_solve_CG's three (hecmw_solver_CG.f90:168, :211, :240)
+        assert 3 * it <= n_ar <= 3 * it + 12, (n_ar, it)
     sref = serial_reference(oracle, (2, 2, 2), m, meth, pc)
     if pc == 3:
         check_against_serial(ovl, sref, meth)
