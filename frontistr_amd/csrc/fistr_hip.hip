@@ -2748,5 +2748,6 @@ extern "C" int fx_get_ssor_ordering(fx_context *c, int32_t *perm, int32_t *color
 }
 
 #include "fx_assemble_host.h"
+#include "fx_update_linear.h"
 #include "fx_nonlinear_host.h"
 #include "fx_debug_host.h"

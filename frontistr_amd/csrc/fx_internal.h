@@ -180,6 +180,11 @@ struct NlDev {
   double maxres = 1.0e10;  // step_ctrl%maxres (m_step.f90:78): Newton gives up when rres exceeds it
   bool is_linear = false;   // fstr_Newton's isLinear: one pass, no convergence test
   int latch = 0;  // MatlMatrix's saved `flag` (calMatMatrix.f90:39): set by the first elastoplastic stress update
+  // fstr_cutback_save / _load (fstr_Cutback.f90:108-198): a device-side copy of the quadrature-point history to roll back to when a
+  // sub-step of an automatic incrementation does not converge (fx_nl_snapshot); allocated at the first save
+  double *bk_stress = nullptr, *bk_strain = nullptr, *bk_stress_bak = nullptr, *bk_strain_bak = nullptr, *bk_plstrain = nullptr, *bk_fstat = nullptr;
+  int32_t *bk_istat = nullptr;
+  bool bk_valid = false;
 };
 
 // TIMELOG (hecmw_solver_Iterative.f90:192-208): device time of the three phases the reference reports -- solver/matvec

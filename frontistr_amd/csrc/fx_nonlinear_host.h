@@ -11,6 +11,8 @@ static void nl_free(fx_context *c) {
   dev_free(n.bc_flag); dev_free(n.bc_val); dev_free(n.bc_node); dev_free(n.bc_dof); dev_free(n.bc_v); dev_free(n.err);
   dev_free(n.colors.order); dev_free(n.colors.pos);
   dev_free(n.mats); dev_free(n.emat);
+  dev_free(n.bk_stress); dev_free(n.bk_strain); dev_free(n.bk_stress_bak); dev_free(n.bk_strain_bak);
+  dev_free(n.bk_plstrain); dev_free(n.bk_fstat); dev_free(n.bk_istat);
   for (double *t : n.tabs) { double *q = t; dev_free(q); }
   n = NlDev();
 }
@@ -366,6 +368,34 @@ extern "C" int fx_nl_commit(fx_context *c) {
                      n.strain, n.stress_bak, n.strain_bak, (const NlMat *)n.mats, (const int32_t *)n.emat);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// fstr_cutback_save (load = 0) / fstr_cutback_load (load = 1), fstr_Cutback.f90:108-198, for the state that lives on the device:
+// the quadrature-point history (fstr_copy_gauss of every point: strain, stress, their _bak copies, plstrain, istatus, fstatus).
+// unode and QFORCE are the host's (the *_at entry points take them from fstrSOLID at every call) and are restored there by the
+// reference's own routine; MatlMatrix's saved flag (`latch`) is process state the reference does not roll back either.
+extern "C" int fx_nl_snapshot(fx_context *c, int load) {
+  NL_READY("fx_nl_snapshot");
+  NlDev &n = c->nl;
+  const size_t npt = (size_t)8 * n.n_elem;
+  if (!n.bk_stress) {
+    if (load) { g_fx_error = "fx_nl_snapshot: nothing was saved"; return FX_ERROR_RUNTIME; }
+    if (dev_alloc(&n.bk_stress, 6 * npt) || dev_alloc(&n.bk_strain, 6 * npt) || dev_alloc(&n.bk_stress_bak, 6 * npt) ||
+        dev_alloc(&n.bk_strain_bak, 6 * npt) || dev_alloc(&n.bk_plstrain, npt) || dev_alloc(&n.bk_fstat, npt) || dev_alloc(&n.bk_istat, npt))
+      return FX_ERROR_RUNTIME;
+  }
+  if (load && !n.bk_valid) { g_fx_error = "fx_nl_snapshot: nothing was saved"; return FX_ERROR_RUNTIME; }
+  struct { void *live; void *bk; size_t bytes; } f[] = {
+      {n.stress, n.bk_stress, 6 * npt * 8}, {n.strain, n.bk_strain, 6 * npt * 8}, {n.stress_bak, n.bk_stress_bak, 6 * npt * 8},
+      {n.strain_bak, n.bk_strain_bak, 6 * npt * 8}, {n.plstrain, n.bk_plstrain, npt * 8}, {n.fstat, n.bk_fstat, npt * 8},
+      {n.istat, n.bk_istat, npt * 4}};
+  for (auto &e : f) {
+    if (load) HIP_TRY(hipMemcpyAsync(e.live, e.bk, e.bytes, hipMemcpyDeviceToDevice, c->stream));
+    else HIP_TRY(hipMemcpyAsync(e.bk, e.live, e.bytes, hipMemcpyDeviceToDevice, c->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  n.bk_valid = true;
   return 0;
 }
 

@@ -9,6 +9,7 @@
     fstr_UpdateNewton    fistr1/src/analysis/static/fstr_Update.f90:25
     fstr_Update_NDForce  fistr1/src/analysis/static/fstr_Residual.f90:23
     fstr_UpdateState     fistr1/src/analysis/static/fstr_Update.f90:296
+    fstr_cutback_save / _load  fistr1/src/analysis/static/fstr_Cutback.f90:108-198
     fstr_Newton          fistr1/src/analysis/static/fstr_solve_NonLinear.f90:29
     fstr_solve_NLGEOM    fistr1/src/analysis/static/fstr_solve_NLGEOM.f90:32 (sub-step loop, linear load ramp)
 
@@ -142,6 +143,16 @@ def fstr_UpdateNewton(fstrSOLID):
 
 def fstr_UpdateState(fstrSOLID):
     _chk(lib().fx_nl_commit(fstrSOLID.ctx.h))
+
+
+def fstr_cutback_save(fstrSOLID):
+    """fstr_Cutback.f90:108-152 for the device-resident quadrature-point history."""
+    _chk(lib().fx_nl_snapshot(fstrSOLID.ctx.h, 0))
+
+
+def fstr_cutback_load(fstrSOLID):
+    """fstr_Cutback.f90:155-198: back to the state of the last fstr_cutback_save."""
+    _chk(lib().fx_nl_snapshot(fstrSOLID.ctx.h, 1))
 
 
 def fstr_Newton(fstrSOLID, hecMAT, factor, bc, cload, max_iter, converg, commit_unconverged=False):

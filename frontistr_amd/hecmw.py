@@ -337,6 +337,27 @@ class SolverContext:
                                     int(bn.size), _ptr(bn), _ptr(bd), _ptr(bv), C.byref(ms)))
         return ms.value
 
+    def update_c3d8_linear(self, coord, conn, E, nu, disp, elemopt=1, elem_mat=None):
+        """fstr_UpdateNewton of a linear static analysis on the device (fx_update_c3d8_linear): strain, stress (n_elem, 8, 6) at the
+        quadrature points and QFORCE (3 * n_node) from the total displacement; E, nu scalars or per-material arrays with
+        elem_mat (1-based).  Returns (strain, stress, qforce, kernel ms)."""
+        coord = np.ascontiguousarray(coord, dtype=np.float64)
+        conn = np.ascontiguousarray(conn, dtype=np.int32)
+        disp = np.ascontiguousarray(disp, dtype=np.float64)
+        Es = np.atleast_1d(np.asarray(E, dtype=np.float64)).copy()
+        nus = np.atleast_1d(np.asarray(nu, dtype=np.float64)).copy()
+        em = None if elem_mat is None else np.ascontiguousarray(elem_mat, dtype=np.int32)
+        mv = _MeshView(coord.shape[0], conn.shape[0], _ptr(coord), _ptr(conn))
+        ps, pt = C.POINTER(C.c_double)(), C.POINTER(C.c_double)()
+        qf = np.zeros(3 * coord.shape[0])
+        ms = C.c_float(0)
+        _chk(lib().fx_update_c3d8_linear(self.h, C.byref(mv), int(Es.size), _ptr(Es), _ptr(nus), _ptr(em), int(elemopt), _ptr(disp),
+                                         C.byref(ps), C.byref(pt), _ptr(qf), C.byref(ms)))
+        n = 48 * conn.shape[0]
+        strain = np.ctypeslib.as_array(ps, shape=(n,)).reshape(-1, 8, 6).copy()      # the library's pinned staging: copy out
+        stress = np.ctypeslib.as_array(pt, shape=(n,)).reshape(-1, 8, 6).copy()
+        return strain, stress, qf, ms.value
+
     def element_stiffness(self, elemopt, ecoord, E, nu):
         ec = np.ascontiguousarray(ecoord, dtype=np.float64).reshape(8, 3)
         k = np.zeros((24, 24))

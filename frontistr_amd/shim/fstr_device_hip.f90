@@ -21,11 +21,12 @@ module fstr_device_hip
   use hecmw_hip_binding
   implicit none
   private
-  public :: fsd_stiffness, fsd_update_newton, fsd_update_state, fsd_active, fsd_report
+  public :: fsd_stiffness, fsd_update_newton, fsd_update_state, fsd_active, fsd_report, fsd_cutback
 
   logical, save :: decided = .false., eligible = .false., ready = .false.
-  ! linear static decks: the stiffness loop only (the tangent is constant, the stress update stays the reference's)
+  ! linear static decks: the stiffness loop (fx_assemble_c3d8_sections) and the stress update (fx_update_c3d8_linear)
   logical, save :: lin_decided = .false., lin_eligible = .false., lin_ready = .false.
+  type(c_ptr), save :: the_ctx_saved = c_null_ptr
   integer(c_int), save :: lin_elemopt = 0
   real(c_double), allocatable, target, save :: lin_E(:), lin_nu(:)
   integer(c_int32_t), allocatable, target, save :: lin_emat(:)
@@ -85,10 +86,9 @@ contains
       if (size(fstrSOLID%contacts) > 0) return
     endif
     if (fstrSOLID%n_fix_mpc > 0) return
-    do i = 1, fstrSOLID%nstep_tot          ! automatic incrementation rolls the host state back (fstr_Cutback.f90): not mirrored on the device
-      if (fstrSOLID%step_ctrl(i)%inc_type /= stepFixedInc) return
-    enddo
-    if (fstrSOLID%restart_nout < 0) return       ! a run continued from a restart file keeps the host loops
+    ! (automatic incrementation, `!AUTOINC_PARAM`: fstr_cutback_save / _load roll the device's copy of the history back with the
+    !  host's, shim/fstr_Cutback_hip.f90 -> fsd_cutback.  A run continued from a restart file: the history read from the file is what
+    !  fsd_init pushes to the device at the first fstr_StiffMatrix, after fstr_read_restart, fstr_solve_NLGEOM.f90:70-76.)
     do i = 1, hecMESH%section%n_sect
       if (fstrSOLID%sections(i)%elemopt361 /= kel361BBAR) return
       if (hecMESH%section%sect_orien_ID(i) > 0) return
@@ -286,7 +286,25 @@ contains
     allocate(b6(6, 8, n_elem), b6b(6, 8, n_elem), b1(8, n_elem), bi(8, n_elem))
     call fsd_push_state(ctx, fstrSOLID)
     ready = .true.
+    the_ctx_saved = ctx
+    if (fstr_cutback_is_on(fstrSOLID)) then    ! the state fstr_solve_NLGEOM.f90:84 saved on the host before the device had any
+      ierr = fx_nl_snapshot(ctx, 0_c_int)
+      if (ierr /= 0) call fsd_fail('fx_nl_snapshot')
+    endif
   end subroutine fsd_init
+
+  type(c_ptr) function the_device_ctx()
+    the_device_ctx = the_ctx_saved
+  end function the_device_ctx
+
+  logical function fstr_cutback_is_on(fstrSOLID)       ! is_cutback_active of fstr_Cutback.f90:32-34
+    type(fstr_solid), intent(in) :: fstrSOLID
+    integer :: i
+    fstr_cutback_is_on = .false.
+    do i = 1, fstrSOLID%nstep_tot
+      if (fstrSOLID%step_ctrl(i)%inc_type == stepAutoInc) fstr_cutback_is_on = .true.
+    enddo
+  end function fstr_cutback_is_on
 
   subroutine fsd_fail(what)
     character(len=*), intent(in) :: what
@@ -360,12 +378,67 @@ contains
     integer(c_int) :: ierr
     real(c_float) :: ms
     fsd_update_newton = .false.
-    if (.not. ready) return
+    if (.not. ready) then
+      if (lin_ready) fsd_update_newton = fsd_update_newton_linear(hecMESH, fstrSOLID)
+      return
+    endif
     ierr = fx_nl_update_at(fxb_context(hecMESH), fstrSOLID%dunode, fstrSOLID%QFORCE, ms)
     if (ierr /= 0) call fsd_fail('fx_nl_update_at')
     call hecmw_update_3_R(hecMESH, fstrSOLID%QFORCE, hecMESH%n_node)
     fsd_update_newton = .true.
   end function fsd_update_newton
+
+  !> fstr_cutback_save (load = 0) / fstr_cutback_load (load = 1) for the device's copy of the quadrature-point history.  Before the
+  !> first fstr_StiffMatrix (fstr_solve_NLGEOM.f90:84 saves the initial state) there is nothing on the device yet: fsd_init will
+  !> push the host's state, which is that very state, and takes the first snapshot itself.
+  subroutine fsd_cutback(load)
+    integer, intent(in) :: load
+    integer(c_int) :: ierr
+    if (.not. ready) return
+    ierr = fx_nl_snapshot(the_device_ctx(), int(load, c_int))
+    if (ierr /= 0) call fsd_fail('fx_nl_snapshot')
+  end subroutine fsd_cutback
+
+  !> fstr_UpdateNewton of a linear static deck (fsd_eligible_linear: TYPE=361, isotropic ELASTIC, the formulation of `ELEMOPT361`):
+  !> UpdateST_C3D8IC / Update_C3D8Bbar / UPDATE_C3 for every element on the device from the total displacement unode + dunode
+  !> (fstr_Update.f90:165 for IC; static_LIB_3d.f90:556 / static_LIB_C3D8.f90:258 for the others); strain and stress come back through
+  !> the library's pinned staging into fstrSOLID%elements(:)%gausses(:), QFORCE into fstrSOLID%QFORCE, then the caller-side halo update
+  !> of fstr_Update.f90:284.  HECMW_GPU_UPDATE=0 keeps the reference's element loop.
+  logical function fsd_update_newton_linear(hecMESH, fstrSOLID)
+    type(hecmwST_local_mesh), intent(in), target :: hecMESH
+    type(fstr_solid), intent(inout), target :: fstrSOLID
+    integer(c_int) :: ierr
+    real(c_float) :: ms
+    type(fx_mesh_view) :: mesh
+    type(c_ptr) :: ps, pt
+    real(c_double), pointer :: s6(:,:,:), t6(:,:,:)
+    real(c_double), allocatable :: tot(:)
+    character(len=8) :: env
+    integer :: elen, estat, icel, g
+    fsd_update_newton_linear = .false.
+    call get_environment_variable('HECMW_GPU_UPDATE', env, elen, estat)
+    if (estat == 0 .and. elen > 0 .and. env(1:1) == '0') return
+    allocate(tot(3*hecMESH%n_node))
+    tot(:) = fstrSOLID%unode(1:3*hecMESH%n_node) + fstrSOLID%dunode(1:3*hecMESH%n_node)
+    mesh%n_node = hecMESH%n_node; mesh%n_elem = hecMESH%n_elem
+    mesh%coord = c_loc(hecMESH%node(1)); mesh%conn = c_loc(hecMESH%elem_node_item(1))
+    ierr = fx_update_c3d8_linear(fxb_context(hecMESH), mesh, int(size(lin_E), c_int32_t), lin_E, lin_nu, lin_emat, lin_elemopt, tot, &
+                                 ps, pt, fstrSOLID%QFORCE, ms)
+    if (ierr /= 0) call fsd_fail('fx_update_c3d8_linear')
+    deallocate(tot)
+    call c_f_pointer(ps, s6, [6, 8, hecMESH%n_elem])
+    call c_f_pointer(pt, t6, [6, 8, hecMESH%n_elem])
+    !$omp parallel do default(shared) private(icel, g)
+    do icel = 1, hecMESH%n_elem
+      do g = 1, 8
+        fstrSOLID%elements(icel)%gausses(g)%strain(1:6) = s6(1:6, g, icel)
+        fstrSOLID%elements(icel)%gausses(g)%stress(1:6) = t6(1:6, g, icel)
+      enddo
+    enddo
+    !$omp end parallel do
+    call hecmw_update_3_R(hecMESH, fstrSOLID%QFORCE, hecMESH%n_node)
+    fsd_update_newton_linear = .true.
+  end function fsd_update_newton_linear
 
   !> fstr_UpdateState on the device, then the history comes back to fstrSOLID%elements (results, restart files and whatever else
   !> of fistr1 reads it) -- once per sub-step, not per Newton iteration.

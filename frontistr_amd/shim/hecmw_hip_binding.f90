@@ -22,7 +22,7 @@ module hecmw_hip_binding
   ! device-side assembly / stress update driven by fistr1's own fstr_Newton (INTEGRATION.md section 5)
   public :: fx_mesh_view, fx_material_view, fx_nl_state_view
   public :: fx_upload, fx_solve_device_matrix, fx_nl_init_sections, fx_nl_stiffness_at, fx_nl_update_at, fx_nl_commit, fx_nl_get_state, &
-            fx_nl_set_state, fx_assemble_c3d8_sections
+            fx_nl_set_state, fx_assemble_c3d8_sections, fx_update_c3d8_linear, fx_nl_snapshot
   public :: fxb_values_owner, fxb_values_addr
   public :: fxb_matrix_on_device, fxb_defer_bc, fxb_solve_device_matrix, FX_UP_PROFILE
   public :: fxb_context, fxb_views, fxb_ensure_transport, fxb_error_text, fxb_on_gpu_path, fx_get_stats
@@ -115,6 +115,20 @@ module hecmw_hip_binding
       type(c_ptr), value :: bc_node, bc_dof, bc_val
       real(c_float) :: ms
     end function fx_assemble_c3d8_sections
+    integer(c_int) function fx_update_c3d8_linear(ctx, mesh, n_mat, E, nu, elem_mat, elemopt, disp, strain, stress, qforce, ms) &
+        bind(C, name='fx_update_c3d8_linear')
+      import :: c_ptr, c_int, c_int32_t, c_double, c_float, fx_mesh_view
+      type(c_ptr), value :: ctx
+      type(fx_mesh_view), intent(in) :: mesh
+      integer(c_int32_t), value :: n_mat
+      real(c_double), intent(in) :: E(*), nu(*)
+      integer(c_int32_t), intent(in) :: elem_mat(*)
+      integer(c_int), value :: elemopt
+      real(c_double), intent(in) :: disp(*)
+      type(c_ptr), intent(out) :: strain, stress          ! pinned host arrays of the library: (6, 8, n_elem)
+      real(c_double), intent(inout) :: qforce(*)
+      real(c_float), intent(out) :: ms
+    end function fx_update_c3d8_linear
     integer(c_int) function fx_nl_init_sections(ctx, mesh, n_mat, mats, elem_mat) bind(C, name='fx_nl_init_sections')
       import :: c_int, c_ptr, c_int32_t, fx_mesh_view, fx_material_view
       type(c_ptr), value :: ctx
@@ -139,6 +153,11 @@ module hecmw_hip_binding
       import :: c_int, c_ptr
       type(c_ptr), value :: ctx
     end function fx_nl_commit
+    integer(c_int) function fx_nl_snapshot(ctx, load) bind(C, name='fx_nl_snapshot')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: load
+    end function fx_nl_snapshot
     integer(c_int) function fx_nl_get_state(ctx, s) bind(C, name='fx_nl_get_state')
       import :: c_int, c_ptr, fx_nl_state_view
       type(c_ptr), value :: ctx

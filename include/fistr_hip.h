@@ -213,6 +213,15 @@ int fx_assemble_c3d8_sections(fx_context *ctx, const fx_mesh_view *mesh, int32_t
                               const double *nu, const int32_t *elem_mat, int elemopt, const double *load,
                               int32_t n_bc, const int32_t *bc_node, const int32_t *bc_dof,
                               const double *bc_val, float *ms_assemble);
+/* fstr_UpdateNewton of a LINEAR static analysis (`!SOLUTION, TYPE=STATIC`; fistr1/src/analysis/static/fstr_Update.f90:25-293) for
+ * one TYPE=361 group of isotropic ELASTIC materials: UpdateST_C3D8IC (static_LIB_3dIC.f90:220-455, elemopt 1), Update_C3D8Bbar
+ * (static_LIB_C3D8.f90:203-547, elemopt 2) or UPDATE_C3 (static_LIB_3d.f90:516-837, elemopt 3) per element, small strain.
+ * disp = total displacement unode + dunode (3*n_node).  *strain, *stress: pinned host arrays OWNED BY THE LIBRARY, valid until the
+ * next call, [n_elem][8][6] = gausses(1:8)%strain(1:6) / %stress(1:6) of every element; qforce (3*n_node, caller's, may be NULL) =
+ * fstrSOLID%QFORCE before its halo update.  n_mat materials, elem_mat 1-based per element (NULL with one material). */
+int fx_update_c3d8_linear(fx_context *ctx, const fx_mesh_view *mesh, int32_t n_mat, const double *E, const double *nu,
+                          const int32_t *elem_mat, int elemopt, const double *disp, const double **strain,
+                          const double **stress, double *qforce, float *ms_kernel);
 /* One element stiffness through the device kernel (tests): ecoord 8x3, stiff 24x24 row-major. */
 int fx_element_stiffness_c3d8(fx_context *ctx, int elemopt, const double *ecoord, double E, double nu,
                               double *stiff);
@@ -271,6 +280,10 @@ int fx_nl_update_at(fx_context *ctx, const double *dunode, double *qforce, float
 int fx_mat_ass_bc(fx_context *ctx, int32_t n_bc, const int32_t *bc_node, const int32_t *bc_dof, const double *bc_val);
 /* unode += dunode, fstr_UpdateState (fstr_Update.f90:296-345). */
 int fx_nl_commit(fx_context *ctx);
+/* fstr_cutback_save (load = 0) / fstr_cutback_load (load = 1) for the device-resident quadrature-point history
+ * (fistr1/src/analysis/static/fstr_Cutback.f90:108-198: fstr_copy_gauss of every point): an automatic incrementation rolls the
+ * state back to the last converged sub-step when Newton fails (fstr_solve_NLGEOM.f90:156-197).  unode / QFORCE stay with the host. */
+int fx_nl_snapshot(fx_context *ctx, int load);
 int fx_nl_get_state(fx_context *ctx, fx_nl_state_view *s);
 int fx_nl_set_state(fx_context *ctx, const fx_nl_state_view *s);
 /* element-level outputs of the two kernels, no scatter (tests): ke n_elem*24*24, qf n_elem*24 */

@@ -322,6 +322,11 @@ def fistr1_overrides(shimdir, gen):
     over["m_fstr_update_ref"] = patched("fistr1/src/analysis/static/fstr_Update.f90",
                                         [("\nmodule m_fstr_Update\n", "\nmodule m_fstr_Update_ref\n"),
                                          ("end module m_fstr_Update", "end module m_fstr_Update_ref")], "fstr_Update_ref.f90")
+    if os.path.exists(os.path.join(shimdir, "fstr_Cutback_hip.f90")):
+        over["m_fstr_cutback_ref"] = patched("fistr1/src/analysis/static/fstr_Cutback.f90",
+                                             [("\nmodule m_fstr_Cutback\n", "\nmodule m_fstr_Cutback_ref\n"),
+                                              ("end module m_fstr_Cutback", "end module m_fstr_Cutback_ref")], "fstr_Cutback_ref.f90")
+        over["m_fstr_cutback"] = os.path.join(shimdir, "fstr_Cutback_hip.f90")
     over["hecmw_matrix_ass"] = patched("hecmw1/src/solver/matrix/hecmw_mat_ass.f90",
                                        [("\nmodule hecmw_matrix_ass\n  use hecmw_util\n", "\nmodule hecmw_matrix_ass\n  use hecmw_util\n  use hecmw_hip_binding, only: fxb_defer_bc\n"),
                                         # the hook sits AFTER `hecMAT%B(row) = RHS`: fstr_AddBC (fstr_AddBC.f90:124) reads hecMAT%B at the rotation-centre
@@ -359,7 +364,7 @@ def build_partitioner(jobs):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--jobs", type=int, default=4)
-    ap.add_argument("--only", choices=["solve", "fem", "nl", "load", "shim", "part", "fistr1"], default=None)
+    ap.add_argument("--only", choices=["solve", "fem", "nl", "load", "update", "shim", "part", "fistr1"], default=None)
     a = ap.parse_args()
     if not os.path.isdir(REF):
         print(f"reference not present at {REF}; oracle/_ref left as is")
@@ -388,6 +393,10 @@ def main():
     ld = os.path.join(HERE, "ref_load_driver.f90")
     if a.only in (None, "load") and os.path.exists(ld):
         build_variant("fem", [ld], False, a.jobs, provides, uses, exe_name="ref_load")
+    # Stress update of linear static decks: UpdateST_C3D8IC / Update_C3D8Bbar / UPDATE_C3 element by element (ref_update_driver.f90)
+    upd = os.path.join(HERE, "ref_update_driver.f90")
+    if a.only in (None, "update") and os.path.exists(upd):
+        build_variant("fem", [upd], False, a.jobs, provides, uses, exe_name="ref_update")
     # The reference partitioner (hecmw1/tools/partitioner, plain C): fixture generator for the
     # HECMW-DIST reader and the multi-rank tests (METHOD=RCB; METIS is absent in this image).
     if a.only in (None, "part"):

@@ -167,3 +167,30 @@ def read_sta(path):
             if m:
                 rows.append((int(m.group(1)), int(m.group(2)), m.group(3), int(m.group(6)), m.group(7).strip()))
     return rows
+
+
+STEP_LINE = re.compile(r"sub_step=|time increment is|State has been restored|Fail to Converge|Number of substeps reached|^\s*iter:\s")
+
+
+def step_lines(stdout):
+    """The lines of fistr1's stdout that describe the incrementation: sub-step headers (time, increment), increment changes,
+    cutbacks ('State has been restored'), Newton iterations ('iter: k, residual: r, disp.corr.: d')."""
+    return [l.rstrip() for l in stdout.split("\n") if STEP_LINE.search(l)]
+
+
+def compare_step_lines(got, want, rtol=1e-3, floor=1e-9):
+    """Same sequence of lines; numbers within rtol (or below `floor` on both sides: converged residuals are rounding noise)."""
+    bad = []
+    if len(got) != len(want):
+        return [("count", len(got), len(want))]
+    num = re.compile(r"[-+]?\d+\.\d+(?:E[-+]\d+)?|[-+]?\d+")
+    for a, b in zip(got, want):
+        if num.sub("#", a).split() != num.sub("#", b).split():
+            bad.append((a, b))
+            continue
+        for x, y in zip(num.findall(a), num.findall(b)):
+            fx, fy = float(x), float(y)
+            if abs(fx - fy) > rtol * max(abs(fx), abs(fy)) and max(abs(fx), abs(fy)) > floor:
+                bad.append((a, b))
+                break
+    return bad

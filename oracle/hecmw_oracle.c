@@ -1292,4 +1292,5 @@ void orc_assemble_c3d8(int elemopt, int32_t NP, int32_t n_elem, const double *co
   }
 }
 
+#include "fstr_update_linear_oracle.c" /* stress update of linear static decks (same translation unit: shares the element helpers) */
 #include "fstr_nl_oracle.c" /* nonlinear C3D8 B-bar path (same translation unit: shares the element helpers) */

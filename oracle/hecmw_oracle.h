@@ -117,6 +117,14 @@ void orc_assemble_c3d8_sections(int elemopt, int32_t NP, int32_t n_elem, const d
                                 const int32_t *itemL, const int32_t *indexU, const int32_t *itemU, double *D,
                                 double *AL, double *AU);
 
+/* ---- stress update of a linear static analysis (fstr_UpdateNewton with UpdateST_C3D8IC / Update_C3D8Bbar / UPDATE_C3, ELASTIC,
+ *      INFINITE): restated in fstr_update_linear_oracle.c ---- */
+void orc_update_c3d8_linear(int elemopt, const double *ecoord, const double *edisp, double E, double nu, double *strain,
+                            double *stress, double *qf);
+void orc_update_linear(int elemopt, int32_t n_node, int32_t n_elem, const double *coord, const int32_t *conn, const double *E,
+                       const double *nu, const int32_t *elem_mat, const double *disp, double *strain, double *stress,
+                       double *qforce);
+
 /* ---- Nonlinear (elastoplastic) C3D8 B-bar path: restated in fstr_nl_oracle.c ---- */
 typedef struct {
   double E, nu;

@@ -220,6 +220,22 @@ def assemble(elemopt, coord, conn, E, nu, bc=None, load=None, sections=None):
     return BSR(NP, NP, indexL, itemL, indexU, itemU, D, AL[:9 * itemL.size], AU[:9 * itemU.size], B)
 
 
+def update_linear(elemopt, coord, conn, E, nu, disp, elem_mat=None):
+    """fstr_UpdateNewton of a linear static analysis (orc_update_linear): strain / stress (n_elem, 8, 6) and QFORCE (3 * n_node)
+    from the total displacement.  E, nu: scalars or per-material arrays with elem_mat (1-based)."""
+    coord = np.ascontiguousarray(coord, dtype=np.float64)
+    conn = np.ascontiguousarray(conn, dtype=np.int32)
+    disp = np.ascontiguousarray(disp, dtype=np.float64)
+    Es = np.atleast_1d(np.asarray(E, dtype=np.float64)).copy()
+    nus = np.atleast_1d(np.asarray(nu, dtype=np.float64)).copy()
+    em = None if elem_mat is None else np.ascontiguousarray(elem_mat, dtype=np.int32)
+    ne, nn = conn.shape[0], coord.shape[0]
+    strain, stress, qf = np.zeros((ne, 8, 6)), np.zeros((ne, 8, 6)), np.zeros(3 * nn)
+    lib().orc_update_linear(int(elemopt), nn, ne, _dp(coord), _ip(conn), _dp(Es), _dp(nus), None if em is None else _ip(em),
+                            _dp(disp), _dp(strain), _dp(stress), _dp(qf))
+    return strain, stress, qf
+
+
 # ---------------------------------------------------------------- nonlinear (elastoplastic) path
 class _Material(C.Structure):
     _fields_ = [("E", C.c_double), ("nu", C.c_double), ("plastic", C.c_int32), ("harden", C.c_int32),

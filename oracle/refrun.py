@@ -205,6 +205,40 @@ def run_fem(coord, conn, E, nu, bc_node, bc_dof, bc_val, B0, elemopt=1, workdir=
     return BSR(N, NP, indexL, itemL, indexU, itemU, D, AL, AU, B), ke, t
 
 
+MAGIC_UPD = 1179210064
+
+
+def run_update(elemopt, coord, conn, E, nu, unode, dunode, elem_mat=None, workdir=None):
+    """Reference stress update of a linear static analysis, element by element (oracle/ref_update_driver.f90):
+    -> strain, stress (n_elem, 8, 6), qforce (3 * n_node)."""
+    exe = os.path.join(REFDIR, "ref_update")
+    if not os.path.exists(exe):
+        raise FileNotFoundError(exe)
+    coord = np.ascontiguousarray(coord, dtype=np.float64)
+    conn = np.ascontiguousarray(conn, dtype=np.int32)
+    Es = np.atleast_1d(np.asarray(E, dtype=np.float64))
+    nus = np.atleast_1d(np.asarray(nu, dtype=np.float64))
+    ne, nn = conn.shape[0], coord.shape[0]
+    em = np.ones(ne, dtype=np.int32) if elem_mat is None else np.ascontiguousarray(elem_mat, dtype=np.int32)
+    with tempfile.TemporaryDirectory(dir=workdir) as td:
+        fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        with open(fin, "wb") as f:
+            np.array([MAGIC_UPD, elemopt, nn, ne, Es.size], dtype=np.int32).tofile(f)
+            Es.tofile(f); nus.tofile(f); em.tofile(f)
+            coord.tofile(f); conn.tofile(f)
+            np.ascontiguousarray(unode, dtype=np.float64).tofile(f)
+            np.ascontiguousarray(dunode, dtype=np.float64).tofile(f)
+        p = subprocess.run([exe, fin, fout], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                           env=dict(os.environ, OMP_NUM_THREADS="1"))
+        if p.returncode != 0 or not os.path.exists(fout):
+            raise RuntimeError("ref_update failed: " + p.stdout)
+        with open(fout, "rb") as f:
+            strain = np.fromfile(f, dtype=np.float64, count=48 * ne).reshape(ne, 8, 6)
+            stress = np.fromfile(f, dtype=np.float64, count=48 * ne).reshape(ne, 8, 6)
+            qf = np.fromfile(f, dtype=np.float64, count=3 * nn)
+    return strain, stress, qf
+
+
 MAGIC_NL = 1179209292
 
 

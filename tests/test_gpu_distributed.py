@@ -489,10 +489,13 @@ def test_bench_decomposition_2x2x2_eight_contexts(oracle, meth, pc, form):
         assert chk["errors"] == [], chk["errors"][:4]
         assert all(len(r["led"]["peers"]) == 7 for r in res) and chk["halo_exchanges"] > 0
     it, n_ar = int(ovl[0]["it"]), ovl[0]["led"]["allreduces"]
-    if form == "eisenstat":      # ||r||^2 and the next rho share one 2-double all-reduce: 2 per iteration + the few of begin / every 50th / the end
-        assert n_ar <= 2 * it + 12 and ovl[0]["led"]["allreduce_bytes"] == 16 * n_ar, (n_ar, it)
-    elif form == "standard":     # rho, p.q, ||r||^2: hecmw_solve_CG's three (hecmw_solver_CG.f90:168, :211, :240)
-        assert 3 * it <= n_ar <= 3 * it + 12, (n_ar, it)
+    # per iteration: Eisenstat's form 2 (p.q; ||r||^2 together with the next rho in one 2-double all-reduce), hecmw_solve_CG's loop
+    # its three (rho :168, p.q :211, ||r||^2 :240); on top of that the few of hecmw_solve_iterative's checks, ||b||, the iterations
+    # that recompute the true residual, the true-residual check at convergence and the final relative residual
+    if form == "eisenstat":
+        assert 2 * it <= n_ar <= 2 * it + 30 and 16 * (n_ar - 4) <= ovl[0]["led"]["allreduce_bytes"] <= 16 * n_ar, (n_ar, it)   # 2 doubles each (a few single sums at the ends)
+    elif form == "standard":
+        assert 3 * it <= n_ar <= 3 * it + 30, (n_ar, it)
     sref = serial_reference(oracle, (2, 2, 2), m, meth, pc)
     if pc == 3:
         check_against_serial(ovl, sref, meth)

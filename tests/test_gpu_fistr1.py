@@ -71,7 +71,8 @@ def test_fistr1_exA_A361_on_the_gpu(method, precond, banner, iters, form):
     r = _run("exA", "A361.msh", "A300.cnt", env=_form_env(form), **kw)
     assert banner in r["stdout"], r["stdout"][:3000]
     _assert_form(r, form, 1)
-    assert DEVICE_ASSEMBLY not in r["stdout"] and LINEAR_DEVICE_ASSEMBLY in r["stdout"]   # linear STATIC, incompatible-mode element: the stiffness loop on the device, the stress update the reference's
+    assert DEVICE_ASSEMBLY not in r["stdout"] and LINEAR_DEVICE_ASSEMBLY in r["stdout"]   # linear STATIC, incompatible-mode element: the stiffness loop on the device ...
+    assert "fstr_UpdateNewton on the device" in r["stdout"] and "fstr_UpdateNewton on the host" not in r["stdout"]   # ... and the stress update (UpdateST_C3D8IC): the strain / stress extrema below come from it
     correct = f1.read_log(os.path.join(f1.DECKS, "exA", "A361_correct.log"))
     assert len(r["log"]) == 2 and f1.compare_step(r["log"][-1], correct[-1]) == []
     assert "### Relative residual =" in r["stdout"] and "### summary of linear solver" in r["stdout"]
@@ -243,6 +244,7 @@ def test_fistr1_linear_static_stiffness_on_the_device(form361, tmp_path):
         assert r["returncode"] == 0 and "FrontISTR Completed !!" in r["stdout"], r["stdout"][-2000:]
         assert (LINEAR_DEVICE_ASSEMBLY in r["stdout"]) == (mode == "device")
         assert ("fstr_StiffMatrix on the device" in r["stdout"]) == (mode == "device")
+        assert ("fstr_UpdateNewton on the device" in r["stdout"]) == (mode == "device")      # UpdateST_C3D8IC / Update_C3D8Bbar / UPDATE_C3 of the same formulation
         assert "### libfistr_hip: solved on the device: NDOF=3 METHOD=1 PRECOND=1" in r["stdout"]
         runs[mode] = r
     a, b = runs["device"]["log"][-1], runs["host"]["log"][-1]
@@ -251,3 +253,32 @@ def test_fistr1_linear_static_stiffness_on_the_device(form361, tmp_path):
     if f1.have("fistr1_ref"):
         ref = f1.run("fistr1_ref", d, threads=2)
         assert f1.compare_step(a, ref["log"][-1]) == []
+
+
+@pytest.mark.parametrize("assembly", ["device", "host"])
+@pytest.mark.parametrize("deck,mesh,cnt,cutbacks", [("autoinc", "C3D8beam.msh", "C3D8beam.cnt", 3),
+                                                   ("t05_autoinc", "necking.msh", "necking_autoinc.cnt", 7)])
+def test_fistr1_autoinc_cutback_on_the_gpu(deck, mesh, cnt, cutbacks, assembly):
+    """Automatic incrementation with cutback (fstr_solve_NLGEOM.f90:85-242, fstr_Cutback.f90:108-198) through fistr1_hip with the
+    element loops on the device: when Newton runs into MAXITER the reference rolls its state back (fstr_cutback_load) and cuts the
+    increment; the device's copy of the quadrature-point history is rolled back with it (fx_nl_snapshot via the
+    m_fstr_Cutback binding).  examples/static/autoinc (the reference's own deck: three cutbacks at the first sub-step) and
+    tutorial-05 with an `!AUTOINC_PARAM` card (configs[4]'s deck: seven cutbacks in a row at t = 0.25, then the run goes on).
+    Same sub-step sequence -- status, Newton iterations, start time, increment of every FSTR.sta row --, same residual / increment
+    lines on stdout (3 digits) and the same 0.log extrema as the unmodified program (make_autoinc_golden.py); `host`: the same
+    deck with HECMW_GPU_ASSEMBLY=0."""
+    r = _run(deck, mesh, cnt, env={"HECMW_GPU_REPORT": "1"} if assembly == "device" else {"HECMW_GPU_REPORT": "1", "HECMW_GPU_ASSEMBLY": "0"})
+    assert (DEVICE_ASSEMBLY in r["stdout"]) == (assembly == "device")
+    assert "Number of substeps reached max number" in r["stdout"]                 # both decks end at their SUBSTEPS bound, as in the reference
+    assert r["stdout"].count("State has been restored") == cutbacks
+    stem = cnt[:-4]
+    want_sta = f1.read_sta(os.path.join(f1.DECKS, deck, stem + "_fistr1_ref_FSTR.sta"))
+    assert [(x[0], x[1], x[2], x[3]) for x in r["sta"]] == [(x[0], x[1], x[2], x[3]) for x in want_sta], r["sta"]
+    want_lines = open(os.path.join(f1.DECKS, deck, stem + "_fistr1_ref_steps.txt")).read().split("\n")
+    want_lines = [l for l in want_lines if l.strip()]
+    bad = f1.compare_step_lines(f1.step_lines(r["stdout"]), want_lines, rtol=2e-3, floor=1e-7)
+    assert bad == [], bad[:5]
+    want = f1.read_log(os.path.join(f1.DECKS, deck, stem + "_fistr1_ref_0.log"))
+    assert len(r["log"]) == len(want)
+    for a, c in zip(r["log"], want):
+        assert f1.compare_step(a, c) == []

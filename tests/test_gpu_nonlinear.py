@@ -348,3 +348,46 @@ def test_newton_exits_maxres_and_linear(hip):
     u = solid.get_state(("unode",))["unode"].reshape(-1, 3)
     assert np.abs(u[m.top_nodes - 1] - np.array([0.03, 0.0, 0.15])).max() < 1e-9     # committed: the prescribed top displacement
     ctx.close()
+
+
+@pytest.mark.parametrize("elemopt,tag", [(1, "ic"), (2, "bbar"), (3, "fi")])
+def test_linear_static_stress_update_matches_the_reference(elemopt, tag):
+    """fstr_UpdateNewton of a linear static analysis on the device (fx_update_c3d8_linear: UpdateST_C3D8IC / Update_C3D8Bbar /
+    UPDATE_C3, two materials) against the outputs of the reference's own routines (tests/golden/update_linear.npz): strain and
+    stress at all quadrature points and QFORCE within 1e-11 of the largest entry (the device sums over the quadrature points
+    instead of multiplying the 33x33 element matrix)."""
+    from conftest import load_golden
+    from frontistr_amd import hecmw as hip
+    g = load_golden("update_linear")
+    ctx = hip.SolverContext()
+    s, t, q, ms = ctx.update_c3d8_linear(g["coord"], g["conn"], g["E"], g["nu"], g["unode"] + g["dunode"], elemopt=elemopt, elem_mat=g["elem_mat"])
+    ctx.close()
+    for got, want in ((s, g[tag + "_strain"]), (t, g[tag + "_stress"]), (q, g[tag + "_qforce"])):
+        assert got.shape == want.shape and np.abs(got - want).max() <= 1e-11 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("n,skew", [(1, 0.0), (5, 0.2), (23, 0.05)])
+def test_linear_static_stress_update_vs_oracle_and_stiffness(oracle, n, skew):
+    """Ragged sizes (1, 125 and 12,167 elements: fewer elements than a workgroup holds, a partly filled last workgroup) against the
+    CPU restatement, and -- independent of any reference output -- QFORCE = K u with the matrix the device assembled for the same
+    formulation (fstr_StiffMatrix and fstr_UpdateNewton agree on the element, IC condensation included)."""
+    from frontistr_amd import hecmw as hip
+    from frontistr_amd.mesh import CubeMesh
+    m = CubeMesh(n, skew=skew)
+    u = 1e-3 * np.sin(0.7 * np.arange(3 * m.n_node) + 0.2)
+    hm = hip.hecmwST_local_mesh(n_node=m.n_node)
+    hm.elem_node_item = m.conn.ravel()
+    for elemopt in (1, 2, 3):
+        ctx = hip.SolverContext()
+        s, t, q, ms = ctx.update_c3d8_linear(m.coord, m.conn, 210000.0, 0.3, u, elemopt=elemopt)
+        so, to, qo = oracle.update_linear(elemopt, m.coord, m.conn, 210000.0, 0.3, u)
+        assert np.abs(s - so).max() <= 1e-11 * np.abs(so).max() and np.abs(t - to).max() <= 1e-11 * np.abs(to).max()
+        assert np.abs(q - qo).max() <= 1e-11 * np.abs(qo).max()
+        mat = hip.hecmw_mat_con(hm, hip.hecmwST_matrix())
+        ctx.upload(mat, what=hip.FX_UP_PROFILE)
+        ctx.assemble_c3d8(m.coord, m.conn, 210000.0, 0.3, elemopt=elemopt)
+        ctx.download_matrix(mat)
+        ctx.close()
+        from oracle.refrun import BSR
+        ku = oracle.matvec(BSR(mat.N, mat.NP, mat.indexL, mat.itemL, mat.indexU, mat.itemU, mat.D, mat.AL, mat.AU, np.zeros(3 * mat.NP)), u)
+        assert np.abs(q - ku).max() <= 1e-10 * np.abs(ku).max(), elemopt
