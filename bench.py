@@ -269,7 +269,9 @@ def main():
     t0 = time.time()
     m = hip.hecmw_mat_con(hm, hip.hecmwST_matrix())
     t_con = time.time() - t0               # hecmw_mat_con alone (round 1 also counted context creation and mesh generation here)
+    t0 = time.time()
     ctx.upload(m, hm, what=hip.FX_UP_PROFILE)
+    t_upload = time.time() - t0            # profile to the device; a large system's value arena is taken here (hipMalloc of fresh VRAM: ~27 ms per GiB)
     ms_asm_first = ctx.assemble_c3d8(coord, conn, E, NU, elemopt=1, load=load, bc=bc)   # builds the element colouring + scatter map
     ms_asm = ctx.assemble_c3d8(coord, conn, E, NU, elemopt=1, load=load, bc=bc)          # what a Newton iteration pays
     m.Iarray[0] = a.warmup + a.steps + 8          # MAXIT: never reached inside the timed region
@@ -477,7 +479,7 @@ def main():
             # (what makes the speed class of this kernel the same in every process)
             "placement": placement,
         },
-        "setup_s": {"mat_con": t_con, "assemble_ms": ms_asm, "precond_setup": t_pre,
+        "setup_s": {"mat_con": t_con, "profile_upload_and_arena": t_upload, "assemble_ms": ms_asm, "precond_setup": t_pre,
                     "note": "precond_setup = ordering + colouring + layouts + factors (no placement search, no timing of candidates: the value arena "
                             "is taken at fx_upload, before the CSR arrays)"},
         "resid_after_steps": resid,

@@ -309,10 +309,15 @@ extern "C" int fx_create(int device, fx_context **out) {
   for (const FxOption &o : g_fx_options)
     if (const char *e = getenv(o.name)) o.set(c, atof(e));
   {  // dataflow sweeps: the co-residency bound of each instantiation (workgroups per CU x CUs), the clamp of FX_DF_GRID
-    int pc[3] = {0, 0, 0};
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc[0], k_tri_dataflow<2, 1, true>, 128, 0) != hipSuccess) pc[0] = 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc[1], k_tri_dataflow<4, 1, true>, 256, 0) != hipSuccess) pc[1] = 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc[2], k_tri_dataflow<8, 1, true>, 512, 0) != hipSuccess) pc[2] = 1;
+    int pc[3] = {64, 64, 64};
+    auto occ = [&](int k, auto kernel, int threads) {  // the minimum over the instantiations of one wave count (POLL 0 / 1, SOA on / off): whichever is launched fits
+      int n = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, 0) != hipSuccess) n = 1;
+      pc[k] = std::min(pc[k], n);
+    };
+    occ(0, k_tri_dataflow<2, 1, true>, 128); occ(0, k_tri_dataflow<2, 0, true>, 128); occ(0, k_tri_dataflow<2, 1, false>, 128); occ(0, k_tri_dataflow<2, 0, false>, 128);
+    occ(1, k_tri_dataflow<4, 1, true>, 256); occ(1, k_tri_dataflow<4, 0, true>, 256); occ(1, k_tri_dataflow<4, 1, false>, 256); occ(1, k_tri_dataflow<4, 0, false>, 256);
+    occ(2, k_tri_dataflow<8, 1, true>, 512); occ(2, k_tri_dataflow<8, 0, true>, 512); occ(2, k_tri_dataflow<8, 1, false>, 512); occ(2, k_tri_dataflow<8, 0, false>, 512);
     (void)hipGetLastError();
     for (int k = 0; k < 3; k++) c->df_grid_max[k] = std::max(1, c->n_cu * std::max(1, std::min(pc[k], 8)));
   }
@@ -2387,7 +2392,10 @@ extern "C" int fx_solve_resident(fx_context *c, int32_t *Iarray, double *Rarray,
     else if (method == 3 || method == 4) {
       HostKrylov hk;
       e = (method == 3) ? gmres_solve(c, maxit, tol, Iarray[5], &hk) : gpbicg_solve(c, maxit, tol, &hk);
-      if (!e && df_take_error(c)) {  // a dataflow sweep of this attempt timed out: again with the launch-per-level sweeps (the solve re-reads its initial X)
+      // a dataflow sweep of this attempt timed out: again with the launch-per-level sweeps (the solve re-reads its initial X).  Asked
+      // BEFORE looking at e: a timed-out sweep leaves tag values (NaN) in the vectors, which is what makes these methods return a
+      // breakdown code in the first place
+      if (df_take_error(c)) {
         hk = HostKrylov();
         e = (method == 3) ? gmres_solve(c, maxit, tol, Iarray[5], &hk) : gpbicg_solve(c, maxit, tol, &hk);
       }

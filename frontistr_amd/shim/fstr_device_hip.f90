@@ -360,6 +360,7 @@ contains
       ierr = fx_assemble_c3d8_sections(fxb_context(hecMESH), mesh, int(size(lin_E), c_int32_t), lin_E, lin_nu, lin_emat, lin_elemopt, &
                                        c_null_ptr, 0_c_int32_t, c_null_ptr, c_null_ptr, c_null_ptr, ms)
       if (ierr /= 0) call fsd_fail('fx_assemble_c3d8_sections')
+      ierr = fx_update_c3d8_linear_prepare(fxb_context(hecMESH), int(hecMESH%n_elem, c_int32_t))   ! the stress update follows the solve: pin its staging meanwhile
       fxb_matrix_on_device = .true.
       fsd_stiffness = .true.
       return
@@ -415,6 +416,7 @@ contains
     real(c_double), allocatable :: tot(:)
     character(len=8) :: env
     integer :: elen, estat, icel, g
+    real(kind=kreal) :: t0
     fsd_update_newton_linear = .false.
     call get_environment_variable('HECMW_GPU_UPDATE', env, elen, estat)
     if (estat == 0 .and. elen > 0 .and. env(1:1) == '0') return
@@ -422,10 +424,13 @@ contains
     tot(:) = fstrSOLID%unode(1:3*hecMESH%n_node) + fstrSOLID%dunode(1:3*hecMESH%n_node)
     mesh%n_node = hecMESH%n_node; mesh%n_elem = hecMESH%n_elem
     mesh%coord = c_loc(hecMESH%node(1)); mesh%conn = c_loc(hecMESH%elem_node_item(1))
+    t0 = hecmw_Wtime()
     ierr = fx_update_c3d8_linear(fxb_context(hecMESH), mesh, int(size(lin_E), c_int32_t), lin_E, lin_nu, lin_emat, lin_elemopt, tot, &
                                  ps, pt, fstrSOLID%QFORCE, ms)
     if (ierr /= 0) call fsd_fail('fx_update_c3d8_linear')
     deallocate(tot)
+    call fsd_report('  of which the library call (uploads, kernel, strain / stress / QFORCE back)', hecmw_Wtime() - t0)
+    call fsd_report('  of which the element kernel alone', real(ms, kreal) * 1.d-3)
     call c_f_pointer(ps, s6, [6, 8, hecMESH%n_elem])
     call c_f_pointer(pt, t6, [6, 8, hecMESH%n_elem])
     !$omp parallel do default(shared) private(icel, g)

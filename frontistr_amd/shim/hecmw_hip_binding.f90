@@ -22,7 +22,7 @@ module hecmw_hip_binding
   ! device-side assembly / stress update driven by fistr1's own fstr_Newton (INTEGRATION.md section 5)
   public :: fx_mesh_view, fx_material_view, fx_nl_state_view
   public :: fx_upload, fx_solve_device_matrix, fx_nl_init_sections, fx_nl_stiffness_at, fx_nl_update_at, fx_nl_commit, fx_nl_get_state, &
-            fx_nl_set_state, fx_assemble_c3d8_sections, fx_update_c3d8_linear, fx_nl_snapshot
+            fx_nl_set_state, fx_assemble_c3d8_sections, fx_update_c3d8_linear, fx_update_c3d8_linear_prepare, fx_nl_snapshot
   public :: fxb_values_owner, fxb_values_addr
   public :: fxb_matrix_on_device, fxb_defer_bc, fxb_solve_device_matrix, FX_UP_PROFILE
   public :: fxb_context, fxb_views, fxb_ensure_transport, fxb_error_text, fxb_on_gpu_path, fx_get_stats
@@ -129,6 +129,11 @@ module hecmw_hip_binding
       real(c_double), intent(inout) :: qforce(*)
       real(c_float), intent(out) :: ms
     end function fx_update_c3d8_linear
+    integer(c_int) function fx_update_c3d8_linear_prepare(ctx, n_elem) bind(C, name='fx_update_c3d8_linear_prepare')
+      import :: c_ptr, c_int, c_int32_t
+      type(c_ptr), value :: ctx
+      integer(c_int32_t), value :: n_elem
+    end function fx_update_c3d8_linear_prepare
     integer(c_int) function fx_nl_init_sections(ctx, mesh, n_mat, mats, elem_mat) bind(C, name='fx_nl_init_sections')
       import :: c_int, c_ptr, c_int32_t, fx_mesh_view, fx_material_view
       type(c_ptr), value :: ctx

@@ -222,6 +222,8 @@ int fx_assemble_c3d8_sections(fx_context *ctx, const fx_mesh_view *mesh, int32_t
 int fx_update_c3d8_linear(fx_context *ctx, const fx_mesh_view *mesh, int32_t n_mat, const double *E, const double *nu,
                           const int32_t *elem_mat, int elemopt, const double *disp, const double **strain,
                           const double **stress, double *qforce, float *ms_kernel);
+/* Optional: start pinning the host staging of fx_update_c3d8_linear for n_elem elements on a helper thread and return at once. */
+int fx_update_c3d8_linear_prepare(fx_context *ctx, int32_t n_elem);
 /* One element stiffness through the device kernel (tests): ecoord 8x3, stiff 24x24 row-major. */
 int fx_element_stiffness_c3d8(fx_context *ctx, int elemopt, const double *ecoord, double E, double nu,
                               double *stiff);

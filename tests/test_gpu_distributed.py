@@ -326,6 +326,9 @@ def test_bench_self_launch(ngpu):
     # the headline is the library's default path -- Eisenstat's form, on subdomains with the halo term -- and says so; hecmw_solve_CG's loop beside it
     assert out["config"]["recurrence"].startswith("eisenstat") and "standard" in out["variants"], (out["config"], out["variants"])
     assert out["variants"]["standard"]["it_per_s"] > 0
+    # the ranks' communication ledgers were cross-checked over the control plane before the line was printed
+    led = out["comm_ledger"]
+    assert led["consistent"] and led["allreduces"] > 0 and led["halo_exchanges"] > 0 and len(led["halo_bytes_sent_per_rank"]) == ngpu
     assert out["config"]["decomposition"] == {2: "2x1x1", 4: "2x2x1"}[ngpu]
     assert out["value"] > 0 and np.isfinite(out["resid_after_steps"])
     assert "cpu_baseline" not in out          # rank 0 at N = 1 only
