@@ -240,7 +240,10 @@ static int context_init(fx_context *c) {
 // ---------------------------------------------------------------------------
 struct FxOption { const char *name; void (*set)(fx_context *, double); };
 static const FxOption g_fx_options[] = {
-    {"FX_ARENA_GB", [](fx_context *c, double v) { c->arena_min_gb = std::max(0, (int)v); }},
+    {"FX_ARENA_GB", [](fx_context *c, double v) { c->arena_min_bytes = v > 0.0 ? (size_t)(v * 1073741824.0) : 0; }},
+    {"FX_ARENA_TRIES", [](fx_context *c, double v) { c->arena_tries = std::max(1, std::min(8, (int)v)); }},
+    {"FX_ARENA_MAX_MB", [](fx_context *c, double v) { c->arena_max_bytes = (size_t)(std::max(0.0, v) * 1048576.0); }},
+    {"FX_ARENA_THRESHOLD_MB", [](fx_context *c, double v) { c->arena_threshold = (size_t)(std::max(0.0, v) * 1048576.0); }},
     {"FX_BFS_DEVICE_MIN", [](fx_context *c, double v) { c->bfs_device_min = (int)v; }},
     {"FX_MC_DEVICE_MIN", [](fx_context *c, double v) { c->mc_device_min = (int)v; }},
     {"FX_BFS_BATCH", [](fx_context *c, double v) { c->bfs_batch = std::max(1, (int)v); }},
@@ -260,6 +263,7 @@ static const FxOption g_fx_options[] = {
     {"FX_EISENSTAT", [](fx_context *c, double v) { c->eisenstat = (int)v != 0; }},
     {"FX_EIS_FUSE", [](fx_context *c, double v) { c->eis_fuse = (int)v != 0; }},
     {"FX_EIS_MERGE", [](fx_context *c, double v) { c->eis_merge = (int)v != 0; }},
+    {"FX_EIS_GRID", [](fx_context *c, double v) { c->eis_grid = std::max(0, (int)v); }},
     {"FX_SPLIT_MAX_SLICES", [](fx_context *c, double v) { c->split_max_slices = (int)v; }},
     {"FX_DATAFLOW", [](fx_context *c, double v) {
        c->df_mode = (int)v;
@@ -327,49 +331,64 @@ extern "C" int fx_create(int device, fx_context **out) {
 
 // ---------------------------------------------------------------------------
 // The value arena (DevArena, fx_internal.h): one large allocation taken before anything else of a large system, the BELL value
-// arrays placed in it by a bump pointer at 2 MiB-aligned offsets.
+// arrays placed in it first-fit at 2 MiB-aligned offsets.
 // ---------------------------------------------------------------------------
 static void arena_destroy(fx_context *c) {
   if (c->arena.base) (void)hipFree(c->arena.base);
   c->arena = DevArena();
+  for (DevArena &a : c->arena_tried)
+    if (a.base) (void)hipFree(a.base);
+  c->arena_tried.clear();
+  c->arena_verified = false;
 }
 // Called when the size of a system becomes known (fx_upload of a profile, before the CSR arrays are allocated): `need` = estimated
 // bytes of the value arrays of M, L and U.  Keeps a large enough arena, replaces an empty smaller one, does nothing for small
 // systems, with FX_ARENA_GB=0 or when the device cannot spare the memory (the arrays then get their own allocations as before).
 static void arena_reserve(fx_context *c, size_t need) {
   DevArena &a = c->arena;
-  if (c->arena_min_gb <= 0 || need < c->arena_threshold) return;
-  need += (size_t)8 << 21;  // alignment slack of a few arrays
+  if (c->arena_min_bytes == 0 || need < c->arena_threshold) return;
+  need += (size_t)4 << 21;  // alignment slack of four arrays
   if (a.base && a.bytes >= need) return;
-  if (a.base && a.live > 0) return;  // in use and too small: the new arrays fall back to their own allocations
+  if (a.base && a.live() > 0) return;  // in use and too small: the new arrays fall back to their own allocations
   arena_destroy(c);
-  size_t want = (size_t)1 << 30;
-  while (want < need || want < ((size_t)c->arena_min_gb << 30)) want <<= 1;
+  size_t want = (size_t)1 << 20;
+  while (want < need || want < c->arena_min_bytes) want <<= 1;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
   // what else this system will allocate is about 2.5x the value arrays (CSR arrays, column ids, source maps, vectors): leave it room
   while (want > need && want + 3 * need > free_b) want >>= 1;
   if (want < need || want + 2 * need > free_b) return;
+  if (c->arena_max_bytes) {  // a cap set by the user: what does not fit gets its own allocation (val2_alloc)
+    while (want > c->arena_max_bytes && want > ((size_t)1 << 20)) want >>= 1;
+  }
   char *p = nullptr;
   if (hipMalloc((void **)&p, want) != hipSuccess) { (void)hipGetLastError(); return; }
-  a.base = p; a.bytes = want; a.used = 0; a.live = 0;
+  a.base = p; a.bytes = want; a.blocks.clear();
 }
 static char *arena_alloc(fx_context *c, size_t bytes) {
   DevArena &a = c->arena;
-  if (!a.base) return nullptr;
-  const size_t off = (a.used + (((size_t)2 << 20) - 1)) & ~(((size_t)2 << 20) - 1);
+  if (!a.base || bytes == 0) return nullptr;
+  const size_t al = ((size_t)2 << 20) - 1;
+  size_t off = 0;
+  size_t at = 0;  // index in blocks before which the new one goes
+  for (; at < a.blocks.size(); at++) {
+    if (off + bytes <= a.blocks[at].first) break;  // the gap before block `at` holds it
+    off = (a.blocks[at].first + a.blocks[at].second + al) & ~al;
+  }
   if (off + bytes > a.bytes) return nullptr;
-  a.used = off + bytes;
-  a.live++;
+  a.blocks.insert(a.blocks.begin() + at, {off, bytes});
   return a.base + off;
 }
-static void arena_release(fx_context *c) {
+static void arena_release(fx_context *c, const void *p) {
   DevArena &a = c->arena;
-  if (a.live > 0 && --a.live == 0) a.used = 0;
+  if (!a.base) return;
+  const size_t off = (size_t)((const char *)p - a.base);
+  for (size_t k = 0; k < a.blocks.size(); k++)
+    if (a.blocks[k].first == off) { a.blocks.erase(a.blocks.begin() + k); return; }
 }
 
 static void bell_free(Bell &b) {
-  if (b.arena_owner) { arena_release(b.arena_owner); b.val2_base = nullptr; }
+  if (b.arena_owner) { arena_release(b.arena_owner, b.val2_base); b.val2_base = nullptr; }
   dev_free(b.pair_ptr); dev_free(b.val2_base); dev_free(b.col2); dev_free(b.slot_row); dev_free(b.src2); dev_free(b.slice_order);
   dev_free(b.wg_interior); dev_free(b.wg_boundary);
   b.val2 = nullptr;
@@ -709,6 +728,81 @@ static int build_full_bell(fx_context *c) {
 
 static int ensure_work(fx_context *c);
 
+static int spmv_launch(fx_context *c, int mode, int dot, double *x, const double *b, double *y, const int32_t *gate,
+                       int32_t gate_val, const int32_t *wg_list, int nwg);
+static inline int spmv_nparts(fx_context *c);
+
+// Move every value array that lives in the context's arena to the same offsets of `to` (which becomes the context's arena; the
+// old one is returned in *from).  Only M holds values at the time this is used (the sweep layouts are filled after it).
+static void arena_switch(fx_context *c, DevArena &to, DevArena *from) {
+  to.blocks = c->arena.blocks;
+  for (Bell *b : {&c->M, &c->ssor.L, &c->ssor.U, &c->ssor.H})
+    if (b->arena_owner == c && b->val2_base) {
+      const size_t off = (size_t)((char *)b->val2_base - c->arena.base);
+      b->val2_base = to.base + off;
+      b->val2 = (double *)(to.base + off);
+    }
+  *from = c->arena;
+  from->blocks.clear();
+  c->arena = to;
+}
+
+// Verification of the arena (fx_context::arena_tries): see fx_internal.h.  M's values have just been filled.
+static int arena_verify(fx_context *c) {
+  c->arena_verified = true;
+  Bell &M = c->M;
+  if (c->arena_tries <= 1 || !c->arena.base || M.arena_owner != c || M.nslices < 8192) return 0;
+  const double bytes = (double)M.npairs * 64 * 76 + 48.0 * c->ord.nslots;
+  auto time_ms = [&](float *ms) -> int {
+    const int nwg = spmv_nparts(c);
+    if (spmv_launch(c, 0, 1, c->W[2], nullptr, c->W[1], nullptr, 0, nullptr, nwg)) return FX_ERROR_RUNTIME;  // untimed
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    for (int i = 0; i < 3; i++)
+      if (spmv_launch(c, 0, 1, c->W[2], nullptr, c->W[1], nullptr, 0, nullptr, nwg)) return FX_ERROR_RUNTIME;
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    *ms /= 3.f;
+    return 0;
+  };
+  c->arena_ms.clear();
+  float best = 1e30f;
+  int best_k = -1;  // index in arena_tried of the best arena so far; -1 = the current one
+  for (int attempt = 0; attempt < c->arena_tries; attempt++) {
+    float ms = 0.f;
+    if (time_ms(&ms)) return FX_ERROR_RUNTIME;
+    c->arena_ms.push_back(ms);
+    if (ms < best) { best = ms; best_k = -1; }
+    if (bytes / (1e-3 * ms) / 1e9 >= c->arena_good_gbs || attempt + 1 == c->arena_tries) break;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < c->arena.bytes + 3 * c->arena.used() + ((size_t)8 << 30)) break;
+    DevArena next;
+    if (hipMalloc((void **)&next.base, c->arena.bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+    next.bytes = c->arena.bytes;
+    DevArena old;
+    arena_switch(c, next, &old);
+    c->arena_tried.push_back(old);
+    if (best_k == -1) best_k = (int)c->arena_tried.size() - 1;  // the best so far is the one just left
+    if (bell_fill_values(c, M)) return FX_ERROR_RUNTIME;
+  }
+  if (best_k >= 0) {  // an earlier arena was the fastest: back to it
+    DevArena back = c->arena_tried[best_k], old;
+    arena_switch(c, back, &old);
+    c->arena_tried[best_k] = old;
+    if (bell_fill_values(c, M)) return FX_ERROR_RUNTIME;
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (DevArena &a : c->arena_tried)
+    if (a.base) (void)hipFree(a.base);
+  c->arena_tried.clear();
+  if (getenv("FX_TIMING") && atoi(getenv("FX_TIMING"))) {
+    fprintf(stderr, "[fx timing] arena verification (SpMV ms per arena tried):");
+    for (float v : c->arena_ms) fprintf(stderr, " %.4f", v);
+    fprintf(stderr, "  kept %.4f\n", best);
+  }
+  return 0;
+}
+
 // Make the ordering, M (symbolic + values) and the work vectors current.
 static int ensure_solver(fx_context *c) {
   if (c->ord.kind < 0 && set_ordering(c, 0, nullptr)) return FX_ERROR_RUNTIME;
@@ -718,6 +812,7 @@ static int ensure_solver(fx_context *c) {
     if (bell_fill_values(c, c->M)) return FX_ERROR_RUNTIME;
     c->bell_valid = true;
     c->values_epoch++;  // the SpMV layout holds new values from here on
+    if (!c->arena_verified && arena_verify(c)) return FX_ERROR_RUNTIME;
   }
   return 0;
 }
@@ -1643,14 +1738,15 @@ extern "C" int fx_precond_setup(fx_context *c, const int32_t *Iarray, const doub
 
 // Where the BELL value arrays of this context live (DevArena, fx_internal.h): out[0] bytes of the arena (0: none -- small system,
 // FX_ARENA_GB=0, or no memory to spare), [1] bytes in use, [2] arrays placed in it, [3..5] 1 if the value array of M / L / U lies in
-// it, [6] bytes of M's value array.  Nothing is measured or searched at set-up: the arena makes the placement the same in every
-// process (rounds 2-3 timed candidate allocations here; scripts/r4/region_probe.py has the evidence for what replaced them).
+// it, [6] bytes of M's value array, [7] arenas the one-off verification timed, [8] the loop's SpMV ms on the arena kept (arena_verify).
 extern "C" int fx_placement_report(fx_context *c, double out[9]) {
   if (!c || !out) { g_fx_error = "fx_placement_report: null argument"; return FX_ERROR_RUNTIME; }
   for (int k = 0; k < 9; k++) out[k] = 0.0;
-  out[0] = (double)c->arena.bytes; out[1] = (double)c->arena.used; out[2] = c->arena.live;
+  out[0] = (double)c->arena.bytes; out[1] = (double)c->arena.used(); out[2] = c->arena.live();
   out[3] = c->M.arena_owner ? 1 : 0; out[4] = c->ssor.L.arena_owner ? 1 : 0; out[5] = c->ssor.U.arena_owner ? 1 : 0;
   out[6] = (double)c->M.npairs * 576 * 8;
+  out[7] = (double)c->arena_ms.size();                                  // arenas the verification timed (0: not verified -- small system, no arena, FX_ARENA_TRIES=1)
+  out[8] = c->arena_ms.empty() ? 0.0 : *std::min_element(c->arena_ms.begin(), c->arena_ms.end());  // SpMV ms on the arena kept
   return 0;
 }
 
@@ -1954,7 +2050,7 @@ static int eis_cg_iteration(fx_context *c, int it) {
       const int s0 = S.color_slice[col], s1 = S.color_slice[col + 1];
       if (s1 <= s0) continue;
       if (s1 - s0 <= c->split_max_slices)
-        hipLaunchKernelGGL((k_eis_backward_split<4>), dim3(s1 - s0), dim3(256), 0, c->stream, s0, s1, S.U.pair_ptr, S.U.val2, S.U.col2, S.alu,
+        hipLaunchKernelGGL((k_eis_backward_split<4>), dim3(c->eis_grid > 0 ? std::min(s1 - s0, c->eis_grid) : s1 - s0), dim3(256), 0, c->stream, s0, s1, S.U.pair_ptr, S.U.val2, S.U.col2, S.alu,
                            c->st, DT, PH, P, gate_status(c));
       else if (c->ssor_bs == 64)
         hipLaunchKernelGGL((k_eis_backward<64>), dim3((s1 - s0 + spb - 1) / spb), dim3(64), 0, c->stream, s0, s1, S.U.pair_ptr, S.U.val2,
@@ -1986,7 +2082,7 @@ static int eis_cg_iteration(fx_context *c, int it) {
       if (s1 <= s0) continue;
       int g = (s1 - s0 + spb - 1) / spb;
       if (s1 - s0 <= c->split_max_slices) {
-        g = s1 - s0;
+        g = c->eis_grid > 0 ? std::min(s1 - s0, c->eis_grid) : s1 - s0;
         hipLaunchKernelGGL((k_eis_forward_split<4>), dim3(g), dim3(256), 0, c->stream, s0, s1, S.L.pair_ptr, S.L.val2, S.L.col2, S.alu,
                            esc, PH, P, V, WH, Q, c->partials, off, gate_status(c), HP);
       } else if (c->ssor_bs == 64)

@@ -98,7 +98,7 @@ extern "C" int fx_debug_replace(fx_context *c, int what, int how, int64_t arg, u
     const size_t bytes = (size_t)M.npairs * 576 * 8;
     if (dbg_alloc(c, bytes, how, arg, &p)) return FX_ERROR_RUNTIME;
     if (!M.arena_owner) g_dbg_leak.push_back(M.val2_base);
-    else arena_release(M.arena_owner);
+    else arena_release(M.arena_owner, M.val2_base);
     M.arena_owner = nullptr;
     M.val2_base = p; M.val2 = (double *)p; M.val2_bytes = bytes;
     if (bell_fill_values(c, M)) return FX_ERROR_RUNTIME;

@@ -209,12 +209,14 @@ struct PhaseClock {
 // in both classes: 47.6k of 171M requests).  What holds on every box measured: inside ONE large allocation taken before anything
 // else every offset runs in the same fast class (1.044-1.048 ms at sixteen offsets of a 64 GiB block on a box whose first
 // power-of-two block ran at 1.180).  So the context takes one arena when it first learns the size of a large system -- before the
-// CSR arrays, the layouts and the vectors -- and the value arrays of M, L and U live in it at fixed 2 MiB-aligned offsets.
+// CSR arrays, the layouts and the vectors -- and the value arrays of M, L and U live in it at 2 MiB-aligned offsets (first fit; the holes a rebuilt layout leaves are re-used).
 // FX_ARENA_GB: 0 = off (every array its own hipMalloc), n = arena of at least n GiB (default 32), always a power of two.
 struct DevArena {
   char *base = nullptr;
-  size_t bytes = 0, used = 0;
-  int live = 0;  // arrays currently placed in it; the bump pointer returns to 0 when the last one goes
+  size_t bytes = 0;
+  std::vector<std::pair<size_t, size_t>> blocks;  // (offset, bytes) of the arrays placed in it, by offset: first fit at 2 MiB-aligned offsets
+  size_t used() const { size_t u = 0; for (auto &b : blocks) u += b.second; return u; }
+  int live() const { return (int)blocks.size(); }
 };
 
 // One pass of the auto-SIGMA_DIAG / METHOD2 loop of hecmw_solve_iterative (hecmw_solver_Iterative.f90:117-157): what the reference
@@ -324,6 +326,7 @@ struct fx_context {
   // stage -- on a decomposed system one 2-double all-reduce -- instead of two).  False after a begin, after an iteration that
   // recomputed the true residual and after a true-residual check: those refresh t and leave new rho partials (FX_EIS_MERGE=0: never).
   bool eis_rho_done = false, eis_merge = true;
+  int eis_grid = 0;  // FX_EIS_GRID: most workgroups of one colour launch of the wave-split Eisenstat sweeps (a workgroup then walks slices b, b + grid, ...); 0 = one workgroup per slice
   bool dbg_onecolor = false; // measurement only (FX_DEBUG_ONECOLOR): the half sweeps as one launch each, dependencies ignored
   bool eis_fuse = true;      // direction update fused into the backward sweep (FX_EIS_FUSE=0: k_cg_update_p + the plain sweep)
   int64_t values_epoch = 0;  // counts the refreshes of the SpMV layout's values
@@ -332,8 +335,20 @@ struct fx_context {
   int32_t mc_device_min = 100000;   // block rows from which the multicolouring of the SSOR set-up runs on the device (FX_MC_DEVICE_MIN)
   bool val2_pow2 = true;            // BELL value arrays of a gigabyte or more that do not fit the arena: ask hipMalloc for the next power of two (FX_VAL2_POW2=0: the exact size)
   DevArena arena;                   // the value arena of this context (see DevArena)
-  int arena_min_gb = 32;            // FX_ARENA_GB
-  size_t arena_threshold = (size_t)1 << 30;  // estimated value-array bytes from which a system gets an arena
+  // The arena makes the class the same for every array and every offset, it does not make it the fast one: a box was met whose
+  // first 32 GiB were a slow region (SpMV 1.17 ms in 8 of 8 processes).  So the arena is VERIFIED once, when M's values are first
+  // filled: the loop's own SpMV (p = W[2] -> q = W[1], fused p.q partial) is timed on it (1 untimed + 3 launches, 5 ms); below
+  // arena_good_gbs the context takes ANOTHER arena (the earlier ones held meanwhile, so that it is different memory), moves the
+  // value arrays and times again, at most arena_tries arenas; the fastest is kept, the others are freed before the set-up returns.
+  // Measured consistency of this timing with the loop's: within 0.3 % (profiles/r04_placement_evidence.txt, "loop" vs "probe").
+  int arena_tries = 4;              // FX_ARENA_TRIES (1 = no verification)
+  double arena_good_gbs = 6450.0;   // the fast classes stream 6.57-6.8 TB/s algorithmic, the slow ones 5.9-6.4
+  std::vector<DevArena> arena_tried; // earlier arenas of a verification in progress (held so that the next request is different memory)
+  std::vector<float> arena_ms;      // what the verification measured, in order (fx_placement_report)
+  bool arena_verified = false;
+  size_t arena_min_bytes = (size_t)32 << 30;  // FX_ARENA_GB (GiB, fractions allowed; 0 = no arena)
+  size_t arena_threshold = (size_t)1 << 30;   // estimated value-array bytes from which a system gets an arena (FX_ARENA_THRESHOLD_MB)
+  size_t arena_max_bytes = 0;                 // FX_ARENA_MAX_MB: never take more than this (0 = no cap); arrays that do not fit get their own allocations
   int32_t bfs_batch = 16;           // levels of the device level ordering between two looks at the level state by the host (FX_BFS_BATCH)
   int32_t bfs_device_min = 100000;  // block rows from which the level ordering of the SSOR set-up runs on the device (FX_BFS_DEVICE_MIN)
   // work vectors (3*NP each)

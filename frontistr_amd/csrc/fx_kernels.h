@@ -632,55 +632,60 @@ __global__ __launch_bounds__(64 * WPS) void k_eis_forward_split(int32_t slice0, 
                                                                 double *__restrict__ v, double *__restrict__ w, double *__restrict__ q,
                                                                 double *__restrict__ partials, int32_t part0,
                                                                 const int32_t *__restrict__ gate, const double *__restrict__ hp) {
+  // grid <= slices of the colour: workgroup b takes slices b, b + grid, ... (FX_EIS_GRID; one partial per workgroup); a second
+  // barrier per slice only when the workgroup goes on to another one (the LDS exchange is single-buffered: occupancy)
   __shared__ double part[WPS][6][64];
-  const int slice = slice0 + blockIdx.x;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int32_t gv = gate ? *gate : 0;  // one scalar round trip for the gate AND the slice's row pointers (the early return used to serialise them)
-  const int h0 = pair_ptr[slice], h1 = pair_ptr[slice + 1];
-  if (gv != 0) return;
-  const int np = (h1 - h0) >> 1;
-  double sv[3] = {0.0, 0.0, 0.0}, sp[3] = {0.0, 0.0, 0.0};
-  const double2 *vbase = (const double2 *)(val2 + (size_t)h0 * 576) + lane;
-  const int2 *cbase = (const int2 *)(col2 + (size_t)h0 * 64) + lane;
-  for (int i = wv; i < np; i += WPS) {
-    const int2 cc = ld_stream(cbase + (size_t)i * 64);
-    double2 a[9];
+  if (gate && *gate != 0) return;
+  double dsum = 0.0;
+  for (int slice = slice0 + blockIdx.x; slice < slice1; slice += gridDim.x) {
+    const int h0 = pair_ptr[slice], h1 = pair_ptr[slice + 1];
+    const int np = (h1 - h0) >> 1;
+    double sv[3] = {0.0, 0.0, 0.0}, sp[3] = {0.0, 0.0, 0.0};
+    const double2 *vbase = (const double2 *)(val2 + (size_t)h0 * 576) + lane;
+    const int2 *cbase = (const int2 *)(col2 + (size_t)h0 * 64) + lane;
+    for (int i = wv; i < np; i += WPS) {
+      const int2 cc = ld_stream(cbase + (size_t)i * 64);
+      double2 a[9];
 #pragma unroll
-    for (int e = 0; e < 9; e++) a[e] = ld_stream(vbase + (size_t)i * 576 + e * 64);
-    double gv[6], gp[6];
+      for (int e = 0; e < 9; e++) a[e] = ld_stream(vbase + (size_t)i * 576 + e * 64);
+      double gv[6], gp[6];
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-      gv[k] = v[(size_t)3 * cc.x + k]; gv[3 + k] = v[(size_t)3 * cc.y + k];
-      gp[k] = p[(size_t)3 * cc.x + k]; gp[3 + k] = p[(size_t)3 * cc.y + k];
+      for (int k = 0; k < 3; k++) {
+        gv[k] = v[(size_t)3 * cc.x + k]; gv[3 + k] = v[(size_t)3 * cc.y + k];
+        gp[k] = p[(size_t)3 * cc.x + k]; gp[3 + k] = p[(size_t)3 * cc.y + k];
+      }
+      bell_pair_fma(a, gv, sv[0], sv[1], sv[2]);
+      bell_pair_fma(a, gp, sp[0], sp[1], sp[2]);
     }
-    bell_pair_fma(a, gv, sv[0], sv[1], sv[2]);
-    bell_pair_fma(a, gp, sp[0], sp[1], sp[2]);
-  }
-  if (((h1 - h0) & 1) && wv == (np % WPS)) {
-    const double *vt = val2 + (size_t)(h0 + 2 * np) * 576 + lane;
-    const int cc = ld_stream(col2 + (size_t)(h0 + 2 * np) * 64 + lane);
-    double a[9];
+    if (((h1 - h0) & 1) && wv == (np % WPS)) {
+      const double *vt = val2 + (size_t)(h0 + 2 * np) * 576 + lane;
+      const int cc = ld_stream(col2 + (size_t)(h0 + 2 * np) * 64 + lane);
+      double a[9];
 #pragma unroll
-    for (int e = 0; e < 9; e++) a[e] = ld_stream(vt + e * 64);
-    const double av[3] = {v[(size_t)3 * cc], v[(size_t)3 * cc + 1], v[(size_t)3 * cc + 2]};
-    const double ap[3] = {p[(size_t)3 * cc], p[(size_t)3 * cc + 1], p[(size_t)3 * cc + 2]};
-    bell_single_fma(a, av, sv[0], sv[1], sv[2]);
-    bell_single_fma(a, ap, sp[0], sp[1], sp[2]);
-  }
+      for (int e = 0; e < 9; e++) a[e] = ld_stream(vt + e * 64);
+      const double av[3] = {v[(size_t)3 * cc], v[(size_t)3 * cc + 1], v[(size_t)3 * cc + 2]};
+      const double ap[3] = {p[(size_t)3 * cc], p[(size_t)3 * cc + 1], p[(size_t)3 * cc + 2]};
+      bell_single_fma(a, av, sv[0], sv[1], sv[2]);
+      bell_single_fma(a, ap, sp[0], sp[1], sp[2]);
+    }
 #pragma unroll
-  for (int k = 0; k < 3; k++) { part[wv][k][lane] = sv[k]; part[wv][3 + k][lane] = sp[k]; }
-  __syncthreads();
-  double d = 0.0;
+    for (int k = 0; k < 3; k++) { part[wv][k][lane] = sv[k]; part[wv][3 + k][lane] = sp[k]; }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) { sv[k] = part[0][k][lane]; sp[k] = part[0][3 + k][lane]; }
+#pragma unroll
+      for (int j = 1; j < WPS; j++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) { sv[k] += part[j][k][lane]; sp[k] += part[j][3 + k][lane]; }
+      dsum += eis_forward_finish(slice, lane, sv, sp, alu, esc, ph, p, v, w, q, hp);
+    }
+    if (slice + (int)gridDim.x < slice1) __syncthreads();
+  }
   if (wv == 0) {
-#pragma unroll
-    for (int k = 0; k < 3; k++) { sv[k] = part[0][k][lane]; sp[k] = part[0][3 + k][lane]; }
-#pragma unroll
-    for (int j = 1; j < WPS; j++)
-#pragma unroll
-      for (int k = 0; k < 3; k++) { sv[k] += part[j][k][lane]; sp[k] += part[j][3 + k][lane]; }
-    d = eis_forward_finish(slice, lane, sv, sp, alu, esc, ph, p, v, w, q, hp);
-    d = wave_sum(d);
-    if (lane == 0) partials[part0 + blockIdx.x] = d;
+    dsum = wave_sum(dsum);
+    if (lane == 0) partials[part0 + blockIdx.x] = dsum;
   }
 }
 
@@ -728,41 +733,42 @@ __global__ __launch_bounds__(64 * WPS) void k_eis_backward_split(int32_t slice0,
                                                                  const double *__restrict__ alu, const KrylovState *__restrict__ st,
                                                                  const double *__restrict__ dt, double *__restrict__ ph,
                                                                  double *__restrict__ p, const int32_t *__restrict__ gate) {
-  __shared__ double part[WPS][3][64];
-  const int slice = slice0 + blockIdx.x;
+  __shared__ double part[WPS][3][64];  // as k_eis_forward_split: workgroup b takes slices b, b + grid, ...
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int32_t gv = gate ? *gate : 0;  // one scalar round trip for the gate AND the slice's row pointers (the early return used to serialise them)
-  const int h0 = pair_ptr[slice], h1 = pair_ptr[slice + 1];
-  if (gv != 0) return;
-  const int np = (h1 - h0) >> 1;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-  const double2 *vbase = (const double2 *)(val2 + (size_t)h0 * 576) + lane;
-  const int2 *cbase = (const int2 *)(col2 + (size_t)h0 * 64) + lane;
-  for (int i = w; i < np; i += WPS) {
-    const int2 cc = ld_stream(cbase + (size_t)i * 64);
-    double2 a[9];
+  if (gate && *gate != 0) return;
+  for (int slice = slice0 + blockIdx.x; slice < slice1; slice += gridDim.x) {
+    const int h0 = pair_ptr[slice], h1 = pair_ptr[slice + 1];
+    const int np = (h1 - h0) >> 1;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    const double2 *vbase = (const double2 *)(val2 + (size_t)h0 * 576) + lane;
+    const int2 *cbase = (const int2 *)(col2 + (size_t)h0 * 64) + lane;
+    for (int i = w; i < np; i += WPS) {
+      const int2 cc = ld_stream(cbase + (size_t)i * 64);
+      double2 a[9];
 #pragma unroll
-    for (int e = 0; e < 9; e++) a[e] = ld_stream(vbase + (size_t)i * 576 + e * 64);
-    const double *xa = p + (size_t)3 * cc.x, *xb = p + (size_t)3 * cc.y;
-    const double xv[6] = {xa[0], xa[1], xa[2], xb[0], xb[1], xb[2]};
-    bell_pair_fma(a, xv, s0, s1, s2);
-  }
-  if (((h1 - h0) & 1) && w == (np % WPS)) {
-    const double *vt = val2 + (size_t)(h0 + 2 * np) * 576 + lane;
-    const int cc = ld_stream(col2 + (size_t)(h0 + 2 * np) * 64 + lane);
-    double a[9];
+      for (int e = 0; e < 9; e++) a[e] = ld_stream(vbase + (size_t)i * 576 + e * 64);
+      const double *xa = p + (size_t)3 * cc.x, *xb = p + (size_t)3 * cc.y;
+      const double xv[6] = {xa[0], xa[1], xa[2], xb[0], xb[1], xb[2]};
+      bell_pair_fma(a, xv, s0, s1, s2);
+    }
+    if (((h1 - h0) & 1) && w == (np % WPS)) {
+      const double *vt = val2 + (size_t)(h0 + 2 * np) * 576 + lane;
+      const int cc = ld_stream(col2 + (size_t)(h0 + 2 * np) * 64 + lane);
+      double a[9];
 #pragma unroll
-    for (int e = 0; e < 9; e++) a[e] = ld_stream(vt + e * 64);
-    const double x[3] = {p[(size_t)3 * cc], p[(size_t)3 * cc + 1], p[(size_t)3 * cc + 2]};
-    bell_single_fma(a, x, s0, s1, s2);
-  }
-  part[w][0][lane] = s0; part[w][1][lane] = s1; part[w][2][lane] = s2;
-  __syncthreads();
-  if (w == 0) {
-    s0 = part[0][0][lane]; s1 = part[0][1][lane]; s2 = part[0][2][lane];
+      for (int e = 0; e < 9; e++) a[e] = ld_stream(vt + e * 64);
+      const double x[3] = {p[(size_t)3 * cc], p[(size_t)3 * cc + 1], p[(size_t)3 * cc + 2]};
+      bell_single_fma(a, x, s0, s1, s2);
+    }
+    part[w][0][lane] = s0; part[w][1][lane] = s1; part[w][2][lane] = s2;
+    __syncthreads();
+    if (w == 0) {
+      s0 = part[0][0][lane]; s1 = part[0][1][lane]; s2 = part[0][2][lane];
 #pragma unroll
-    for (int k = 1; k < WPS; k++) { s0 += part[k][0][lane]; s1 += part[k][1][lane]; s2 += part[k][2][lane]; }
-    eis_backward_finish(slice, lane, s0, s1, s2, alu, st, dt, ph, p);
+      for (int k = 1; k < WPS; k++) { s0 += part[k][0][lane]; s1 += part[k][1][lane]; s2 += part[k][2][lane]; }
+      eis_backward_finish(slice, lane, s0, s1, s2, alu, st, dt, ph, p);
+    }
+    if (slice + (int)gridDim.x < slice1) __syncthreads();
   }
 }
 

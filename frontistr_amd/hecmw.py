@@ -216,7 +216,7 @@ class SolverContext:
         _chk(lib().fx_placement_report(self.h, out))
         return {"arena_bytes": int(out[0]), "arena_used_bytes": int(out[1]), "arrays_in_arena": int(out[2]),
                 "spmv_values_in_arena": bool(out[3]), "lower_values_in_arena": bool(out[4]), "upper_values_in_arena": bool(out[5]),
-                "spmv_value_bytes": int(out[6])}
+                "spmv_value_bytes": int(out[6]), "arenas_timed": int(out[7]), "kept_ms": float(out[8])}
 
     def solve_resident(self, hecMAT, want_history=True):
         info = _SolveInfo()

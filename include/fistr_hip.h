@@ -151,7 +151,8 @@ int fx_get_stats(fx_context *ctx, int64_t out[16]);
 /* Where the value arrays of the sliced layouts live: out[0] bytes of the context's value arena (one large allocation taken when the
  * size of a large system first becomes known, before anything else of it: 0 = none), [1] bytes in use, [2] arrays placed in it,
  * [3..5] 1 if the value array of the SpMV layout / the lower / the upper sweep layout lies in it, [6] bytes of the SpMV layout's
- * value array.  FX_ARENA_GB (0 = off, default 32 = at least 32 GiB).  Nothing is timed or searched at set-up. */
+ * value array, [7] arenas the one-off verification timed (the loop's SpMV on the arena, 5 ms; a slow one is replaced by another arena,
+ * at most FX_ARENA_TRIES = 4, the fastest kept), [8] the SpMV's ms on the arena kept.  FX_ARENA_GB (0 = off, default 32 = at least 32 GiB). */
 int fx_placement_report(fx_context *ctx, double out[9]);
 /* The passes of the auto-SIGMA_DIAG / METHOD2 loop of the last solve on this context (hecmw_solver_Iterative.f90:117-157: banner
  * :125 before every pass, 'Increasing SIGMA_DIAG to' :149 before a retry): METHOD, the SIGMA_DIAG in effect and the number of

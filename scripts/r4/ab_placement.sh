@@ -12,9 +12,9 @@ for i in $(seq 1 $N); do
 import json, sys
 d = json.loads(sys.stdin.read().strip().splitlines()[-1]); r = d['roofline']; p = r['placement']; v = d['variants']
 o = list(v.values())[0] if v else {}
-print('process %s  %-8s SpMV frac %.3f  %.4f ms (stream ceiling %.0f GB/s)  apply %.3f ms  headline %.1f it/s (%s)  other form %.1f it/s  arena %.0f GiB, SpMV values in it: %s'
+print('process %s  %-8s SpMV frac %.3f  %.4f ms (stream ceiling %.0f GB/s)  apply %.3f ms  headline %.1f it/s (%s)  other form %.1f it/s  arena %.0f GiB, SpMV values in it: %s; verification timed %d arena(s), kept %.4f ms'
       % ('$i', '$mode', r['frac'], r['ms_per_launch'], r['measured_stream_ceiling'], r['precond_apply']['ms'], d['value'], d['config']['recurrence'].split()[0],
-         o.get('it_per_s', 0.0), p['arena_bytes'] / 2.0**30, p['spmv_values_in_arena']))" >> $OUT || exit 1
+         o.get('it_per_s', 0.0), p['arena_bytes'] / 2.0**30, p['spmv_values_in_arena'], p['arenas_timed'], p['kept_ms']))" >> $OUT || exit 1
   done
 done
 unset FX_ARENA_GB

@@ -1026,3 +1026,56 @@ def test_natural_order_ssor_matches_the_serial_reference(hip, oracle, deck, meth
     z0 = ctx.precond_apply(r)
     assert np.array_equal(z0, z)
     ctx.close()
+
+
+def test_value_arena_places_reuses_and_falls_back(hip, monkeypatch):
+    """The value arena (DevArena: one allocation taken at fx_upload before anything else of a large system, the BELL value arrays of
+    M / L / U first-fit at 2 MiB-aligned offsets in it) on small systems, with its thresholds lowered: (1) arrays placed in it,
+    golden solves; (2) a second, different profile on the same context re-uses the arena (everything of the first was released);
+    (3) ILU(0) after SSOR on the same profile: the sweep layouts are released and their places re-used, several times over, without
+    the arena filling up; (4) block-Jacobi: M alone; (5) an arena capped below what the three arrays need (FX_ARENA_MAX_MB): the
+    one that does not fit gets its own allocation, same answers; (6) FX_ARENA_GB=0: no arena."""
+    monkeypatch.setenv("FX_ARENA_THRESHOLD_MB", "0")
+    monkeypatch.setenv("FX_ARENA_GB", str(16.0 / 1024))          # at least 16 MiB
+    decks = {d: golden_matrix(load_golden(d)) for d in ("cube4", "exA_A361", "cube3s")}
+
+    def solve(ctx, deck, meth, pc, thr):
+        g = load_golden(deck)
+        m = to_hecmat(hip, decks[deck])
+        m.Iarray[0] = 10000; m.Iarray[1] = meth; m.Iarray[2] = pc
+        assert hip.hecmw_solve(None, m, ctx=ctx) == 0
+        tag = "sol_m%d_p%d_t%d_" % (meth, pc, thr)
+        assert relerr(m.X, g[tag + "X"]) < (1e-9 if meth == 1 else 5e-8)
+        return ctx.placement_report()
+
+    ctx = hip.SolverContext()
+    p = solve(ctx, "cube4", 1, 1, 4)
+    size = p["arena_bytes"]
+    assert size >= 16 << 20 and size & (size - 1) == 0                                    # a power of two, at least what was asked
+    assert p["spmv_values_in_arena"] and p["lower_values_in_arena"] and p["upper_values_in_arena"] and p["arrays_in_arena"] == 3
+    assert 0 < p["arena_used_bytes"] <= size and p["arenas_timed"] == 0                   # small system: no verification
+    used1 = p["arena_used_bytes"]
+    p = solve(ctx, "exA_A361", 1, 1, 4)                            # another profile, same context: everything of cube4 was released first
+    assert p["arena_bytes"] == size and p["arrays_in_arena"] == 3 and p["arena_used_bytes"] != used1
+    for _ in range(6):                                             # SSOR <-> ILU(0) on the same profile: M stays, L / U are rebuilt in the holes they left
+        p = solve(ctx, "exA_A361", 2, 10, 1)
+        assert p["arrays_in_arena"] == 3 and p["spmv_values_in_arena"] and p["lower_values_in_arena"]
+        p = solve(ctx, "exA_A361", 1, 1, 4)
+        assert p["arrays_in_arena"] == 3 and p["upper_values_in_arena"]
+    p = solve(ctx, "cube3s", 1, 3, 1)                              # block-Jacobi: only M
+    assert p["arrays_in_arena"] == 1 and p["spmv_values_in_arena"]
+    ctx.close()
+    monkeypatch.setenv("FX_ARENA_MAX_MB", "4")                     # room for two arrays at 2 MiB-aligned offsets: the third gets its own allocation
+    ctx = hip.SolverContext()
+    p = solve(ctx, "cube4", 1, 1, 4)
+    assert p["arena_bytes"] == 4 << 20 and p["arrays_in_arena"] == 2
+    assert [p["spmv_values_in_arena"], p["lower_values_in_arena"], p["upper_values_in_arena"]].count(True) == 2
+    p = solve(ctx, "cube4", 2, 10, 1)
+    assert p["arrays_in_arena"] == 2
+    ctx.close()
+    monkeypatch.delenv("FX_ARENA_MAX_MB")
+    monkeypatch.setenv("FX_ARENA_GB", "0")
+    ctx = hip.SolverContext()
+    p = solve(ctx, "cube4", 1, 1, 4)
+    assert p["arena_bytes"] == 0 and not p["spmv_values_in_arena"] and p["arrays_in_arena"] == 0
+    ctx.close()
