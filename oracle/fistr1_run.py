@@ -194,3 +194,21 @@ def compare_step_lines(got, want, rtol=1e-3, floor=1e-9):
                 bad.append((a, b))
                 break
     return bad
+
+
+def run_restart_pair(binary, deck_dir, workdir, threads=1, env=None):
+    """examples/static/restart2/case02_resume as its readme runs it: the first analysis (C3D8beam.cnt, `!RESTART, FREQUENCY=1`,
+    SUBSTEPS=3) stops at its third sub-step and leaves a restart file; the second (C3D8beam_res.cnt, `!RESTART, FREQUENCY=-1`)
+    resumes from sub-step 4.  deck_dir holds C3D8beam.msh and the two control files.  -> (first run, resumed run)"""
+    for f in ("C3D8beam.msh", "C3D8beam.cnt", "C3D8beam_res.cnt"):
+        shutil.copy(os.path.join(deck_dir, f), os.path.join(workdir, f))
+    outs = []
+    for cnt in ("C3D8beam.cnt", "C3D8beam_res.cnt"):
+        with open(os.path.join(workdir, "hecmw_ctrl.dat"), "w") as fh:
+            fh.write("!MESH, NAME=fstrMSH,TYPE=HECMW-ENTIRE\n C3D8beam.msh\n!CONTROL,NAME=fstrCNT\n %s\n"
+                     "!RESTART,NAME=restart_out,IO=INOUT\n C3D8beam.restart\n!RESULT,NAME=fstrRES,IO=OUT\n C3D8beam.res\n" % cnt)
+        for stale in ("0.log", "FSTR.sta"):
+            if os.path.exists(os.path.join(workdir, stale)):
+                os.remove(os.path.join(workdir, stale))
+        outs.append(run(binary, workdir, threads=threads, env=env))
+    return outs

@@ -47,3 +47,22 @@ for name, mesh, c in (("autoinc", "C3D8beam.msh", "C3D8beam.cnt"), ("t05_autoinc
     ncut = len(re.findall(r"State has been restored", r["stdout"]))
     print(name, len(r["log"]), "summaries;", len(r["sta"]), "sub-step rows, statuses", [x[2] for x in r["sta"]], "; cutbacks", ncut)
     shutil.rmtree(d)
+
+
+# examples/static/restart2/case02_resume: write a restart file every sub-step, stop after three, resume from the fourth (`!RESTART,
+# FREQUENCY=-1`) -- the continuation takes the device path with the history read from the file (the restart guard of
+# fsd_eligible was dead code).  Golden: FSTR.sta, step lines and 0.log of the RESUMED run of the unmodified program.
+outr = os.path.join(f1.DECKS, "restart2")
+os.makedirs(outr, exist_ok=True)
+for f in ("C3D8beam.msh", "C3D8beam.cnt", "C3D8beam_res.cnt"):
+    shutil.copy(os.path.join("/root/reference/examples/static/restart2/case02_resume", f), os.path.join(outr, f))
+d = tempfile.mkdtemp(prefix="restart2_")
+first, res = f1.run_restart_pair("fistr1_ref", outr, d, threads=4)
+assert first["returncode"] == 0 and res["returncode"] == 0, (first["stdout"][-2000:], res["stdout"][-2000:])
+assert "FrontISTR Completed !!" in res["stdout"] or "Number of substeps reached max number" in res["stdout"], res["stdout"][-3000:]   # ends at its SUBSTEPS = 100 bound
+shutil.copy(os.path.join(d, "0.log"), os.path.join(outr, "resumed_fistr1_ref_0.log"))
+shutil.copy(os.path.join(d, "FSTR.sta"), os.path.join(outr, "resumed_fistr1_ref_FSTR.sta"))
+with open(os.path.join(outr, "resumed_fistr1_ref_steps.txt"), "w") as fh:
+    fh.write("\n".join(f1.step_lines(res["stdout"])) + "\n")
+print("restart2: first run", [x[2] for x in first["sta"]], "; resumed", len(res["sta"]), "rows", [x[2] for x in res["sta"]][:12], "...", len(res["log"]), "summaries")
+shutil.rmtree(d)

@@ -282,3 +282,30 @@ def test_fistr1_autoinc_cutback_on_the_gpu(deck, mesh, cnt, cutbacks, assembly):
     assert len(r["log"]) == len(want)
     for a, c in zip(r["log"], want):
         assert f1.compare_step(a, c) == []
+
+
+@pytest.mark.parametrize("assembly", ["device", "host"])
+def test_fistr1_restart_continuation_on_the_gpu(assembly, tmp_path):
+    """examples/static/restart2/case02_resume through fistr1_hip: the first analysis writes a restart file every sub-step and stops
+    after its third; the second resumes from sub-step 4 (`!RESTART, FREQUENCY=-1`, fstr_solve_NLGEOM.f90:70-76).  The continuation
+    takes the device path: the quadrature-point history read from the file is what the first fstr_StiffMatrix pushes to the device
+    (fsd_init after fstr_read_restart).  The resumed run's FSTR.sta rows, increment / residual lines and 0.log against
+    the unmodified program's resumed run (make_autoinc_golden.py), element loops on the device and on the host."""
+    if not f1.have("fistr1_hip"):
+        pytest.skip("oracle/_ref/fistr1_hip not built (needs /root/reference at build time)")
+    deck = os.path.join(f1.DECKS, "restart2")
+    env = {"HECMW_GPU_REPORT": "1"} if assembly == "device" else {"HECMW_GPU_REPORT": "1", "HECMW_GPU_ASSEMBLY": "0"}
+    first, res = f1.run_restart_pair("fistr1_hip", deck, str(tmp_path), env=env)
+    for r in (first, res):
+        assert r["returncode"] == 0 and "reference CPU solver used" not in r["stdout"], r["stdout"][-2000:]
+        assert (DEVICE_ASSEMBLY in r["stdout"]) == (assembly == "device")
+    assert [x[2] for x in first["sta"]] == ["1F", "2F", "S", "S", "S"]
+    want_sta = f1.read_sta(os.path.join(deck, "resumed_fistr1_ref_FSTR.sta"))
+    assert [(x[0], x[1], x[2], x[3]) for x in res["sta"]] == [(x[0], x[1], x[2], x[3]) for x in want_sta]
+    want_lines = [l for l in open(os.path.join(deck, "resumed_fistr1_ref_steps.txt")).read().split("\n") if l.strip()]
+    bad = f1.compare_step_lines(f1.step_lines(res["stdout"]), want_lines, rtol=2e-3, floor=1e-7)
+    assert bad == [], bad[:5]
+    want = f1.read_log(os.path.join(deck, "resumed_fistr1_ref_0.log"))
+    assert len(res["log"]) == len(want) > 50
+    for a, c in zip(res["log"], want):
+        assert f1.compare_step(a, c) == []
