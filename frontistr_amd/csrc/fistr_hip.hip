@@ -241,6 +241,7 @@ static int context_init(fx_context *c) {
 struct FxOption { const char *name; void (*set)(fx_context *, double); };
 static const FxOption g_fx_options[] = {
     {"FX_ARENA_GB", [](fx_context *c, double v) { c->arena_min_bytes = v > 0.0 ? (size_t)(v * 1073741824.0) : 0; }},
+    {"FX_ARENA_GOOD_GBS", [](fx_context *c, double v) { c->arena_good_gbs = v; }},
     {"FX_ARENA_TRIES", [](fx_context *c, double v) { c->arena_tries = std::max(1, std::min(8, (int)v)); }},
     {"FX_ARENA_MAX_MB", [](fx_context *c, double v) { c->arena_max_bytes = (size_t)(std::max(0.0, v) * 1048576.0); }},
     {"FX_ARENA_THRESHOLD_MB", [](fx_context *c, double v) { c->arena_threshold = (size_t)(std::max(0.0, v) * 1048576.0); }},

@@ -350,6 +350,8 @@ contains
     integer(c_int) :: ierr
     real(c_float) :: ms
     type(fx_mesh_view) :: mesh
+    character(len=8) :: env
+    integer :: elen, estat
     fsd_stiffness = .false.
     fxb_matrix_on_device = .false.
     if (.not. fsd_eligible(hecMESH, hecMAT, fstrSOLID)) then
@@ -360,7 +362,9 @@ contains
       ierr = fx_assemble_c3d8_sections(fxb_context(hecMESH), mesh, int(size(lin_E), c_int32_t), lin_E, lin_nu, lin_emat, lin_elemopt, &
                                        c_null_ptr, 0_c_int32_t, c_null_ptr, c_null_ptr, c_null_ptr, ms)
       if (ierr /= 0) call fsd_fail('fx_assemble_c3d8_sections')
-      ierr = fx_update_c3d8_linear_prepare(fxb_context(hecMESH), int(hecMESH%n_elem, c_int32_t))   ! the stress update follows the solve: pin its staging meanwhile
+      call get_environment_variable('HECMW_GPU_UPDATE', env, elen, estat)
+      if (.not. (estat == 0 .and. elen > 0 .and. env(1:1) == '0')) &    ! the stress update follows the solve: pin its staging meanwhile
+        ierr = fx_update_c3d8_linear_prepare(fxb_context(hecMESH), int(hecMESH%n_elem, c_int32_t))
       fxb_matrix_on_device = .true.
       fsd_stiffness = .true.
       return

@@ -259,7 +259,9 @@ def test_fistr1_headline_workload_matches_the_reference(tmp_path):
     d = str(tmp_path / "deck")
     subprocess.run([sys.executable, os.path.join(root, "scripts", "fistr1_cube_deck.py"), d, "149", "--linear"], check=True, stdout=subprocess.DEVNULL)
     cnt = os.path.join(d, "cube.cnt")
-    open(cnt, "w").write(open(cnt).read().replace("ITERLOG=NO", "ITERLOG=YES"))
+    text = open(cnt).read().replace("ITERLOG=NO", "ITERLOG=YES")
+    assert "ITERLOG=YES" in text
+    open(cnt, "w").write(text)
     r = f1.run("fistr1_hip", d, threads=min(16, os.cpu_count() or 1), env={"HECMW_GPU_REPORT": "1"}, timeout=1500)
     assert r["returncode"] == 0 and "FrontISTR Completed !!" in r["stdout"], r["stdout"][-3000:]
     assert "fstr_StiffMatrix on the device" in r["stdout"] and "fstr_UpdateNewton on the device" in r["stdout"]
