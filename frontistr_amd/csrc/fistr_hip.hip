@@ -216,6 +216,8 @@ static inline int grid_for(int64_t n, int per_block = FX_BLOCK, int cap = 256 * 
 extern "C" const char *fx_last_error(void) { return g_fx_error.c_str(); }
 extern "C" const char *fx_version(void) { return "fistr_hip 0.1 (gfx950)"; }
 
+#include "fx_march.h"  // the plane march of the level-scheduled sweeps: kernels, program builder, launch
+
 static int context_init(fx_context *c) {
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&c->ev0));
@@ -277,6 +279,11 @@ static const FxOption g_fx_options[] = {
     {"FX_DF_POLL", [](fx_context *c, double v) { c->df_poll = (int)v; }},
     {"FX_DF_SLEEP", [](fx_context *c, double v) { c->df_sleep = std::max(0, (int)v); }},
     {"FX_DF_WPS", [](fx_context *c, double v) { c->df_wps = ((int)v == 2 || (int)v == 4) ? (int)v : 8; }},
+    {"FX_MARCH", [](fx_context *c, double v) { c->march_mode = std::max(0, std::min(2, (int)v)); }},
+    {"FX_MARCH_CHUNK", [](fx_context *c, double v) { c->march_chunk = std::max(0, (int)v); }},
+    {"FX_MARCH_WAVES", [](fx_context *c, double v) { c->march_waves = (int)v; }},
+    {"FX_MARCH_GRID", [](fx_context *c, double v) { c->march_grid = std::max(0, (int)v); }},
+    {"FX_MARCH_XCD", [](fx_context *c, double v) { c->march_xcd = (int)v != 0; }},
     {"FX_DEBUG_DF_FAIL", [](fx_context *c, double v) { c->dbg_df_fail = (int)v != 0; }},
     {"FX_DEBUG_ONECOLOR", [](fx_context *c, double v) { c->dbg_onecolor = (int)v != 0; }},
     {"FX_SSOR_NATURAL", [](fx_context *c, double v) { c->ssor_natural = (int)v != 0; }},
@@ -325,6 +332,13 @@ extern "C" int fx_create(int device, fx_context **out) {
     occ(2, k_tri_dataflow<8, 1, true>, 512); occ(2, k_tri_dataflow<8, 0, true>, 512); occ(2, k_tri_dataflow<8, 1, false>, 512); occ(2, k_tri_dataflow<8, 0, false>, 512);
     (void)hipGetLastError();
     for (int k = 0; k < 3; k++) c->df_grid_max[k] = std::max(1, c->n_cu * std::max(1, std::min(pc[k], 8)));
+    int pm[4] = {1, 1, 1, 1};
+    auto occm = [&](int k, auto kernel, int threads) {
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pm[k], kernel, threads, 0) != hipSuccess) pm[k] = 1;
+    };
+    occm(0, k_tri_march<2>, 64 * 3); occm(1, k_tri_march<4>, 64 * 5); occm(2, k_tri_march<6>, 64 * 7); occm(3, k_tri_march<8>, 64 * 9);
+    (void)hipGetLastError();
+    for (int k = 0; k < 4; k++) c->march_grid_max[k] = std::max(8, c->n_cu * std::max(1, std::min(pm[k], 2)));
   }
   *out = c;
   return 0;
@@ -423,6 +437,7 @@ static void free_precond(fx_context *c) {
   bell_free(c->ssor.L); bell_free(c->ssor.U); bell_free(c->ssor.H);
   dev_free(c->ssor.alu); dev_free(c->ssor.slot_node); dev_free(c->ssor.zs); dev_free(c->ssor.zb);
   dev_free(c->ssor.lu_D); dev_free(c->ssor.lu_AL); dev_free(c->ssor.lu_AU);
+  march_free(c->ssor.march);
   c->ssor = SsorDev();
   c->precond_valid = false;
   c->precond_valid_sweeps = false;
@@ -1636,6 +1651,9 @@ static int ilu_setup_symbolic(fx_context *c) {
   }
   dev_free(S.alu);
   if (dev_alloc(&S.alu, (size_t)(nslots / 64) * 576)) return FX_ERROR_RUNTIME;
+  pt.lap("level layouts");
+  if (march_build(c)) return FX_ERROR_RUNTIME;  // the same sweeps as a plane march (fx_march.h), when the structure and the cost model admit it
+  pt.lap("march programs");
   return 0;
 }
 
@@ -1650,6 +1668,7 @@ static int ilu_setup_numeric(fx_context *c, double sigma_diag, bool factor) {
     if (bell_fill_values(c, S.L) || bell_fill_values(c, S.U)) return FX_ERROR_RUNTIME;
     hipLaunchKernelGGL(k_alu_setup, dim3((S.nslots + 255) / 256), dim3(256), 0, c->stream, S.nslots, A.N, S.slot_node, A.D, sigma_diag, S.alu);
     HIP_TRY(hipGetLastError());
+    if (march_fill_values(c, A.AL, A.AU, sigma_diag)) return FX_ERROR_RUNTIME;
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
   }
@@ -1674,6 +1693,7 @@ static int ilu_setup_numeric(fx_context *c, double sigma_diag, bool factor) {
   hipLaunchKernelGGL(k_alu_setup, dim3((nslots + 255) / 256), dim3(256), 0, c->stream, nslots, A.N, S.slot_node, A.D, sigma_diag,
                      S.alu);
   HIP_TRY(hipGetLastError());
+  if (march_fill_values(c, S.lu_AL, S.lu_AU, sigma_diag)) return FX_ERROR_RUNTIME;
   HIP_TRY(hipStreamSynchronize(c->stream));
   dev_free(S.lu_D); dev_free(S.lu_AL); dev_free(S.lu_AU);  // the sweeps only stream the BELL copies
   return 0;
@@ -1751,6 +1771,23 @@ extern "C" int fx_placement_report(fx_context *c, double out[9]) {
   return 0;
 }
 
+// The plane march of this context's level-scheduled preconditioner (fx_march.h): out[0] 1 if the programs are built, [1] rows per
+// chunk, [2] chunks, [3] pair waves per workgroup, [4] / [5] rounds of the forward / backward program, [6] blocks gathered from
+// the LDS ring, [7] from memory, [8] of those from the row's own chunk, [9] / [10] the cost model's microseconds per half sweep as a
+// march / as dependency levels, [11] seconds the build took, [12] applies that took the march, [13] workgroups of the last launch,
+// [14] largest round (rows), [15] dependency levels.
+extern "C" int fx_march_report(fx_context *c, double out[16]) {
+  if (!c || !out) { g_fx_error = "fx_march_report: null argument"; return FX_ERROR_RUNTIME; }
+  const MarchDev &M = c->ssor.march;
+  for (int k = 0; k < 16; k++) out[k] = 0.0;
+  out[0] = M.ok ? 1 : 0; out[1] = M.S; out[2] = M.nchunks; out[3] = M.NW;
+  out[4] = (double)M.F.nrounds; out[5] = (double)M.B.nrounds;
+  out[6] = (double)M.near_blocks; out[7] = (double)M.far_blocks; out[8] = M.far_same_chunk;
+  out[9] = M.est_us; out[10] = M.est_level_us; out[11] = M.build_s;
+  out[12] = c->march_launches; out[13] = c->df_grid_last; out[14] = M.max_round_rows; out[15] = c->ssor.ncolor;
+  return 0;
+}
+
 // z = M^-1 r  (hecmw_precond_apply hecmw_precond.f90:75-123 with iterPREmax = 1; the
 // ZP/Z prologue is folded into the kernels).  want_dot: leave partials of r.z.
 // Returns the number of partials written (0 if none).
@@ -1775,6 +1812,12 @@ static int precond_apply_once(fx_context *c, const double *r, double *z, bool wa
     const bool full = (c->ord.kind == 1);  // Krylov vectors already colour-major: sweep in place on z
     const int32_t *sn = full ? (const int32_t *)nullptr : S.slot_node;
     double *zsweep = full ? z : S.zs, *znat = full ? (double *)nullptr : z;
+    if (level_sched(c) && c->df_mode >= 1 && S.march.ok && !full && (c->march_mode == 2 || (c->march_mode == 1 && c->df_wps == 8))) {  // its sums are those of 8 waves per slice
+      // plane march: chunks of rows per workgroup, in-chunk dependencies through LDS (fx_march.h); r.z by a separate dot
+      if (march_apply(c, r, z, gate_status(c))) return FX_ERROR_RUNTIME;
+      *nparts = 0;
+      return 0;
+    }
     if ((level_sched(c) && c->df_mode >= 1) || (c->precond_kind == 1 && c->df_mode >= 2)) {
       // one persistent launch: forward values in S.zs, backward values in z itself (colour-major Krylov vectors) or in
       // S.zb (+ z in the caller's numbering); both start as the sentinel pattern (0xFF bytes)

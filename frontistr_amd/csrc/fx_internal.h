@@ -84,6 +84,30 @@ struct Ordering {
 };
 
 // Multicolour SSOR state (hecmw_precond_SSOR_33.f90 module variables).
+// Plane march of the level-scheduled sweeps (fx_march.h): one direction's program.  The rows of a chunk (a contiguous range of the
+// natural numbering, one workgroup) are executed in ROUNDS -- the chunk's own dependency levels, split to at most R rows -- and the
+// matrix is stored in exactly that order: 8 lanes per row, lanes 0..6 one block pair each, lane 7 the LU of the diagonal block.
+struct MarchProg {
+  int64_t nrounds = 0;
+  int32_t *round_ptr = nullptr;  // device [nchunks + 1]: rounds of chunk c = [round_ptr[c], round_ptr[c + 1])
+  int32_t *rstart = nullptr;     // device [nrounds + 1]: march position of each round's first row
+  double *val = nullptr;         // device: per round [9][8 n] double2 (n = rows of the round)
+  int32_t *col = nullptr;        // device: int2 per lane (>= 0 far: row whose entry is gathered from memory; -1 padding;
+                                 //   <= -2 near: -(ring slot) - 2; lane 7: (row, 0))
+  int32_t *src = nullptr;        // device: int2 per lane, source codes of the two blocks (k_bell_fill's; lane 7: 3 * row)
+  std::vector<int32_t> h_round_ptr, h_rstart;
+};
+struct MarchDev {
+  bool ok = false;
+  int32_t S = 0, NW = 0, nchunks = 0;  // rows per chunk, pair waves per workgroup (8 rows each), chunks
+  MarchProg F, B;                      // forward (L) and backward (U) programs
+  double *zf = nullptr;                // forward sweep's vector, 3 N, natural numbering
+  double est_us = 0.0, est_level_us = 0.0;  // cost model: one half sweep as a march / as dependency levels
+  double build_s = 0.0;
+  int32_t max_round_rows = 0, far_same_chunk = 0;
+  int64_t near_blocks = 0, far_blocks = 0;
+};
+
 struct SsorDev {
   int32_t ncolor = 0;
   std::vector<int32_t> color_slice;  // slice range per colour: [color_slice[c], color_slice[c+1])
@@ -101,6 +125,7 @@ struct SsorDev {
   int32_t max_row_blocks = 0;        // ILU(0): largest number of off-diagonal blocks in a row (<= 32: lane-per-block factorisation)
   std::vector<int32_t> perm;         // new -> old (1-based), as the reference's perm(:)
   std::vector<int32_t> colorindex;   // COLORindex(0:ncolor)
+  MarchDev march;                    // level-scheduled sweeps as a plane march (fx_march.h)
 };
 
 struct DiagDev {
@@ -309,6 +334,13 @@ struct fx_context {
   bool dbg_df_fail = false;   // test hook (FX_DEBUG_DF_FAIL): the dataflow launches report a timeout at once
   int df_fallbacks = 0;       // times a timed-out dataflow sweep made this context fall back to the launch-per-level sweeps (fx_get_stats)
   int32_t *df_err = nullptr;  // device: raised by a sweep whose bounded spin ran out
+  // Plane march (fx_march.h, k_tri_march): the level-scheduled sweeps (ILU(0), natural-order SSOR) with whole chunks of rows per
+  // workgroup, dependencies inside a chunk through an LDS ring, between chunks through the sentinel-tagged vectors.  FX_MARCH=0 off,
+  // 1 (default) when the cost model prefers it to the per-slice hand-offs of k_tri_dataflow, 2 whenever the structure admits it;
+  // FX_MARCH_CHUNK rows per chunk (0 = from the matrix profile), FX_MARCH_WAVES pair waves per workgroup (0 = from the level sizes).
+  int march_mode = 1, march_chunk = 0, march_waves = 0, march_grid = 0, march_xcd = 1;
+  int march_grid_max[4] = {0, 0, 0, 0};  // co-resident workgroups of k_tri_march<2 / 4 / 6 / 8 pair waves>
+  int march_launches = 0;                // applies that took the march (fx_march_report)
   // software-pipelined row loop (2-deep: values + gathers of pair i+1 and ids of pair i+2 in flight while pair i
   // is multiplied; 116 VGPRs, 4 waves/SIMD).  Measured on MI355X at 10.1M DOF with the final layout (odd-tail BELL,
   // non-temporal stream loads): SpMV 1.14-1.17 -> 1.105-1.11 ms; colour sweeps 1.685 -> 1.61 ms per apply.

@@ -218,6 +218,18 @@ class SolverContext:
                 "spmv_values_in_arena": bool(out[3]), "lower_values_in_arena": bool(out[4]), "upper_values_in_arena": bool(out[5]),
                 "spmv_value_bytes": int(out[6]), "arenas_timed": int(out[7]), "kept_ms": float(out[8])}
 
+    def march_report(self):
+        """The plane march of the level-scheduled sweeps of this context (fx_march_report)."""
+        out = (C.c_double * 16)()
+        _chk(lib().fx_march_report(self.h, out))
+        keys = ("built", "chunk_rows", "chunks", "pair_waves", "rounds_fwd", "rounds_bwd", "near_blocks", "far_blocks",
+                "far_same_chunk", "est_us", "est_level_us", "build_s", "applies", "grid", "max_round_rows", "levels")
+        d = {k: float(out[i]) for i, k in enumerate(keys)}
+        for k in keys:
+            if k not in ("est_us", "est_level_us", "build_s"):
+                d[k] = int(d[k])
+        return d
+
     def solve_resident(self, hecMAT, want_history=True):
         info = _SolveInfo()
         maxit = int(hecMAT.Iarray[0])

@@ -154,6 +154,13 @@ int fx_get_stats(fx_context *ctx, int64_t out[16]);
  * value array, [7] arenas the one-off verification timed (the loop's SpMV on the arena, 5 ms; a slow one is replaced by another arena,
  * at most FX_ARENA_TRIES = 4, the fastest kept), [8] the SpMV's ms on the arena kept.  FX_ARENA_GB (0 = off, default 32 = at least 32 GiB). */
 int fx_placement_report(fx_context *ctx, double out[9]);
+/* The plane march of the level-scheduled sweeps (ILU(0) hecmw_precond_BILU_33.f90:90-157, natural-order SSOR
+ * hecmw_precond_SSOR_33.f90:300-410; csrc/fx_march.h): out[0] 1 if this context's preconditioner has the march programs, [1] rows per
+ * chunk, [2] chunks, [3] pair waves per workgroup, [4] / [5] rounds of the forward / backward program, [6] blocks gathered from the LDS
+ * ring, [7] from memory, [8] of those in the row's own chunk, [9] / [10] the cost model's microseconds per half sweep as a march / as
+ * dependency levels, [11] seconds the build took, [12] applies that took the march, [13] workgroups of the last launch, [14] rows of the
+ * largest round, [15] dependency levels.  FX_MARCH = 0 off, 1 (default) when the cost model prefers it, 2 whenever the structure admits it. */
+int fx_march_report(fx_context *ctx, double out[16]);
 /* The passes of the auto-SIGMA_DIAG / METHOD2 loop of the last solve on this context (hecmw_solver_Iterative.f90:117-157: banner
  * :125 before every pass, 'Increasing SIGMA_DIAG to' :149 before a retry): METHOD, the SIGMA_DIAG in effect and the number of
  * residual-history lines of every pass, and the lines themselves.  fx_solve's own `hist` holds the LAST pass. */

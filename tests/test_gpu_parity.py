@@ -1079,3 +1079,124 @@ def test_value_arena_places_reuses_and_falls_back(hip, monkeypatch):
     p = solve(ctx, "cube4", 1, 1, 4)
     assert p["arena_bytes"] == 0 and not p["spmv_values_in_arena"] and p["arrays_in_arena"] == 0
     ctx.close()
+
+
+# --------------------------------------------------------------------------------------------------------------------------
+# plane march of the level-scheduled sweeps (csrc/fx_march.h)
+# --------------------------------------------------------------------------------------------------------------------------
+def _march_system(hip, kind):
+    """A resident system for the march tests: cubes of several sizes (plane = (n+1)^2 rows) and the mesher-made hex mesh of
+    tutorial 05 (unstructured numbering)."""
+    import os
+    from frontistr_amd.mesh import CubeMesh
+    if kind == "necking":
+        g = np.load(os.path.join(os.path.dirname(__file__), "golden", "nl_necking.npz"))
+        coord, conn = g["coord"], g["conn"]
+        bc = (g["bc_node"], g["bc_dof"], g["bc_val"] * 0.01)
+        load = np.zeros(3 * coord.shape[0])
+        E, nu = 206900.0, 0.29
+    else:
+        mesh = CubeMesh(kind[0], skew=kind[1])
+        coord, conn, bc, load, E, nu = mesh.coord, mesh.conn, mesh.dirichlet(), mesh.load(), 210000.0, 0.3
+    hm = hip.hecmwST_local_mesh(n_node=coord.shape[0])
+    hm.elem_node_item = conn.ravel()
+    m = hip.hecmw_mat_con(hm, hip.hecmwST_matrix())
+    return m, (coord, conn, E, nu, load, bc)
+
+
+@pytest.mark.parametrize("pc", [10, 1])
+@pytest.mark.parametrize("kind", [(6, 0.05), (12, 0.0), (24, 0.03), "necking"])
+def test_march_sweeps_equal_level_sweeps_bitwise(hip, kind, pc):
+    """k_tri_march (fx_march.h: chunks of rows per workgroup, in-chunk dependencies through an LDS ring, chunk-to-chunk through the
+    tagged vectors) gives every row the operands of k_tri_dataflow / k_ssor_color_split with 8 waves per slice in the same order:
+    z = M^-1 r bit for bit, for ILU(0) and the natural-order SSOR, whatever the chunk size (aligned with the mesh planes or not,
+    one chunk, more chunks than workgroups), the number of pair waves, the grid and the chunk -> workgroup map.  The program
+    builder's own replay (march_check) runs at these sizes.  A mesh whose rows have more than 14 lower blocks keeps the other kernels."""
+    m, (coord, conn, E, nu, load, bc) = _march_system(hip, kind)
+    N = m.N
+    r = np.cos(0.37 * np.arange(3 * m.NP) + 0.1)
+    plane = (kind[0] + 1) ** 2 if kind != "necking" else 0
+    configs = [dict(), dict(FX_MARCH_WAVES=2), dict(FX_MARCH_CHUNK=N, FX_MARCH_WAVES=4), dict(FX_MARCH_CHUNK=97, FX_MARCH_WAVES=6, FX_MARCH_XCD=0),
+               dict(FX_MARCH_CHUNK=max(64, N // 40), FX_MARCH_WAVES=8, FX_MARCH_GRID=8)]
+    if plane:
+        configs += [dict(FX_MARCH_CHUNK=plane, FX_MARCH_WAVES=4), dict(FX_MARCH_CHUNK=(plane + 1) // 2, FX_MARCH_WAVES=2, FX_MARCH_GRID=16)]
+    ref = None
+    for cfg in configs:
+        ctx = hip.SolverContext()
+        ctx.set_option("FX_MARCH", 2)
+        for k, v in cfg.items():
+            ctx.set_option(k, v)
+        if pc == 1:
+            ctx.set_option("FX_SSOR_NATURAL", 1)
+        ctx.upload(m, what=hip.FX_UP_PROFILE)
+        ctx.assemble_c3d8(coord, conn, E, nu, elemopt=1, load=load, bc=bc)
+        m.Iarray[1] = 2; m.Iarray[2] = pc
+        ctx.precond_setup(m)
+        rep = ctx.march_report()
+        z = ctx.precond_apply(r)
+        ctx.precond_apply(np.sin(1.7 * r) + 0.5)          # other data in between: every apply re-initialises the tags
+        z2 = ctx.precond_apply(r)
+        assert np.array_equal(z, z2) and np.all(np.isfinite(z[:3 * N]))
+        applies = ctx.march_report()["applies"]
+        ctx.set_option("FX_MARCH", 0)
+        zd = ctx.precond_apply(r)                           # k_tri_dataflow, 8 waves per slice
+        ctx.set_option("FX_DATAFLOW", 0)
+        zl = ctx.precond_apply(r)                           # one launch per level
+        st = ctx.stats()
+        ctx.close()
+        assert st["df_fallbacks"] == 0
+        assert np.array_equal(zd[:3 * N], zl[:3 * N])
+        if kind == "necking" and not rep["built"]:
+            assert applies == 0                             # rows of up to 27 blocks: more than 7 pairs in a half -- not this kernel's case
+        else:
+            assert rep["built"] == 1 and applies == 3, (cfg, rep)
+            assert rep["chunks"] == -(-N // rep["chunk_rows"]) and rep["rounds_fwd"] >= rep["chunks"]
+            if "FX_MARCH_CHUNK" in cfg:
+                assert rep["chunk_rows"] == min(N, cfg["FX_MARCH_CHUNK"])
+            if "FX_MARCH_WAVES" in cfg:
+                assert rep["pair_waves"] == cfg["FX_MARCH_WAVES"] and rep["max_round_rows"] <= 8 * cfg["FX_MARCH_WAVES"]
+        assert np.array_equal(z[:3 * N], zd[:3 * N]), (cfg, rep)
+        if ref is None:
+            ref = z[:3 * N].copy()
+        assert np.array_equal(z[:3 * N], ref)
+
+
+@pytest.mark.parametrize("meth,pc", [(2, 10), (1, 1)])
+def test_march_in_the_krylov_loops(hip, oracle, meth, pc):
+    """BiCGSTAB + ILU(0) and CG + natural-order SSOR with the march inside the device-resident loop (r.z by a separate dot: the
+    histories agree with the dataflow sweeps' to rounding, not bit for bit), against the oracle; and a march whose bounded wait
+    runs out (FX_DEBUG_DF_FAIL) falls back to the level sweeps like a dataflow sweep does."""
+    from oracle.refrun import default_params
+    m, (coord, conn, E, nu, load, bc) = _march_system(hip, (12, 0.04))
+    A = oracle.assemble(1, coord, conn, E, nu, bc=bc, load=load)
+    I, R = default_params(method=meth, precond=pc)
+    o = oracle.solve_iterative(A, I, R, nthreads=1)
+    out = {}
+    for tag in ("march", "dataflow", "fail"):
+        ctx = hip.SolverContext()
+        ctx.set_option("FX_MARCH", 0 if tag == "dataflow" else 2)
+        if pc == 1:
+            ctx.set_option("FX_SSOR_NATURAL", 1)
+        ctx.upload(m, what=hip.FX_UP_PROFILE)
+        ctx.assemble_c3d8(coord, conn, E, nu, elemopt=1, load=load, bc=bc)
+        m.Iarray[0] = 10000; m.Iarray[1] = meth; m.Iarray[2] = pc
+        if tag == "fail":
+            ctx.precond_setup(m)
+            ctx.set_option("FX_DEBUG_DF_FAIL", 1)
+        code = ctx.solve_resident(m)
+        ctx.download_x(m)
+        out[tag] = (code, ctx.info.iterations, m.X.copy(), np.array(ctx.history), ctx.march_report(), ctx.stats())
+        ctx.close()
+    for tag in out:
+        code, it, X, hist, rep, st = out[tag]
+        assert code == 0 and o["code"] == 0
+        assert abs(it - o["iter"]) <= max(2, 0.15 * o["iter"] if meth == 2 else 1), (tag, it, o["iter"])
+        assert relerr(X, o["X"]) < 1e-7
+        k = min(10, len(hist), len(o["history"]))
+        assert np.all(np.abs(hist[:k] - o["history"][:k]) <= 1e-9 * o["history"][:k])
+    # (applies counts the enqueues: at this size the iteration is a replayed graph, captured once or twice per solve)
+    assert out["march"][4]["built"] == 1 and out["march"][4]["applies"] >= 1 and out["march"][5]["df_fallbacks"] == 0
+    assert out["dataflow"][4]["applies"] == 0
+    assert out["fail"][5]["df_fallbacks"] == 1 and out["fail"][5]["df_mode"] == 0
+    k = min(len(out["march"][3]), len(out["dataflow"][3]), 10)
+    assert np.all(np.abs(out["march"][3][:k] - out["dataflow"][3][:k]) <= 1e-11 * out["dataflow"][3][:k])
