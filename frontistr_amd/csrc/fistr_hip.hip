@@ -336,9 +336,9 @@ extern "C" int fx_create(int device, fx_context **out) {
     auto occm = [&](int k, auto kernel, int threads) {
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pm[k], kernel, threads, 0) != hipSuccess) pm[k] = 1;
     };
-    occm(0, k_tri_march<2>, 64 * 3); occm(1, k_tri_march<4>, 64 * 5); occm(2, k_tri_march<6>, 64 * 7); occm(3, k_tri_march<8>, 64 * 9);
+    occm(0, k_tri_march<1>, 64 * 2); occm(1, k_tri_march<2>, 64 * 3); occm(2, k_tri_march<3>, 64 * 4); pm[3] = pm[2];
     (void)hipGetLastError();
-    for (int k = 0; k < 4; k++) c->march_grid_max[k] = std::max(8, c->n_cu * std::max(1, std::min(pm[k], 2)));
+    for (int k = 0; k < 4; k++) c->march_grid_max[k] = std::max(8, c->n_cu * std::max(1, std::min(pm[k], 4)));
   }
   *out = c;
   return 0;

@@ -224,3 +224,60 @@ extern "C" int fx_debug_spmv_ms(fx_context *c, int kind, int xsel, int ysel, int
   *ms_out = ms / std::max(nrepeat, 1);
   return 0;
 }
+
+// One preconditioner apply as a traced plane march (fx_march.h): per chunk 8 words -- forward start / end, backward start / end in
+// ticks of the 100 MHz constant clock (relative to the earliest start), rounds of wave 0 that found an entry missing and its re-reads,
+// forward / backward.  out: 8 * chunks doubles.
+extern "C" int fx_debug_march_trace(fx_context *c, double *out, int32_t cap, int32_t *nchunks) {
+  HIP_TRY(hipSetDevice(c->device));
+  MarchDev &M = c->ssor.march;
+  if (!M.ok) { g_fx_error = "fx_debug_march_trace: no march programs on this context"; return FX_ERROR_RUNTIME; }
+  if (ensure_work(c)) return FX_ERROR_RUNTIME;
+  *nchunks = M.nchunks;
+  if (cap < 8 * M.nchunks) { g_fx_error = "fx_debug_march_trace: buffer too small"; return FX_ERROR_RUNTIME; }
+  unsigned long long *tr = nullptr;
+  if (dev_alloc(&tr, (size_t)8 * M.nchunks)) return FX_ERROR_RUNTIME;
+  HIP_TRY(hipMemsetAsync(tr, 0, (size_t)64 * M.nchunks, c->stream));
+  HIP_TRY(hipMemsetAsync(c->W[6], 0, (size_t)24 * c->A.NP, c->stream));
+  int rc = march_apply(c, c->W[6], c->W[7], nullptr, tr);
+  if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = FX_ERROR_RUNTIME;
+  std::vector<unsigned long long> h((size_t)8 * M.nchunks);
+  if (!rc && hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = FX_ERROR_RUNTIME;
+  dev_free(tr);
+  if (rc) return rc;
+  unsigned long long t0 = ~0ull;
+  for (int32_t k = 0; k < M.nchunks; k++) if (h[8 * k]) t0 = std::min(t0, h[8 * k]);
+  for (int32_t k = 0; k < M.nchunks; k++) {
+    for (int j = 0; j < 4; j++) out[8 * k + j] = h[8 * k + j] ? (double)(h[8 * k + j] - t0) : -1.0;
+    for (int j = 4; j < 8; j++) out[8 * k + j] = (double)h[8 * k + j];
+  }
+  return 0;
+}
+
+// Per-round timeline of one chunk's forward sweep in a traced march apply: out[k] = microseconds (from the workgroup's entry into the kernel) at which
+// round k passed its barrier, negative if that round had to wait for a far entry.  Returns the number of rounds in *nrounds.
+extern "C" int fx_debug_march_rounds(fx_context *c, int32_t chunk, double *out, int32_t cap, int32_t *nrounds) {
+  HIP_TRY(hipSetDevice(c->device));
+  MarchDev &M = c->ssor.march;
+  if (!M.ok || chunk < 0 || chunk >= M.nchunks) { g_fx_error = "fx_debug_march_rounds: no march programs / no such chunk"; return FX_ERROR_RUNTIME; }
+  if (ensure_work(c)) return FX_ERROR_RUNTIME;
+  const int32_t nr = M.F.h_round_ptr[chunk + 1] - M.F.h_round_ptr[chunk];
+  *nrounds = nr;
+  if (cap < nr) { g_fx_error = "fx_debug_march_rounds: buffer too small"; return FX_ERROR_RUNTIME; }
+  unsigned long long *tr = nullptr;
+  if (dev_alloc(&tr, (size_t)nr + 1)) return FX_ERROR_RUNTIME;
+  HIP_TRY(hipMemsetAsync(tr, 0, ((size_t)nr + 1) * 8, c->stream));
+  HIP_TRY(hipMemsetAsync(c->W[6], 0, (size_t)24 * c->A.NP, c->stream));
+  int rc = march_apply(c, c->W[6], c->W[7], nullptr, nullptr, tr, chunk);
+  if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = FX_ERROR_RUNTIME;
+  std::vector<unsigned long long> h((size_t)nr + 1);
+  if (!rc && hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = FX_ERROR_RUNTIME;
+  dev_free(tr);
+  if (rc) return rc;
+  const unsigned long long mask = ~(1ull << 63), t0 = h[nr];  // the workgroup's entry into the kernel
+  for (int32_t k = 0; k < nr; k++) {
+    const double us = 0.01 * (double)((h[k] & mask) - t0);
+    out[k] = (h[k] >> 63) ? -us - 1e-9 : us;
+  }
+  return 0;
+}

@@ -327,7 +327,10 @@ struct fx_context {
   // Round 3, same context (scripts/r3/ab_opts.py, ILU(0) at 10.1M DOF): sweep vectors in the [slice][k][lane] layout (df_soa) 4.73 -> 4.44 ms
   // per apply; with that layout one workgroup per CU instead of one per two 4.44 -> 4.27; no sleep between polls 4.27 -> 4.20; the
   // hand-off vectors in uncached device memory 4.20 -> 4.15 (not kept); re-reading all entries per poll 5.11; 4 waves per slice 5.04.
-  int df_mode = 1, df_grid = 0, df_wps = 8, df_poll = 1, df_sleep = 0;
+  // Round 4: the re-reads of a polling pass are issued together (no branch, hence no wait, between them: df_gather) -- one round trip per
+  // pass instead of one per missing entry: 4.19 -> 3.43 ms per apply; with that, re-reading every entry per pass (FX_DF_POLL=0) is the
+  // faster form, 3.33 ms (scripts/r3/ab_opts.py, same context), and the default.
+  int df_mode = 1, df_grid = 0, df_wps = 8, df_poll = 0, df_sleep = 0;
   bool df_soa = true;         // private sweep vectors of the dataflow sweeps in the [slice][k][lane] layout (FX_DF_SOA=0: 3 s + k)
   int df_grid_max[3] = {128, 128, 128};  // co-resident workgroups of k_tri_dataflow<2 / 4 / 8 waves> (occupancy query at fx_create)
   int df_grid_last = 0;       // workgroups of the last dataflow launch (after the co-residency clamp)
@@ -335,11 +338,12 @@ struct fx_context {
   int df_fallbacks = 0;       // times a timed-out dataflow sweep made this context fall back to the launch-per-level sweeps (fx_get_stats)
   int32_t *df_err = nullptr;  // device: raised by a sweep whose bounded spin ran out
   // Plane march (fx_march.h, k_tri_march): the level-scheduled sweeps (ILU(0), natural-order SSOR) with whole chunks of rows per
-  // workgroup, dependencies inside a chunk through an LDS ring, between chunks through the sentinel-tagged vectors.  FX_MARCH=0 off,
-  // 1 (default) when the cost model prefers it to the per-slice hand-offs of k_tri_dataflow, 2 whenever the structure admits it;
-  // FX_MARCH_CHUNK rows per chunk (0 = from the matrix profile), FX_MARCH_WAVES pair waves per workgroup (0 = from the level sizes).
-  int march_mode = 1, march_chunk = 0, march_waves = 0, march_grid = 0, march_xcd = 1;
-  int march_grid_max[4] = {0, 0, 0, 0};  // co-resident workgroups of k_tri_march<2 / 4 / 6 / 8 pair waves>
+  // workgroup, dependencies inside a chunk through an LDS ring, between chunks through the sentinel-tagged vectors.  FX_MARCH=0 (default)
+  // off: bit-identical to k_tri_dataflow but, as measured at 10.1 M DOF, slower (6.3 against 3.3 ms per apply; DESIGN.md section 4 has the
+  // per-round timeline); 1 when the cost model prefers it, 2 whenever the structure admits it.  FX_MARCH_CHUNK rows per chunk (0 = from
+  // the matrix profile), FX_MARCH_WAVES pair waves per workgroup (1, 2, 3; 0 = from the level sizes).
+  int march_mode = 0, march_chunk = 0, march_waves = 0, march_grid = 0, march_xcd = 1;
+  int march_grid_max[4] = {0, 0, 0, 0};  // co-resident workgroups of k_tri_march<1 / 2 / 3 pair waves>
   int march_launches = 0;                // applies that took the march (fx_march_report)
   // software-pipelined row loop (2-deep: values + gathers of pair i+1 and ids of pair i+2 in flight while pair i
   // is multiplied; 116 VGPRs, 4 waves/SIMD).  Measured on MI355X at 10.1M DOF with the final layout (odd-tail BELL,

@@ -912,12 +912,21 @@ __device__ __forceinline__ void df_gather(const double *__restrict__ zs, const i
   for (unsigned spins = 1;; spins++) {
     for (int q = 0; q < nsleep; q++) __builtin_amdgcn_s_sleep(1);  // 64 clocks each
     any = false;
+    // all re-reads of a pass in flight together -- an entry that is not re-read loads the row's own slot instead, so that there is no
+    // branch (and no wait) between the loads: one round trip per pass, not one per missing entry
+    double v[3 * NB];
+#pragma unroll
+    for (int e = 0; e < 3 * NB; e++) {
+      const bool need = col[e / 3] != self;
+      const bool rd = POLL == 0 ? need : miss[e];
+      v[e] = df_load(zs + df_ix<SOA>(rd ? col[e / 3] : self) + (e % 3) * DF_ST(SOA));
+    }
 #pragma unroll
     for (int e = 0; e < 3 * NB; e++) {
       const bool need = col[e / 3] != self;
       if (POLL == 0 ? need : miss[e]) {
-        x[e] = df_load(zs + df_ix<SOA>(col[e / 3]) + (e % 3) * DF_ST(SOA));
-        miss[e] = __double_as_longlong(x[e]) == FX_DF_SENTINEL;
+        x[e] = v[e];
+        miss[e] = __double_as_longlong(v[e]) == FX_DF_SENTINEL;
         any |= miss[e];
       }
     }

@@ -32,10 +32,13 @@ struct MarchSide { const int32_t *round_ptr, *rstart; const double2 *val; const 
 struct MarchArgs {
   MarchSide F, B;
   int32_t nchunks;
-  const double *r;
+  const double *r, *dummy;  // dummy: three zeros, what a lane that gathers nothing reads
   double *zf, *z;
   int32_t *err;
   int nsleep, xcd;
+  unsigned long long *rtrace;  // diagnostics: per round of the forward sweep of chunk rtrace_chunk: ticks at the barrier, bit 63 = the round waited
+  int rtrace_chunk;
+  unsigned long long *trace;  // diagnostics (fx_debug_march_trace): per chunk 8 words -- forward start / end, backward start / end (100 MHz ticks), rounds that had to wait and polls, forward / backward
 };
 
 __device__ __forceinline__ void march_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -85,19 +88,20 @@ __global__ __launch_bounds__(256) void k_march_fill(const int32_t *__restrict__ 
 }
 
 // The pair waves of one chunk, one direction.  r0 <= rounds < r1 (r1 > r0).  Barriers executed: r1 - r0 + 1.
-// Software pipeline, all in registers, two buffer sets used alternately (the loop is unrolled by two: a loaded value is never copied,
-// so no wait for a prefetch sits at the end of a round):
-//   round rho consumes  a, k, x, f   = values, column codes, far entries, right-hand side of round rho (loaded during round rho - 1)
-//                       fa_use       = column codes of round rho + 1 (loaded during round rho - 1): the ADDRESSES of its far entries
-//   and issues          an, kn, xn, fn for round rho + 1, fa_load = column codes of round rho + 2.
-// Round descriptors are scalars: [rsA, rsB) this round's march positions, [rsN, rsNe) the next, [rsM, rsMe) the one after; the row
-// count of round rho + 3 rides in the spare half of the finishing lanes' column codes (0 = past the end: the last round again).
+// Software pipeline, all in registers.  The matrix stream (values + column codes) does not depend on the sweep: it is loaded THREE rounds
+// ahead into four buffers used in turn; the far entries and the right-hand side of a round are loaded ONE round ahead (their addresses
+// are the column codes of the next round, long there) into two buffers.  The loop is unrolled by four, so a loaded value is never
+// copied and no wait for a prefetch sits at the end of a round.  Loads return in order: within a round the far gathers are issued
+// before the stream loads, so waiting for them does not wait for the stream.
+// Round descriptors are scalars ([s, e) = march positions of the rounds rho .. rho + 3); the row count of round rho + 4 rides in the spare
+// half of the finishing lanes' column codes (0 = past the chunk's end: the last round again).
 template <bool FWD, int NW>
 struct MarchPairs {
   static constexpr int R = 8 * NW;
+  struct Buf { double2 a[9]; int2 k; };
   const MarchSide &P;
   const double *__restrict__ rvec;
-  const double *zsrc, *zown;
+  const double *zsrc, *zown, *dummy;
   double *ring;
   int32_t *ringrow, *ringn;
   double (*scr)[4][64];
@@ -105,28 +109,43 @@ struct MarchPairs {
   bool &dead;
   const int nsleep;
   const int t, lane, w, g, q, gk, lead;
-  int rsA, rsB, rsN, rsNe, rsM, rsMe;
+  int sA, eA, sB, eB, sC, eC, sD, eD;
+  unsigned waited = 0, polls = 0;  // diagnostics: rounds of this wave that found an entry missing, re-reads
+  unsigned long long *rtr = nullptr;
 
-  __device__ __forceinline__ MarchPairs(const MarchSide &P_, const double *rvec_, const double *zsrc_, const double *zown_, double *ring_,
-                                        int32_t *ringrow_, int32_t *ringn_, double (*scr_)[4][64], int32_t *err_, bool &dead_, int nsleep_)
-      : P(P_), rvec(rvec_), zsrc(zsrc_), zown(zown_), ring(ring_), ringrow(ringrow_), ringn(ringn_), scr(scr_), err(err_), dead(dead_),
-        nsleep(nsleep_), t(threadIdx.x), lane(threadIdx.x & 63), w(threadIdx.x >> 6), g(threadIdx.x & 7), q(threadIdx.x >> 3),
+  __device__ __forceinline__ MarchPairs(const MarchSide &P_, const double *rvec_, const double *zsrc_, const double *zown_,
+                                        const double *dummy_, double *ring_, int32_t *ringrow_, int32_t *ringn_, double (*scr_)[4][64],
+                                        int32_t *err_, bool &dead_, int nsleep_)
+      : P(P_), rvec(rvec_), zsrc(zsrc_), zown(zown_), dummy(dummy_), ring(ring_), ringrow(ringrow_), ringn(ringn_), scr(scr_), err(err_),
+        dead(dead_), nsleep(nsleep_), t(threadIdx.x), lane(threadIdx.x & 63), w(threadIdx.x >> 6), g(threadIdx.x & 7), q(threadIdx.x >> 3),
         gk((threadIdx.x & 7) < 2 ? (threadIdx.x & 7) : 2), lead((threadIdx.x & 63) | 7) {}
 
-  __device__ __forceinline__ int2 load_cols(int rs, int re) const {
-    const int nl = 8 * (re - rs);
-    return ld_stream(P.col + (size_t)8 * rs + (t < nl ? t : nl - 1));
-  }
-  __device__ __forceinline__ void load_vals(int rs, int re, double2 (&v)[9]) const {
-    const int nl = 8 * (re - rs);
-    const double2 *p = P.val + (size_t)72 * rs + (t < nl ? t : nl - 1);
+  // values and column codes of the round [s, e): one contiguous kilobyte per wave and load (uniform base + 32-bit lane offset)
+  __device__ __forceinline__ void load_stream(int s, int e, Buf &b) const {
+    const unsigned nl = 8u * (unsigned)(e - s), tt = (unsigned)t < nl ? (unsigned)t : nl - 1u;
+    const char *vb = (const char *)(P.val + (size_t)72 * s), *cb = (const char *)(P.col + (size_t)8 * s);
+    b.k = ld_stream((const int2 *)(cb + 8u * tt));  // first: the codes are wanted a round before the values (as addresses of the far gathers)
+#ifdef FX_MARCH_EXP_NOVALS  // timing experiment: one value word instead of nine
+    b.a[0] = ld_stream((const double2 *)(vb + 16u * tt));
 #pragma unroll
-    for (int e = 0; e < 9; e++) v[e] = ld_stream(p + (size_t)e * nl);
-  }
-  __device__ __forceinline__ void load_far(const int2 &c, double (&v)[6]) const {  // every lane loads: lanes that gather nothing read entry 0
-    const double *pa = zsrc + (size_t)3 * ((g < 7 && c.x >= 0) ? c.x : 0), *pb = zsrc + (size_t)3 * ((g < 7 && c.y >= 0) ? c.y : 0);
+    for (int i = 1; i < 9; i++) b.a[i] = b.a[0];
+#else
 #pragma unroll
-    for (int k = 0; k < 3; k++) { v[k] = df_load(pa + k); v[3 + k] = df_load(pb + k); }
+    for (int i = 0; i < 9; i++) b.a[i] = ld_stream((const double2 *)(vb + (16u * tt + 16u * (unsigned)i * nl)));
+#endif
+  }
+  // the far entries of the round whose column codes are c and which has nrows rows: lanes that gather nothing read the dummy entry
+  __device__ __forceinline__ void load_far(const int2 &c, int nrows, double (&v)[6]) const {
+    const bool on = g < 7 && q < nrows;
+    const double *pa = (on && c.x >= 0) ? zsrc + (size_t)3 * c.x : dummy, *pb = (on && c.y >= 0) ? zsrc + (size_t)3 * c.y : dummy;
+#if defined(FX_MARCH_EXP_NOFAR)  // timing experiment: no far gathers
+    for (int i = 0; i < 6; i++) v[i] = 1e-3 * (double)(c.x + i);
+#elif defined(FX_MARCH_EXP_FARPLAIN)  // timing experiment: far gathers as ordinary cached loads
+    for (int i = 0; i < 3; i++) { v[i] = pa[i]; v[3 + i] = pb[i]; }
+#else
+#pragma unroll
+    for (int i = 0; i < 3; i++) { v[i] = df_load(pa + i); v[3 + i] = df_load(pb + i); }
+#endif
   }
   // lanes 0..2 of a row: component g of its right-hand side (forward) / of its own forward value (backward)
   __device__ __forceinline__ double load_f(const int2 &c) const {
@@ -135,51 +154,90 @@ struct MarchPairs {
     return FWD ? ld_stream(p) : df_load(p);
   }
 
-  __device__ __forceinline__ void round(const int rl_local, double2 (&a)[9], int2 &k, double (&x)[6], double &f, const int2 &fa_use,
-                                        double2 (&an)[9], int2 &kn, double (&xn)[6], double &fn, int2 &fa_load) {
-    fa_load = load_cols(rsM, rsMe);  // first: it is the first thing the next round waits for (loads return in order)
-    load_vals(rsN, rsNe, an);
-    kn = load_cols(rsN, rsNe);
-    load_far(fa_use, xn);
-    fn = load_f(fa_use);
+  __device__ __forceinline__ void round(const int rl_local, const Buf &cur, const Buf &nxt, Buf &ld, double (&x)[6], double &f, double (&xn)[6],
+                                        double &fn) {
+    load_far(nxt.k, eB - sB, xn);
+    fn = load_f(nxt.k);
     march_lds_barrier();  // the ring holds the previous round
-    const int n = rsB - rsA;
+    const int n = eA - sA;
     const bool act = q < n;
-    const int cx = k.x, cy = k.y;
+    const int cx = cur.k.x, cy = cur.k.y;
+    bool wflag = false;
     {
-      const bool farx = act && g < 7 && cx >= 0, fary = act && g < 7 && cy >= 0, ownf = !FWD && act && g < 3;
-      bool m[7];
-      bool any = false;
+      // cheap test first: the tag is all ones, and lanes that need nothing have read the dummy entry (0.0)
+      unsigned h = (unsigned)__double2hiint(x[0]);
 #pragma unroll
-      for (int i = 0; i < 3; i++) { m[i] = farx && march_tag(x[i]); m[3 + i] = fary && march_tag(x[3 + i]); any |= m[i] | m[3 + i]; }
-      m[6] = ownf && march_tag(f);
-      any |= m[6];
-      if (__any(any) && !dead) {  // a far entry (or this row's own forward value) is not published yet: re-read what is missing
-        const int row = __shfl(cx, lead, 64);
-        unsigned long long t0 = 0;
-        for (unsigned spins = 1;; spins++) {
-          for (int s = 0; s < nsleep; s++) __builtin_amdgcn_s_sleep(1);
-          any = false;
+      for (int i = 1; i < 6; i++) h = max(h, (unsigned)__double2hiint(x[i]));
+      if (!FWD) h = max(h, (unsigned)__double2hiint(f));
+      bool any = h == 0xFFFFFFFFu;
+#ifdef FX_MARCH_EXP_NOPOLL  // timing experiment: never wait
+      any = false;
+#endif
+      if (__any(any) && !dead) {  // a far entry (or this row's own forward value) may not be published yet: look exactly, re-read what is missing
+        const bool farx = act && g < 7 && cx >= 0, fary = act && g < 7 && cy >= 0, ownf = !FWD && act && g < 3;
+        bool m[7];
+        any = false;
 #pragma unroll
-          for (int i = 0; i < 3; i++) {
-            if (m[i]) { x[i] = df_load(zsrc + (size_t)3 * cx + i); m[i] = march_tag(x[i]); any |= m[i]; }
-            if (m[3 + i]) { x[3 + i] = df_load(zsrc + (size_t)3 * cy + i); m[3 + i] = march_tag(x[3 + i]); any |= m[3 + i]; }
-          }
-          if (m[6]) { f = df_load(zown + (size_t)3 * row + gk); m[6] = march_tag(f); any |= m[6]; }
-          if (!__any(any)) break;
-          if ((spins & 255u) == 0u) {
-            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-            if (t0 == 0) t0 = now;
-            const int e = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (e != 0 || now - t0 > FX_DF_TIMEOUT_TICKS) {
-              if (e == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              dead = true;
-              break;
+        for (int i = 0; i < 3; i++) { m[i] = farx && march_tag(x[i]); m[3 + i] = fary && march_tag(x[3 + i]); any |= m[i] | m[3 + i]; }
+        m[6] = ownf && march_tag(f);
+        any |= m[6];
+        if (__any(any)) {
+          waited++; wflag = true;
+          // While this round waits, the NEXT round's far entries -- requested at the top of this round, i.e. before the wait -- go
+          // stale: they are re-read in the same polls, so that a wave which had to wait once does not wait in every round after it.
+          const int nx = nxt.k.x, ny = nxt.k.y;
+          const bool actn = q < eB - sB, nfarx = actn && g < 7 && nx >= 0, nfary = actn && g < 7 && ny >= 0, nownf = !FWD && actn && g < 3;
+          const int row = __shfl(cx, lead, 64), rown = __shfl(nx, lead, 64);
+          unsigned long long t0 = 0;
+          int back = 0;  // back-off: a wave that waits long (a chunk far ahead of the frontier) must not flood the fabric with re-reads
+          for (unsigned spins = 1;; spins++) {
+            polls++;
+            for (int s = 0; s < back + nsleep; s++) __builtin_amdgcn_s_sleep(4);  // 256 clocks each
+            back = back < 4 ? 2 * back + 1 : back;  // 0, 1, 3, 7 x 0.1 us
+            any = false;
+            // all re-reads of a poll in flight together (a lane that misses nothing re-reads the dummy entry): one round trip per poll
+            double v[7], vn[7];
+            const double *pxa = zsrc + (size_t)3 * cx, *pya = zsrc + (size_t)3 * cy, *pfa = zown + (size_t)3 * row + gk;
+            const double *pxn = zsrc + (size_t)3 * nx, *pyn = zsrc + (size_t)3 * ny, *pfn = zown + (size_t)3 * rown + gk;
+            bool mn[7];
+#pragma unroll
+            for (int i = 0; i < 3; i++) { mn[i] = nfarx && march_tag(xn[i]); mn[3 + i] = nfary && march_tag(xn[3 + i]); }
+            mn[6] = nownf && march_tag(fn);
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+              v[i] = df_load(m[i] ? pxa + i : dummy); v[3 + i] = df_load(m[3 + i] ? pya + i : dummy);
+              vn[i] = df_load(mn[i] ? pxn + i : dummy); vn[3 + i] = df_load(mn[3 + i] ? pyn + i : dummy);
+            }
+            v[6] = df_load(m[6] ? pfa : dummy); vn[6] = df_load(mn[6] ? pfn : dummy);
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+              if (m[i]) { x[i] = v[i]; m[i] = march_tag(v[i]); any |= m[i]; }
+              if (mn[i]) xn[i] = vn[i];
+            }
+            if (m[6]) { f = v[6]; m[6] = march_tag(v[6]); any |= m[6]; }
+            if (mn[6]) fn = vn[6];
+            if (!__any(any)) break;
+            if ((spins & 31u) == 0u) {
+              const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+              if (t0 == 0) t0 = now;
+              const int e = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (e != 0 || now - t0 > FX_DF_TIMEOUT_TICKS) {
+                if (e == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                dead = true;
+                break;
+              }
             }
           }
+          // nothing in flight when the slow path rejoins: the refreshed entries are the youngest loads, and a join with them pending would
+          // make every round's wait for its far entries as strict as this path needs it (the stream loads would lose a round of flight)
+          __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         }
       }
     }
+    // the matrix stream of round + 3: after the check, so that a wave which has to poll (its re-reads are the youngest loads, waiting for
+    // them waits for everything) does not wait for stream loads it has only just issued
+    load_stream(sD, eD, ld);
+    if (rtr && t == 0) rtr[rl_local] = __builtin_amdgcn_s_memrealtime() | (wflag ? 1ull << 63 : 0ull);
     // near gathers from the ring (lanes that gather nothing read slot 0)
     const int sx = cx <= -2 ? -cx - 2 : 0, sy = cy <= -2 ? -cy - 2 : 0;
     double xv[6];
@@ -190,7 +248,7 @@ struct MarchPairs {
       xv[3 + i] = cy >= 0 ? x[3 + i] : (cy <= -2 ? ny : 0.0);
     }
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    bell_pair_fma(a, xv, s0, s1, s2);
+    bell_pair_fma(cur.a, xv, s0, s1, s2);
     scr[w][0][lane] = s0; scr[w][1][lane] = s1; scr[w][2][lane] = s2; scr[w][3][lane] = f;
     __builtin_amdgcn_wave_barrier();
     if (g == 7 && act) {  // the finishing lane: partial sums in lane order (= wave order of the split kernels), 3x3 substitution
@@ -201,7 +259,7 @@ struct MarchPairs {
       const double f0 = pf[0], f1 = pf[1], f2 = pf[2];
       double u[9];
 #pragma unroll
-      for (int e = 0; e < 9; e++) u[e] = a[e].x;
+      for (int e = 0; e < 9; e++) u[e] = cur.a[e].x;
       double x1, x2, x3;
       if (FWD) {
         x1 = f0 - s0; x2 = f1 - s1; x3 = f2 - s2;
@@ -216,36 +274,40 @@ struct MarchPairs {
       if (t == 7) ringn[rl_local & (FX_MARCH_RING - 1)] = n;
     }
     __builtin_amdgcn_wave_barrier();
-    // descriptors: this round's finishing lanes carry the row count of round + 3
+    // descriptors: this round's finishing lanes carry the row count of round + 4
     const int nn = __builtin_amdgcn_readlane(cy, 7);
-    rsA = rsN; rsB = rsNe; rsN = rsM; rsNe = rsMe;
-    if (nn > 0) { rsM = rsMe; rsMe = rsMe + nn; }
+    sA = sB; eA = eB; sB = sC; eB = eC; sC = sD; eC = eD;
+    if (nn > 0) { sD = eD; eD = eD + nn; }
   }
 
   __device__ __forceinline__ void run(const int r0, const int r1) {
     const int rl = r1 - 1;
     {
-      const int rn = r0 + 1 < rl ? r0 + 1 : rl, rm = r0 + 2 < rl ? r0 + 2 : rl;
-      rsA = __builtin_amdgcn_readfirstlane(P.rstart[r0]); rsB = __builtin_amdgcn_readfirstlane(P.rstart[r0 + 1]);
-      rsN = __builtin_amdgcn_readfirstlane(P.rstart[rn]); rsNe = __builtin_amdgcn_readfirstlane(P.rstart[rn + 1]);
-      rsM = __builtin_amdgcn_readfirstlane(P.rstart[rm]); rsMe = __builtin_amdgcn_readfirstlane(P.rstart[rm + 1]);
+      const int rb = r0 + 1 < rl ? r0 + 1 : rl, rc = r0 + 2 < rl ? r0 + 2 : rl, rd = r0 + 3 < rl ? r0 + 3 : rl;
+      sA = __builtin_amdgcn_readfirstlane(P.rstart[r0]); eA = __builtin_amdgcn_readfirstlane(P.rstart[r0 + 1]);
+      sB = __builtin_amdgcn_readfirstlane(P.rstart[rb]); eB = __builtin_amdgcn_readfirstlane(P.rstart[rb + 1]);
+      sC = __builtin_amdgcn_readfirstlane(P.rstart[rc]); eC = __builtin_amdgcn_readfirstlane(P.rstart[rc + 1]);
+      sD = __builtin_amdgcn_readfirstlane(P.rstart[rd]); eD = __builtin_amdgcn_readfirstlane(P.rstart[rd + 1]);
     }
-    double2 a0[9], a1[9];
-    int2 k0, k1, fa0, fa1;
-    double x0[6], x1[6], f0, f1;
-    k0 = load_cols(rsA, rsB);
-    fa1 = load_cols(rsN, rsNe);
-    load_vals(rsA, rsB, a0);
-    load_far(k0, x0);
-    f0 = load_f(k0);
+    Buf b0, b1, b2, b3;
+    double xa[6], xb[6], fa, fb;
+    load_stream(sA, eA, b0);
+    load_stream(sB, eB, b1);
+    load_stream(sC, eC, b2);
+    load_far(b0.k, eA - sA, xa);
+    fa = load_f(b0.k);
     // nothing of the prologue in flight at the loop header: the wait insertion merges the header's predecessors, and a load pending on
     // the entry edge only would put its wait into every round (once per chunk, this costs one latency)
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-    for (int rho = r0;; rho += 2) {
-      round(rho - r0, a0, k0, x0, f0, fa1, a1, k1, x1, f1, fa0);
+    for (int rho = r0;; rho += 4) {
+      round(rho - r0, b0, b1, b3, xa, fa, xb, fb);
       if (rho + 1 >= r1) break;
-      round(rho + 1 - r0, a1, k1, x1, f1, fa0, a0, k0, x0, f0, fa1);
+      round(rho + 1 - r0, b1, b2, b0, xb, fb, xa, fa);
       if (rho + 2 >= r1) break;
+      round(rho + 2 - r0, b2, b3, b1, xa, fa, xb, fb);
+      if (rho + 3 >= r1) break;
+      round(rho + 3 - r0, b3, b0, b2, xb, fb, xa, fa);
+      if (rho + 4 >= r1) break;
     }
     march_lds_barrier();  // the last round is in the ring (the publisher takes it from there)
   }
@@ -270,7 +332,7 @@ __device__ __forceinline__ void march_publisher(const int r0, const int r1, doub
 }
 
 template <int NW>
-__global__ __launch_bounds__(64 * (NW + 1)) void k_tri_march(MarchArgs A, const int32_t *__restrict__ gate) {
+__global__ __launch_bounds__(256) void k_tri_march(MarchArgs A, const int32_t *__restrict__ gate) {
   if (gate && *gate != 0) return;
   if (A.nsleep < 0) {  // test hook (FX_DEBUG_DF_FAIL), as k_tri_dataflow
     if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(A.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -287,18 +349,36 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_tri_march(MarchArgs A, const 
   const bool pub = ((int)threadIdx.x >> 6) == NW;
   bool dead = false;
   int last = -1;
+  const unsigned long long t_entry = A.rtrace ? __builtin_amdgcn_s_memrealtime() : 0ull;
   for (int ch = first; ch < A.nchunks; ch += G) {
     const int r0 = A.F.round_ptr[ch], r1 = A.F.round_ptr[ch + 1];
     last = ch;
     if (r1 <= r0) continue;
     if (pub) march_publisher<NW>(r0, r1, A.zf, ring, ringrow, ringn);
-    else MarchPairs<true, NW>(A.F, A.r, A.zf, A.zf, ring, ringrow, ringn, scr, A.err, dead, A.nsleep).run(r0, r1);
+    else {
+      MarchPairs<true, NW> mp(A.F, A.r, A.zf, A.zf, A.dummy, ring, ringrow, ringn, scr, A.err, dead, A.nsleep);
+      if (A.rtrace && ch == A.rtrace_chunk) { mp.rtr = A.rtrace; if (threadIdx.x == 0) A.rtrace[r1 - r0] = t_entry; }
+      const unsigned long long t0 = A.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+      mp.run(r0, r1);
+      if (A.trace && threadIdx.x == 0) {
+        unsigned long long *tr = A.trace + (size_t)8 * ch;
+        tr[0] = t0; tr[1] = __builtin_amdgcn_s_memrealtime(); tr[4] = mp.waited; tr[5] = mp.polls;
+      }
+    }
   }
   for (int ch = last; ch >= 0; ch -= G) {  // backward: the same chunks, last first
     const int r0 = A.B.round_ptr[ch], r1 = A.B.round_ptr[ch + 1];
     if (r1 <= r0) continue;
     if (pub) march_publisher<NW>(r0, r1, A.z, ring, ringrow, ringn);
-    else MarchPairs<false, NW>(A.B, A.r, A.z, A.zf, ring, ringrow, ringn, scr, A.err, dead, A.nsleep).run(r0, r1);
+    else {
+      MarchPairs<false, NW> mp(A.B, A.r, A.z, A.zf, A.dummy, ring, ringrow, ringn, scr, A.err, dead, A.nsleep);
+      const unsigned long long t0 = A.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+      mp.run(r0, r1);
+      if (A.trace && threadIdx.x == 0) {
+        unsigned long long *tr = A.trace + (size_t)8 * ch;
+        tr[2] = t0; tr[3] = __builtin_amdgcn_s_memrealtime(); tr[6] = mp.waited; tr[7] = mp.polls;
+      }
+    }
   }
 }
 
@@ -440,8 +520,8 @@ static void march_lanes(int32_t N, int32_t S, int32_t R, Ents ents /* (i, cols, 
           cl[k] = code;  // lane k / 2, half k % 2: int2 per lane = two consecutive ints
           sl[k] = sc[k];
         }
-        const size_t gr = (size_t)mr.round_ptr[c] + mr.rho[i];  // the finishing lane: its row, and the row count of round + 3 (0: past the chunk's end)
-        cl[14] = i; cl[15] = gr + 3 < (size_t)mr.round_ptr[c + 1] ? mr.rstart[gr + 4] - mr.rstart[gr + 3] : 0;
+        const size_t gr = (size_t)mr.round_ptr[c] + mr.rho[i];  // the finishing lane: its row, and the row count of round + 4 (0: past the chunk's end)
+        cl[14] = i; cl[15] = gr + 4 < (size_t)mr.round_ptr[c + 1] ? mr.rstart[gr + 5] - mr.rstart[gr + 4] : 0;
         sl[14] = 3 * i; sl[15] = -1;
       }
     }
@@ -470,7 +550,7 @@ static bool march_check(int32_t N, int32_t S, int32_t R, bool fwd, Ents ents, co
   for (int32_t c = 0; c < nch; c++) {
     const int32_t r0 = mr.round_ptr[c], r1 = mr.round_ptr[c + 1];
     std::fill(ringrow.begin(), ringrow.end(), -1);
-    int32_t rsM = mr.rstart[std::min(r0 + 2, r1 - 1)], rsMe = mr.rstart[std::min(r0 + 2, r1 - 1) + 1];
+    int32_t rsM = mr.rstart[std::min(r0 + 3, r1 - 1)], rsMe = mr.rstart[std::min(r0 + 3, r1 - 1) + 1];
     for (int32_t r = r0; r < r1; r++) {
       const int32_t rs = mr.rstart[r], n = mr.rstart[r + 1] - rs;
       if (n < 1 || n > R) { why = "round with no rows or more than R"; return false; }
@@ -493,14 +573,14 @@ static bool march_check(int32_t N, int32_t S, int32_t R, bool fwd, Ents ents, co
             if (!(earlier || (cj == c && mr.rho[j] < mr.rho[i]))) { why = "far code names a row that is not produced before"; return false; }
           } else { why = "column code is neither its neighbour nor a ring slot"; return false; }
         }
-        const int32_t want = r + 3 < r1 ? mr.rstart[r + 4] - mr.rstart[r + 3] : 0;
-        if (cl[15] != want) { why = "row count of round + 3 in the finishing lane"; return false; }
+        const int32_t want = r + 4 < r1 ? mr.rstart[r + 5] - mr.rstart[r + 4] : 0;
+        if (cl[15] != want) { why = "row count of round + 4 in the finishing lane"; return false; }
       }
       for (int32_t qq = 0; qq < n; qq++) ringrow[(size_t)((r - r0) & (FX_MARCH_RING - 1)) * R + qq] = mrow[(size_t)rs + qq];
-      // the descriptor chain of the kernel: after round r, [rsM, rsMe) must be round min(r + 3, last)
+      // the descriptor chain of the kernel: after round r, [rsM, rsMe) must be round min(r + 4, last)
       const int32_t nn = col[(size_t)16 * rs + 15];
       if (nn > 0) { rsM = rsMe; rsMe += nn; }
-      const int32_t tgt = std::min(r + 3, r1 - 1);
+      const int32_t tgt = std::min(r + 4, r1 - 1);
       if (rsM != mr.rstart[tgt] || rsMe != mr.rstart[tgt + 1]) { why = "descriptor chain leaves the round table"; return false; }
     }
   }
@@ -522,7 +602,7 @@ static int march_upload(fx_context *c, MarchProg &p, const MarchRounds &mr, cons
   return 0;
 }
 
-static inline int march_nw_index(int nw) { return nw == 2 ? 0 : nw == 4 ? 1 : nw == 6 ? 2 : 3; }
+static inline int march_nw_index(int nw) { return nw <= 1 ? 0 : nw == 2 ? 1 : 2; }
 
 // Build the two programs for the level-scheduled preconditioner of this context (after ilu_setup_symbolic).  Leaves march.ok false
 // when the structure does not qualify (a row with more than 14 lower or upper blocks) or the cost model prefers k_tri_dataflow.
@@ -563,7 +643,7 @@ static int march_build(fx_context *c) {
       for (int32_t j = iL[i]; j < iL[i + 1]; j++) { const int32_t o = i - (jL[j] - 1); if (2 * o > bw) offs.push_back(o); }
     if (!offs.empty()) { std::nth_element(offs.begin(), offs.begin() + offs.size() / 2, offs.end()); plane = offs[offs.size() / 2]; }
   }
-  const int idx_of[4] = {2, 4, 6, 8};
+  const int idx_of[3] = {1, 2, 3};
   struct Cand { int32_t S, NW; double est; };
   std::vector<Cand> cands;
   if (c->march_chunk > 0) cands.push_back({std::min(N, c->march_chunk), c->march_waves, 0.0});
@@ -576,14 +656,14 @@ static int march_build(fx_context *c) {
     // pair waves: enough for the chunk's typical level (levels are then rarely split); fixed by FX_MARCH_WAVES
     MarchRounds probe;
     int32_t nw = cd.NW;
-    if (nw != 2 && nw != 4 && nw != 6 && nw != 8) {
+    if (nw != 1 && nw != 2 && nw != 3) {
       march_rounds(N, cd.S, 1 << 20, true, entsL, probe);  // unsplit levels
       std::vector<int32_t> sz;
       for (size_t k = 0; k + 1 < probe.rstart.size(); k++) sz.push_back(probe.rstart[k + 1] - probe.rstart[k]);
       std::sort(sz.begin(), sz.end());
       const int32_t p90 = sz.empty() ? 8 : sz[(size_t)(0.9 * (sz.size() - 1))];
-      nw = 8;
-      for (int k = 0; k < 4; k++) if (8 * idx_of[k] >= p90) { nw = idx_of[k]; break; }
+      nw = 3;
+      for (int k = 0; k < 3; k++) if (8 * idx_of[k] >= p90) { nw = idx_of[k]; break; }
     }
     const int32_t nch = (N + cd.S - 1) / cd.S;
     const int gmax = std::max(8, c->march_grid_max[march_nw_index(nw)] / 8 * 8);
@@ -617,7 +697,8 @@ static int march_build(fx_context *c) {
     if (march_upload(c, M.B, mb, col, src)) return FX_ERROR_RUNTIME;
     M.max_round_rows = std::max(M.max_round_rows, mb.max_rows);
   }
-  if (dev_alloc(&M.zf, (size_t)3 * N + 2)) return FX_ERROR_RUNTIME;
+  if (dev_alloc(&M.zf, (size_t)3 * N + 4)) return FX_ERROR_RUNTIME;
+  HIP_TRY(hipMemset(M.zf, 0, ((size_t)3 * N + 4) * 8));  // the tail is the dummy entry
   M.ok = true;
   M.build_s = now_s() - t_begin;
   return 0;
@@ -636,7 +717,8 @@ static int march_fill_values(fx_context *c, const double *AL, const double *AU, 
   return 0;
 }
 
-static int march_apply(fx_context *c, const double *r, double *z, const int32_t *gate) {
+static int march_apply(fx_context *c, const double *r, double *z, const int32_t *gate, unsigned long long *trace = nullptr,
+                       unsigned long long *rtrace = nullptr, int rtrace_chunk = -1) {
   MarchDev &M = c->ssor.march;
   const int32_t N = c->A.N;
   hipLaunchKernelGGL(k_march_tags, dim3(grid_for((int64_t)3 * N, 256, 2048)), dim3(256), 0, c->stream, (int64_t)3 * N, M.zf, z);
@@ -644,19 +726,19 @@ static int march_apply(fx_context *c, const double *r, double *z, const int32_t 
   a.F = {M.F.round_ptr, M.F.rstart, (const double2 *)M.F.val, (const int2 *)M.F.col};
   a.B = {M.B.round_ptr, M.B.rstart, (const double2 *)M.B.val, (const int2 *)M.B.col};
   a.nchunks = M.nchunks;
-  a.r = r; a.zf = M.zf; a.z = z;
+  a.r = r; a.zf = M.zf; a.z = z; a.dummy = M.zf + (size_t)3 * N;
   a.err = c->df_err;
   a.nsleep = c->dbg_df_fail ? -1 : c->df_sleep;
   a.xcd = c->march_xcd ? 1 : 0;
+  a.trace = trace; a.rtrace = rtrace; a.rtrace_chunk = rtrace_chunk;
   const int gmax = std::max(8, c->march_grid_max[march_nw_index(M.NW)] / 8 * 8);
   int grid = std::min(gmax, (M.nchunks + 7) / 8 * 8);
   if (c->march_grid > 0) grid = std::max(8, std::min(grid, c->march_grid / 8 * 8));
   c->df_grid_last = grid;
   switch (M.NW) {
+    case 1: hipLaunchKernelGGL((k_tri_march<1>), dim3(grid), dim3(64 * 2), 0, c->stream, a, gate); break;
     case 2: hipLaunchKernelGGL((k_tri_march<2>), dim3(grid), dim3(64 * 3), 0, c->stream, a, gate); break;
-    case 4: hipLaunchKernelGGL((k_tri_march<4>), dim3(grid), dim3(64 * 5), 0, c->stream, a, gate); break;
-    case 6: hipLaunchKernelGGL((k_tri_march<6>), dim3(grid), dim3(64 * 7), 0, c->stream, a, gate); break;
-    default: hipLaunchKernelGGL((k_tri_march<8>), dim3(grid), dim3(64 * 9), 0, c->stream, a, gate); break;
+    default: hipLaunchKernelGGL((k_tri_march<3>), dim3(grid), dim3(64 * 4), 0, c->stream, a, gate); break;
   }
   HIP_TRY(hipGetLastError());
   c->march_launches++;

@@ -230,6 +230,28 @@ class SolverContext:
                 d[k] = int(d[k])
         return d
 
+    def march_trace(self):
+        """Diagnostics: one traced march apply (fx_debug_march_trace) -> array [chunks, 8]: forward start / end, backward start / end
+        in microseconds, rounds that waited and polls, forward / backward."""
+        n = self.march_report()["chunks"]
+        out = np.zeros(8 * max(n, 1))
+        nch = C.c_int32(0)
+        f = lib().fx_debug_march_trace
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        _chk(f(self.h, _ptr(out), out.size, C.byref(nch)))
+        a = out.reshape(-1, 8)
+        a[:, :4] = np.where(a[:, :4] >= 0, a[:, :4] * 0.01, -1.0)
+        return a
+
+    def march_rounds(self, chunk):
+        """Diagnostics: when each round of one chunk's forward sweep passed its barrier (us; negative = the round waited)."""
+        out = np.zeros(1 << 16)
+        n = C.c_int32(0)
+        f = lib().fx_debug_march_rounds
+        f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+        _chk(f(self.h, int(chunk), _ptr(out), out.size, C.byref(n)))
+        return out[:n.value].copy()
+
     def solve_resident(self, hecMAT, want_history=True):
         info = _SolveInfo()
         maxit = int(hecMAT.Iarray[0])

@@ -10,6 +10,7 @@ if "--precond" in args:
 if "--n" in args:
     i = args.index("--n"); n = int(args[i + 1]); del args[i:i + 2]
 from frontistr_amd import hecmw as hip
+if os.environ.get('FX_LIBPATH'): hip.LIBPATH = os.environ['FX_LIBPATH']   # timing experiments: a library built with -DFX_MARCH_EXP_*
 from frontistr_amd.mesh import CubeMesh
 mesh = CubeMesh(n)
 hm = hip.hecmwST_local_mesh(n_node=mesh.n_node)
@@ -38,6 +39,25 @@ for spec in (args or ["0:0"]):
         ctx.close(); continue
     z = ctx.precond_apply(r)[:3 * m.N].copy()
     ms_m = [ctx.precond_apply_ms(10) for _ in range(3)]
+    if os.environ.get("MARCH_TRACE"):
+        tr = ctx.march_trace()
+        np.save("gpurun_out/r4/march_trace_%s.npy" % spec.replace(":", "_"), tr)
+        k = np.linspace(0, len(tr) - 1, 12).astype(int)
+        print("   chunk   fwd start..end      bwd start..end (us)   waited/polls fwd  bwd")
+        for i in k:
+            print("   %5d  %8.1f %8.1f   %8.1f %8.1f   %6d %8d  %6d %8d" % ((i,) + tuple(tr[i, :4]) + tuple(int(v) for v in tr[i, 4:])), flush=True)
+        print("   totals: fwd done %.1f us, all done %.1f us, waited rounds %d / %d, polls %d / %d"
+              % (tr[:, 1].max(), tr[:, 3].max(), tr[:, 4].sum(), tr[:, 6].sum(), tr[:, 5].sum(), tr[:, 7].sum()), flush=True)
+    for ch in [int(x) for x in os.environ.get("MARCH_ROUNDS", "").split(",") if x]:
+        if ch >= rep["chunks"]:
+            continue
+        rr = ctx.march_rounds(ch)
+        tt = np.abs(rr); dt = np.diff(tt); w = rr[1:] < 0
+        print("   chunk %d: first round at %.1f us, %d rounds in %.1f us; %d waited; round time median %.2f us, free rounds mean %.2f, waited rounds mean %.2f, max %.1f"
+              % (ch, tt[0], len(rr), tt[-1] - tt[0], int(w.sum()), np.median(dt), dt[~w].mean() if (~w).any() else 0, dt[w].mean() if w.any() else 0, dt.max()), flush=True)
+        print("     first 60 round times (us, * = waited): " + " ".join(("%.1f%s" % (d, "*" if ww else "")) for d, ww in zip(dt[:60], w[:60])), flush=True)
+        mid = len(dt) // 2
+        print("     middle 60: " + " ".join(("%.1f%s" % (d, "*" if ww else "")) for d, ww in zip(dt[mid:mid + 60], w[mid:mid + 60])), flush=True)
     ctx.set_option("FX_MARCH", 0)
     if zref is None:
         zref = ctx.precond_apply(r)[:3 * m.N].copy()

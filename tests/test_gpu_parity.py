@@ -757,7 +757,8 @@ def test_dataflow_sweeps_equal_launch_per_level_sweeps_bitwise(hip, deck, pc, mo
         assert np.all(np.isfinite(lev))
         assert np.array_equal(df, lev), wps
         ref[wps] = lev
-    assert np.array_equal(apply(dict(FX_DATAFLOW="2", FX_DF_WPS="8", FX_DF_POLL="0")), ref[8])
+    for poll in ("0", "1"):      # 0 (default): a pass re-reads every entry; 1: only the unpublished ones
+        assert np.array_equal(apply(dict(FX_DATAFLOW="2", FX_DF_WPS="8", FX_DF_POLL=poll)), ref[8])
     assert relerr(ref[2], ref[4]) < 1e-13 and relerr(ref[8], ref[4]) < 1e-13
 
 
@@ -1116,10 +1117,10 @@ def test_march_sweeps_equal_level_sweeps_bitwise(hip, kind, pc):
     N = m.N
     r = np.cos(0.37 * np.arange(3 * m.NP) + 0.1)
     plane = (kind[0] + 1) ** 2 if kind != "necking" else 0
-    configs = [dict(), dict(FX_MARCH_WAVES=2), dict(FX_MARCH_CHUNK=N, FX_MARCH_WAVES=4), dict(FX_MARCH_CHUNK=97, FX_MARCH_WAVES=6, FX_MARCH_XCD=0),
-               dict(FX_MARCH_CHUNK=max(64, N // 40), FX_MARCH_WAVES=8, FX_MARCH_GRID=8)]
+    configs = [dict(), dict(FX_MARCH_WAVES=2), dict(FX_MARCH_CHUNK=N, FX_MARCH_WAVES=3), dict(FX_MARCH_CHUNK=97, FX_MARCH_WAVES=1, FX_MARCH_XCD=0),
+               dict(FX_MARCH_CHUNK=max(64, N // 40), FX_MARCH_WAVES=3, FX_MARCH_GRID=8)]
     if plane:
-        configs += [dict(FX_MARCH_CHUNK=plane, FX_MARCH_WAVES=4), dict(FX_MARCH_CHUNK=(plane + 1) // 2, FX_MARCH_WAVES=2, FX_MARCH_GRID=16)]
+        configs += [dict(FX_MARCH_CHUNK=plane, FX_MARCH_WAVES=3), dict(FX_MARCH_CHUNK=(plane + 1) // 2, FX_MARCH_WAVES=2, FX_MARCH_GRID=16)]
     ref = None
     for cfg in configs:
         ctx = hip.SolverContext()
