@@ -1,5 +1,5 @@
 #!/bin/bash
-# timing experiments on the plane march at 10.1 M DOF: which part of a round costs what (libraries built with -DFX_MARCH_EXP_*; results of those are wrong on purpose)
+# timing experiments on the plane march at 10.1 M DOF: which part of a round costs what (libraries built by scripts/r4/march_exp_build.sh with -DFX_MARCH_EXP_*; results of those are wrong on purpose)
 mkdir -p gpurun_out/r4
 for v in "" NOPOLL FARPLAIN NOFAR NOVALS NOVALSNOFAR; do
   echo "##### variant ${v:-product}"
