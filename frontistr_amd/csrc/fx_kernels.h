@@ -740,6 +740,17 @@ __global__ __launch_bounds__(64 * WPS) void k_eis_backward_split(int32_t slice0,
     const int h0 = pair_ptr[slice], h1 = pair_ptr[slice + 1];
     const int np = (h1 - h0) >> 1;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    // the finishing wave's own operands (diagonal factor, D~t, ph) do not depend on the sweep: in flight before its block pairs, so that
+    // their latency overlaps the pairs' instead of following the LDS exchange (round 4, same-process pairs: 1.788 -> 1.774 ms per
+    // iteration; the same change in the forward kernel, which carries six more gathered entries per pair, lost 2 %: 106 -> 130 VGPRs)
+    double fu[9], fd[3], fp[3];
+    if (w == 0) {
+      const size_t o = (size_t)3 * (slice * 64 + lane), base = (size_t)slice * 576 + lane;
+#pragma unroll
+      for (int e = 0; e < 9; e++) fu[e] = alu[base + (size_t)e * 64];
+#pragma unroll
+      for (int k = 0; k < 3; k++) { fd[k] = dt[o + k]; fp[k] = ph[o + k]; }
+    }
     const double2 *vbase = (const double2 *)(val2 + (size_t)h0 * 576) + lane;
     const int2 *cbase = (const int2 *)(col2 + (size_t)h0 * 64) + lane;
     for (int i = w; i < np; i += WPS) {
@@ -766,7 +777,18 @@ __global__ __launch_bounds__(64 * WPS) void k_eis_backward_split(int32_t slice0,
       s0 = part[0][0][lane]; s1 = part[0][1][lane]; s2 = part[0][2][lane];
 #pragma unroll
       for (int k = 1; k < WPS; k++) { s0 += part[k][0][lane]; s1 += part[k][1][lane]; s2 += part[k][2][lane]; }
-      eis_backward_finish(slice, lane, s0, s1, s2, alu, st, dt, ph, p);
+      {
+        const size_t o = (size_t)3 * (slice * 64 + lane);
+        double g0 = fd[0], g1 = fd[1], g2 = fd[2];
+        if (st->iter != 1) {
+          const double beta = st->beta;
+          g0 = g0 + beta * fp[0]; g1 = g1 + beta * fp[1]; g2 = g2 + beta * fp[2];
+        }
+        ph[o] = g0; ph[o + 1] = g1; ph[o + 2] = g2;
+        double x1 = g0 - s0, x2 = g1 - s1, x3 = g2 - s2;
+        lusolve33_dev(fu, x1, x2, x3);
+        p[o] = x1; p[o + 1] = x2; p[o + 2] = x3;
+      }
     }
     if (slice + (int)gridDim.x < slice1) __syncthreads();
   }
