@@ -327,9 +327,43 @@ __global__ __launch_bounds__(FXA_BS(ELEMOPT)) void k_assemble_c3d8(int32_t n_ele
     }
   }
   if (!active) return;
+  // Strips, using the symmetry of the element matrix (K_ba = K_ab^T: B_b^T D B_a is the transpose of B_a^T D B_b, and so is the
+  // condensation term): lane a computes the blocks (a, a), (a, a+1), (a, a+2), (a, a+3) (mod 8) and -- lanes 0..3 only -- (a, a+4), 36
+  // of the 64, and scatters each off-diagonal one twice, as it stands into row a and transposed into row b.  4.5 strips per lane
+  // instead of 8; the transposed copies differ from separately accumulated ones in the last bit at most (sums of the same products in the
+  // same order, transposed), far inside the 1e-12 of the parity tests.  No other element of the launch touches these rows (colouring).
   const int32_t inod = conn[(size_t)8 * elem + a];
+  auto block_ptr = [&](int ra, int rb, int32_t rnod, int32_t cnod) -> double * {  // hecmw_mat_add_node, hecmw_mat_ass.f90:72-134
+    if (rnod == cnod) return D + (size_t)9 * (rnod - 1);
+    if (cnod < rnod) {
+      const int32_t k = pos_map ? pos_map[(size_t)64 * elem + 8 * ra + rb] : item_search(itemL, indexL[rnod - 1], indexL[rnod], cnod);
+      return k < 0 ? nullptr : AL + (size_t)9 * k;
+    }
+    const int32_t k = pos_map ? pos_map[(size_t)64 * elem + 8 * ra + rb] : item_search(itemU, indexU[rnod - 1], indexU[rnod], cnod);
+    return k < 0 ? nullptr : AU + (size_t)9 * k;
+  };
 #pragma unroll 1
-  for (int b = 0; b < 8; b++) {
+  for (int st = 0; st < 5; st++) {
+    if (st == 4 && a >= 4) break;
+    const int b = (a + st) & 7;
+    // the destination blocks of this strip and -- coloured scatter: plain read-modify-write -- their old values, requested BEFORE the
+    // strip's arithmetic: the reads' latency runs under ~500 flops instead of after them
+    double *dst = nullptr, *dstT = nullptr;
+    double old[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, oldT[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (!Kout) {
+      const int32_t jnod = conn[(size_t)8 * elem + b];
+      dst = block_ptr(a, b, inod, jnod);
+      if (st > 0) dstT = block_ptr(b, a, jnod, inod);
+      if (!dst || (st > 0 && !dstT)) { if (err) atomicExch(err, 2); continue; }
+      if (elem_list) {
+#pragma unroll
+        for (int e = 0; e < 9; e++) old[e] = dst[e];
+        if (st > 0) {
+#pragma unroll
+          for (int e = 0; e < 9; e++) oldT[e] = dstT[e];
+        }
+      }
+    }
     double K[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll 1
     for (int LX = 0; LX < 8; LX++) {
@@ -343,38 +377,40 @@ __global__ __launch_bounds__(FXA_BS(ELEMOPT)) void k_assemble_c3d8(int32_t n_ele
       for (int i = 0; i < 3; i++)
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-          double s = 0.0;
+          double sm = 0.0;
 #pragma unroll
-          for (int q = 0; q < 9; q++) s += tk[i][q] * Ksh[el][q][3 * b + j];
-          K[3 * i + j] -= s;
+          for (int q = 0; q < 9; q++) sm += tk[i][q] * Ksh[el][q][3 * b + j];
+          K[3 * i + j] -= sm;
         }
     }
     if (Kout) {
 #pragma unroll
       for (int i = 0; i < 3; i++)
 #pragma unroll
-        for (int j = 0; j < 3; j++) Kout[(size_t)elem * 576 + (size_t)(3 * a + i) * 24 + 3 * b + j] = K[3 * i + j];
+        for (int j = 0; j < 3; j++) {
+          Kout[(size_t)elem * 576 + (size_t)(3 * a + i) * 24 + 3 * b + j] = K[3 * i + j];
+          if (st > 0) Kout[(size_t)elem * 576 + (size_t)(3 * b + j) * 24 + 3 * a + i] = K[3 * i + j];
+        }
       continue;
-    }
-    // scatter (hecmw_mat_add_node, hecmw_mat_ass.f90:72-134)
-    const int32_t jnod = conn[(size_t)8 * elem + b];
-    double *dst;
-    if (inod == jnod) dst = D + (size_t)9 * (inod - 1);
-    else if (jnod < inod) {
-      const int32_t k = pos_map ? pos_map[(size_t)64 * elem + 8 * a + b] : item_search(itemL, indexL[inod - 1], indexL[inod], jnod);
-      if (k < 0) { if (err) atomicExch(err, 2); continue; }
-      dst = AL + (size_t)9 * k;
-    } else {
-      const int32_t k = pos_map ? pos_map[(size_t)64 * elem + 8 * a + b] : item_search(itemU, indexU[inod - 1], indexU[inod], jnod);
-      if (k < 0) { if (err) atomicExch(err, 2); continue; }
-      dst = AU + (size_t)9 * k;
     }
     if (elem_list) {
 #pragma unroll
-      for (int e = 0; e < 9; e++) dst[e] += K[e];
+      for (int e = 0; e < 9; e++) dst[e] = old[e] + K[e];
+      if (st > 0) {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+          for (int j = 0; j < 3; j++) dstT[3 * j + i] = oldT[3 * j + i] + K[3 * i + j];
+      }
     } else {
 #pragma unroll
       for (int e = 0; e < 9; e++) unsafeAtomicAdd(dst + e, K[e]);
+      if (st > 0) {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+          for (int j = 0; j < 3; j++) unsafeAtomicAdd(dstT + 3 * j + i, K[3 * i + j]);
+      }
     }
   }
 }
