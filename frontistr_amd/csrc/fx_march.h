@@ -464,7 +464,9 @@ static void march_rounds(int32_t N, int32_t S, int32_t R, bool fwd, Ents ents, M
 template <class Ents>
 static double march_estimate(int32_t N, int32_t S, int32_t NW, int32_t G, Ents ents, const MarchRounds &mr) {
   const int32_t nch = (N + S - 1) / S;
-  const double t_round = 0.40 + 0.085 * NW, hop = 1.6;  // per round: barrier + in-LDS chain + NW waves x 17 loads at the CU's issue rate
+  // measured at 10.1 M DOF (profiles/r04_march_10m_ilu0.txt): a free-running round 0.84 us with 2 pair waves, 0.96 with 3; a hand-over between
+  // chunks 5 us when nothing else waits, ~9 us deep in the mesh (a round that waits costs a memory round trip, and its consumers wait too)
+  const double t_round = 0.60 + 0.12 * NW, hop = 7.0;
   std::vector<double> fin((size_t)mr.round_ptr[nch], 0.0), chunk_end((size_t)nch, 0.0), need;
   std::vector<int32_t> nbr;
   double total = 0.0;
@@ -674,7 +676,7 @@ static int march_build(fx_context *c) {
   }
   M.S = pick.S; M.NW = pick.NW; M.nchunks = (N + pick.S - 1) / pick.S;
   M.est_us = pick.est;
-  M.est_level_us = 2.0 * Sd.ncolor;  // k_tri_dataflow: ~2.0 us per dependency level and half sweep (measured)
+  M.est_level_us = 1.6 * Sd.ncolor;  // k_tri_dataflow: 1.6 us per dependency level and half sweep (3.33 ms per apply at 1,044 levels)
   if (c->march_mode == 1 && !(M.est_us < 0.8 * M.est_level_us)) { M.build_s = now_s() - t_begin; return 0; }
   const int32_t R = 8 * M.NW;
   const bool check = N <= 200000 || getenv("FX_MARCH_CHECK") != nullptr;
