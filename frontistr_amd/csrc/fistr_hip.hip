@@ -278,6 +278,7 @@ static const FxOption g_fx_options[] = {
     {"FX_DF_GRID", [](fx_context *c, double v) { c->df_grid = (int)v; }},
     {"FX_DF_POLL", [](fx_context *c, double v) { c->df_poll = (int)v; }},
     {"FX_DF_SLEEP", [](fx_context *c, double v) { c->df_sleep = std::max(0, (int)v); }},
+    {"FX_DF_PRESLEEP", [](fx_context *c, double v) { c->df_presleep = std::max(0, (int)v); }},
     {"FX_DF_WPS", [](fx_context *c, double v) { c->df_wps = ((int)v == 2 || (int)v == 4) ? (int)v : 8; }},
     {"FX_MARCH", [](fx_context *c, double v) { c->march_mode = std::max(0, std::min(2, (int)v)); }},
     {"FX_MARCH_CHUNK", [](fx_context *c, double v) { c->march_chunk = std::max(0, (int)v); }},
@@ -436,7 +437,7 @@ static void free_precond(fx_context *c) {
   dev_free(c->diag.alu);
   bell_free(c->ssor.L); bell_free(c->ssor.U); bell_free(c->ssor.H);
   dev_free(c->ssor.alu); dev_free(c->ssor.slot_node); dev_free(c->ssor.zs); dev_free(c->ssor.zb);
-  dev_free(c->ssor.lu_D); dev_free(c->ssor.lu_AL); dev_free(c->ssor.lu_AU);
+  dev_free(c->ssor.lu_D); dev_free(c->ssor.lu_AL); dev_free(c->ssor.lu_AU); dev_free(c->ssor.slice_level);
   march_free(c->ssor.march);
   c->ssor = SsorDev();
   c->precond_valid = false;
@@ -1651,6 +1652,14 @@ static int ilu_setup_symbolic(fx_context *c) {
   }
   dev_free(S.alu);
   if (dev_alloc(&S.alu, (size_t)(nslots / 64) * 576)) return FX_ERROR_RUNTIME;
+  {  // level of every slice (FX_DF_PRESLEEP)
+    std::vector<int32_t> sl((size_t)nslots / 64, 0);
+    for (int32_t l = 1; l <= nlev; l++)
+      for (int32_t k = S.color_slice[l - 1]; k < S.color_slice[l]; k++) sl[k] = l;
+    dev_free(S.slice_level);
+    if (dev_alloc(&S.slice_level, sl.size())) return FX_ERROR_RUNTIME;
+    HIP_TRY(hipMemcpy(S.slice_level, sl.data(), sl.size() * 4, hipMemcpyHostToDevice));
+  }
   pt.lap("level layouts");
   if (march_build(c)) return FX_ERROR_RUNTIME;  // the same sweeps as a plane march (fx_march.h), when the structure and the cost model admit it
   pt.lap("march programs");
@@ -1836,7 +1845,8 @@ static int precond_apply_once(fx_context *c, const double *r, double *z, bool wa
       double *part = want_dot ? c->partials : (double *)nullptr;
 #define DF_LAUNCH3(W, P, SOA)                                                                                                       \
   hipLaunchKernelGGL((k_tri_dataflow<W, P, SOA>), dim3(grid), dim3(64 * W), 0, c->stream, nsl, S.L.pair_ptr, S.L.val2, S.L.col2, \
-                     S.U.pair_ptr, S.U.val2, S.U.col2, sn, S.alu, r, S.zs, zbk, znat, part, gate_status(c), c->df_err, c->dbg_df_fail ? -1 : c->df_sleep)
+                     S.U.pair_ptr, S.U.val2, S.U.col2, sn, S.alu, r, S.zs, zbk, znat, part, gate_status(c), c->df_err, c->dbg_df_fail ? -1 : c->df_sleep, \
+                     level_sched(c) ? S.slice_level : (const int32_t *)nullptr, c->df_presleep)
 #define DF_LAUNCH2(W, P)                                    \
   do {                                                      \
     if (!full && c->df_soa) DF_LAUNCH3(W, P, true);         \

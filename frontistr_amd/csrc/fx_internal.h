@@ -126,6 +126,7 @@ struct SsorDev {
   std::vector<int32_t> perm;         // new -> old (1-based), as the reference's perm(:)
   std::vector<int32_t> colorindex;   // COLORindex(0:ncolor)
   MarchDev march;                    // level-scheduled sweeps as a plane march (fx_march.h)
+  int32_t *slice_level = nullptr;    // device: dependency level of every slice of the level-major layouts (ILU(0), natural SSOR)
 };
 
 struct DiagDev {
@@ -331,6 +332,7 @@ struct fx_context {
   // pass instead of one per missing entry: 4.19 -> 3.43 ms per apply; with that, re-reading every entry per pass (FX_DF_POLL=0) is the
   // faster form, 3.33 ms (scripts/r3/ab_opts.py, same context), and the default.
   int df_mode = 1, df_grid = 0, df_wps = 8, df_poll = 0, df_sleep = 0;
+  int df_presleep = 2;        // FX_DF_PRESLEEP: x 0.1 us of sleep per level of lead before a workgroup starts to poll for its next slice (round 4, same context: 0 -> 3.27, 1 -> 3.14, 2 -> 3.13, 3 -> 3.13, 5 -> 3.16, 8 -> 3.24, 12 -> 3.57 ms per apply)
   bool df_soa = true;         // private sweep vectors of the dataflow sweeps in the [slice][k][lane] layout (FX_DF_SOA=0: 3 s + k)
   int df_grid_max[3] = {128, 128, 128};  // co-resident workgroups of k_tri_dataflow<2 / 4 / 8 waves> (occupancy query at fx_create)
   int df_grid_last = 0;       // workgroups of the last dataflow launch (after the co-residency clamp)

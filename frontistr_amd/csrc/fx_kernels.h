@@ -1076,7 +1076,7 @@ __global__ __launch_bounds__(64 * WPS) void k_tri_dataflow(int32_t nslices, cons
                                                            double *__restrict__ zf, double *__restrict__ zb,
                                                            double *__restrict__ z, double *__restrict__ partials,
                                                            const int32_t *__restrict__ gate, int32_t *__restrict__ err,
-                                                           int nsleep) {
+                                                           int nsleep, const int32_t *__restrict__ slice_level, int presleep) {
   if (gate && *gate != 0) return;
   if (nsleep < 0) {  // test hook (FX_DEBUG_DF_FAIL): behave like a launch whose bounded wait ran out at once -- nothing usable written, err raised
     if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1085,12 +1085,24 @@ __global__ __launch_bounds__(64 * WPS) void k_tri_dataflow(int32_t nslices, cons
   __shared__ double part[2][WPS][3][64];  // double-buffered: one workgroup barrier per slice
   int buf = 0;
   bool dead = false;  // per wave: its bounded wait ran out (or another wave's did); it then stops waiting, never stops running
-  for (int slice = blockIdx.x; slice < nslices; slice += gridDim.x, buf ^= 1)
+  // A workgroup that has just finished a slice of level l0 and goes on to one of level l1 is l1 - l0 - 1 levels ahead of the frontier:
+  // it sleeps `presleep` x 0.1 us per level of that lead before it starts to poll (FX_DF_PRESLEEP; its polls would only compete with
+  // the frontier's hand-offs).
+  auto lead_sleep = [&](int from, int to) {
+    if (!slice_level || presleep <= 0) return;
+    const int lead = abs(slice_level[to] - slice_level[from]) - 1;
+    for (int q = 0; q < lead * presleep; q++) __builtin_amdgcn_s_sleep(4);  // 256 clocks = 0.1 us each
+  };
+  for (int slice = blockIdx.x; slice < nslices; slice += gridDim.x, buf ^= 1) {
+    if (slice != (int)blockIdx.x) lead_sleep(slice - (int)gridDim.x, slice);
     df_slice<true, WPS, POLL, SOA>(slice, Lptr, Lval, Lcol, slot_node, alu, r, zf, zb, z, partials, err, part[buf], dead, nsleep);
+  }
   // backward: the SAME slices, last first (a row's forward value is then its own thread's earlier store)
   const int mine = nslices > (int)blockIdx.x ? (nslices - 1 - (int)blockIdx.x) / (int)gridDim.x : -1;
-  for (int slice = (int)blockIdx.x + mine * (int)gridDim.x; mine >= 0 && slice >= 0; slice -= gridDim.x, buf ^= 1)
+  for (int slice = (int)blockIdx.x + mine * (int)gridDim.x; mine >= 0 && slice >= 0; slice -= gridDim.x, buf ^= 1) {
+    if (slice + (int)gridDim.x < nslices) lead_sleep(slice + (int)gridDim.x, slice);
     df_slice<false, WPS, POLL, SOA>(slice, Uptr, Uval, Ucol, slot_node, alu, r, zf, zb, z, partials, err, part[buf], dead, nsleep);
+  }
 }
 
 // ------------------------------------------------------------------------
