@@ -934,14 +934,14 @@ __device__ __forceinline__ void df_gather(const double *__restrict__ zs, const i
   for (unsigned spins = 1;; spins++) {
     for (int q = 0; q < nsleep; q++) __builtin_amdgcn_s_sleep(1);  // 64 clocks each
     any = false;
-    // all re-reads of a pass in flight together -- an entry that is not re-read loads the row's own slot instead, so that there is no
+    // all re-reads of a pass in flight together -- an entry that is not re-read loads slot 0 instead (3.140 -> 3.115 ms against the row's own slot), so that there is no
     // branch (and no wait) between the loads: one round trip per pass, not one per missing entry
     double v[3 * NB];
 #pragma unroll
     for (int e = 0; e < 3 * NB; e++) {
       const bool need = col[e / 3] != self;
       const bool rd = POLL == 0 ? need : miss[e];
-      v[e] = df_load(zs + df_ix<SOA>(rd ? col[e / 3] : self) + (e % 3) * DF_ST(SOA));
+      v[e] = df_load(zs + df_ix<SOA>(rd ? col[e / 3] : 0) + (e % 3) * DF_ST(SOA));  // not re-read: slot 0, one address for all such lanes
     }
 #pragma unroll
     for (int e = 0; e < 3 * NB; e++) {
