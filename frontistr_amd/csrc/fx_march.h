@@ -1,7 +1,13 @@
 // Plane march of the level-scheduled triangular sweeps (ILU(0) hecmw_precond_BILU_33.f90:90-157, natural-order SSOR
 // hecmw_precond_SSOR_33.f90:300-410).  Included by fistr_hip.hip after fx_kernels.h and the host helpers.
 //
-// k_tri_dataflow hands every dependency level from workgroup to workgroup through memory: 2 x 1,044 hand-offs of ~2 us at 10.1 M DOF.
+// STATUS (round 4): correct -- bit-identical to the level sweeps on every mesh tried, 10.1 M DOF included -- and SLOWER than k_tri_dataflow
+// (6.3 against 3.1 ms per apply), hence opt-in (FX_MARCH=2).  DESIGN.md section 4 "Round 4: the plane march" has the measurements: a free
+// round costs 0.84 us for 16 rows, a round that waits for another chunk 2.4-3.6 us, and the plane-to-plane lag alone (149 x 5-10 us) is
+// what k_tri_dataflow needs for its 1,044 hand-offs.  Kept as an independent second implementation of the sweeps and as a measuring tool
+// (fx_debug_march_trace / _rounds).
+//
+// k_tri_dataflow hands every dependency level from workgroup to workgroup through memory: 2 x 1,044 hand-offs of 1.5-2 us at 10.1 M DOF.
 // Here a workgroup keeps a CHUNK -- a contiguous range of the natural numbering, on a structured mesh one plane of nodes (or a
 // fraction of it) -- for the whole sweep.  Inside a chunk the rows run in ROUNDS: the chunk's own dependency levels (counting only
 // the lower neighbours that lie in the chunk), a level of more than R rows split.  What a row needs from its own chunk was produced at
