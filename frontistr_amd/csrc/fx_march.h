@@ -752,3 +752,57 @@ static int march_apply(fx_context *c, const double *r, double *z, const int32_t 
   c->march_launches++;
   return 0;
 }
+
+// Host-only: plan the two march programs for a block profile (1-based items as hecMAT's, N internal rows) with `chunk` rows per chunk and
+// `waves` pair waves (1, 2, 3), replay them with march_check and report.  No device is touched: the CPU test suite runs the schedule builder
+// through this on structured and unstructured profiles.  out[0] 1 = both programs pass their replay, 0 = the structure is not admitted (a row
+// with more than 14 lower or upper blocks), [1] chunks, [2] / [3] rounds forward / backward, [4] / [5] near / far blocks of the forward
+// program, [6] rows of the largest round, [7] dependency levels of the whole matrix (what the level sweeps need).
+extern "C" int fx_march_plan(int32_t N, const int32_t *indexL, const int32_t *itemL, const int32_t *indexU, const int32_t *itemU,
+                             int32_t chunk, int32_t waves, double out[8]) {
+  if (!indexL || !itemL || !indexU || !itemU || !out || N < 1 || chunk < 1 || waves < 1 || waves > 3) {
+    g_fx_error = "fx_march_plan: bad argument";
+    return FX_ERROR_RUNTIME;
+  }
+  for (int k = 0; k < 8; k++) out[k] = 0.0;
+  const int32_t *iL = indexL, *jL = itemL, *iU = indexU, *jU = itemU;
+  int32_t maxl = 0, maxu = 0, nlev = 0;
+  {
+    std::vector<int32_t> level((size_t)N, 0);
+    for (int32_t i = 0; i < N; i++) {
+      maxl = std::max(maxl, iL[i + 1] - iL[i]);
+      int32_t k = 0, l = 0;
+      for (int32_t j = iU[i]; j < iU[i + 1]; j++) k += (jU[j] <= N);
+      maxu = std::max(maxu, k);
+      for (int32_t j = iL[i]; j < iL[i + 1]; j++) l = std::max(l, level[jL[j] - 1]);
+      level[i] = l + 1;
+      nlev = std::max(nlev, l + 1);
+    }
+  }
+  out[7] = nlev;
+  if (maxl > FX_MARCH_MAXBLOCKS || maxu > FX_MARCH_MAXBLOCKS) return 0;
+  auto entsL = [=](int32_t i, std::vector<int32_t> &o) { for (int32_t j = iL[i]; j < iL[i + 1]; j++) o.push_back(jL[j] - 1); };
+  auto entsU = [=](int32_t i, std::vector<int32_t> &o) { for (int32_t j = iU[i + 1] - 1; j >= iU[i]; j--) if (jU[j] <= N) o.push_back(jU[j] - 1); };
+  auto entsL2 = [=](int32_t i, std::vector<int32_t> &o, std::vector<int32_t> &sc) {
+    for (int32_t j = iL[i]; j < iL[i + 1]; j++) { o.push_back(jL[j] - 1); sc.push_back(3 * j + 1); }
+  };
+  auto entsU2 = [=](int32_t i, std::vector<int32_t> &o, std::vector<int32_t> &sc) {
+    for (int32_t j = iU[i + 1] - 1; j >= iU[i]; j--) if (jU[j] <= N) { o.push_back(jU[j] - 1); sc.push_back(3 * j + 2); }
+  };
+  const int32_t S = std::min(N, chunk), R = 8 * waves;
+  std::string why;
+  std::vector<int32_t> col, src;
+  int64_t nb = 0, fb = 0;
+  int32_t fs = 0;
+  MarchRounds mf, mb;
+  march_rounds(N, S, R, true, entsL, mf);
+  march_lanes(N, S, R, entsL2, mf, col, src, nb, fb, fs);
+  if (!march_check(N, S, R, true, entsL2, mf, col, why)) { g_fx_error = "fx_march_plan, forward program: " + why; return FX_ERROR_RUNTIME; }
+  out[4] = (double)nb; out[5] = (double)fb;
+  march_rounds(N, S, R, false, entsU, mb);
+  march_lanes(N, S, R, entsU2, mb, col, src, nb, fb, fs);
+  if (!march_check(N, S, R, false, entsU2, mb, col, why)) { g_fx_error = "fx_march_plan, backward program: " + why; return FX_ERROR_RUNTIME; }
+  out[0] = 1.0; out[1] = (N + S - 1) / S; out[2] = (double)mf.rstart.size() - 1; out[3] = (double)mb.rstart.size() - 1;
+  out[6] = std::max(mf.max_rows, mb.max_rows);
+  return 0;
+}

@@ -458,6 +458,18 @@ def hecmw_mat_con(hecMESH, hecMAT):
     return hecMAT
 
 
+def march_plan(hecMAT, chunk, waves):
+    """Host-only: the two plane-march programs of hecMAT's profile (fx_march_plan), replayed on the host."""
+    out = (C.c_double * 8)()
+    f = lib().fx_march_plan
+    f.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    iL, jL = np.ascontiguousarray(hecMAT.indexL, dtype=np.int32), np.ascontiguousarray(hecMAT.itemL, dtype=np.int32)
+    iU, jU = np.ascontiguousarray(hecMAT.indexU, dtype=np.int32), np.ascontiguousarray(hecMAT.itemU, dtype=np.int32)
+    _chk(f(int(hecMAT.N), _ptr(iL), _ptr(jL), _ptr(iU), _ptr(jU), int(chunk), int(waves), out))
+    keys = ("admitted", "chunks", "rounds_fwd", "rounds_bwd", "near_blocks", "far_blocks", "max_round_rows", "levels")
+    return {k: int(out[i]) for i, k in enumerate(keys)}
+
+
 def hecmw_solve(hecMESH, hecMAT, ctx=None, want_history=True):
     """subroutine hecmw_solve(hecMESH, hecMAT): solves hecMAT in place (X, Iarray flags).
     Returns the reference's status code (0, or a W-code such as 3001 / 2002)."""

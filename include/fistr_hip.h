@@ -161,6 +161,13 @@ int fx_placement_report(fx_context *ctx, double out[9]);
  * dependency levels, [11] seconds the build took, [12] applies that took the march, [13] workgroups of the last launch, [14] rows of the
  * largest round, [15] dependency levels.  FX_MARCH = 0 off, 1 (default) when the cost model prefers it, 2 whenever the structure admits it. */
 int fx_march_report(fx_context *ctx, double out[16]);
+/* Host-only (no device): plan the two march programs for a block profile (indexL / itemL / indexU / itemU as hecMAT's, 1-based items, N
+ * internal rows) with `chunk` rows per chunk and `waves` pair waves (1, 2, 3), replay them on the host and report: out[0] 1 = both programs
+ * pass their replay (every in-chunk dependency found in its ring slot, every other one produced by an earlier chunk or round), 0 = the
+ * structure is not admitted (a row with more than 14 lower or upper blocks), [1] chunks, [2] / [3] rounds forward / backward, [4] / [5]
+ * blocks gathered from the ring / from memory (forward), [6] rows of the largest round, [7] dependency levels of the matrix. */
+int fx_march_plan(int32_t N, const int32_t *indexL, const int32_t *itemL, const int32_t *indexU, const int32_t *itemU, int32_t chunk,
+                  int32_t waves, double out[8]);
 /* The passes of the auto-SIGMA_DIAG / METHOD2 loop of the last solve on this context (hecmw_solver_Iterative.f90:117-157: banner
  * :125 before every pass, 'Increasing SIGMA_DIAG to' :149 before a retry): METHOD, the SIGMA_DIAG in effect and the number of
  * residual-history lines of every pass, and the lines themselves.  fx_solve's own `hist` holds the LAST pass. */

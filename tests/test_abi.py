@@ -131,3 +131,39 @@ def test_ssor_ordering_is_the_references(oracle):
         perm, cidx = _lib_ordering(A, nc)
         assert np.array_equal(cidx, P.colorindex), (A.N, nc)
         assert np.array_equal(perm, P.perm), (A.N, nc)
+
+
+def test_march_programs_replay_on_the_host():
+    """The schedule builder of the plane march (csrc/fx_march.h, host-only entry fx_march_plan): for structured and unstructured profiles and
+    chunkings aligned with the mesh planes or not, both programs pass the replay -- every in-chunk dependency is found in the LDS-ring slot
+    its column code names, every other one is produced by an earlier chunk or round, the chained row counts reproduce the round table --
+    and the numbers add up: chunks, one round at least per dependency level of a chunk, every block either near or far.  A mesh whose
+    rows have more than 14 lower blocks (the mesher-made hex mesh of tutorial 05) is not admitted."""
+    from frontistr_amd import hecmw
+    from frontistr_amd.mesh import CubeMesh
+    for n, chunks in ((5, (36, 18, 25, 216, 7)), (11, (144, 48, 100, 1728)), (20, (441, 147, 1000))):
+        m = CubeMesh(n)
+        mesh = hecmw.hecmwST_local_mesh(n_node=m.n_node)
+        mesh.elem_node_item = m.conn.ravel()
+        mat = hecmw.hecmw_mat_con(mesh, hecmw.hecmwST_matrix())
+        nlower = int(mat.indexL[mat.N])
+        for S in chunks:
+            for waves in (1, 2, 3):
+                p = hecmw.march_plan(mat, S, waves)
+                assert p["admitted"] == 1, (n, S, waves)
+                assert p["chunks"] == -(-mat.N // S) and p["max_round_rows"] <= 8 * waves
+                assert p["near_blocks"] + p["far_blocks"] == nlower
+                assert p["rounds_fwd"] >= p["chunks"] and p["rounds_bwd"] >= p["chunks"]
+                if S >= mat.N:                       # one chunk: its levels are the matrix's, every round a level or a part of one
+                    assert p["rounds_fwd"] >= p["levels"] == 7 * n + 1
+        # whole planes per chunk: every lower neighbour of the same plane is at most 3 levels back -> in the ring; the 9 of the plane below are not
+        p = hecmw.march_plan(mat, (n + 1) ** 2, 3)
+        assert p["far_blocks"] > p["near_blocks"] > 0
+    g = np.load(os.path.join(ROOT, "tests", "golden", "nl_necking.npz"))
+    mesh = hecmw.hecmwST_local_mesh(n_node=g["coord"].shape[0])
+    mesh.elem_node_item = g["conn"].ravel()
+    mat = hecmw.hecmw_mat_con(mesh, hecmw.hecmwST_matrix())
+    p = hecmw.march_plan(mat, 500, 2)
+    assert p["levels"] > 0
+    if p["admitted"]:
+        assert p["near_blocks"] + p["far_blocks"] == int(mat.indexL[mat.N])
