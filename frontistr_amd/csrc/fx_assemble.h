@@ -355,6 +355,7 @@ __global__ __launch_bounds__(FXA_BS(ELEMOPT)) void k_assemble_c3d8(int32_t n_ele
       dst = block_ptr(a, b, inod, jnod);
       if (st > 0) dstT = block_ptr(b, a, jnod, inod);
       if (!dst || (st > 0 && !dstT)) { if (err) atomicExch(err, 2); continue; }
+#ifndef FXA_EXP_NOSCATTER
       if (elem_list) {
 #pragma unroll
         for (int e = 0; e < 9; e++) old[e] = dst[e];
@@ -363,8 +364,12 @@ __global__ __launch_bounds__(FXA_BS(ELEMOPT)) void k_assemble_c3d8(int32_t n_ele
           for (int e = 0; e < 9; e++) oldT[e] = dstT[e];
         }
       }
+#endif
     }
     double K[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#ifdef FXA_EXP_NOCOMPUTE  // timing experiment: the scatter alone
+    K[0] = 1e-3 * (double)(a + b);
+#else
 #pragma unroll 1
     for (int LX = 0; LX < 8; LX++) {
       double Ba[6][3], Bb[6][3];
@@ -372,6 +377,7 @@ __global__ __launch_bounds__(FXA_BS(ELEMOPT)) void k_assemble_c3d8(int32_t n_ele
       node_B_at(b, LX, Bb);
       btdb_accumulate(Ba, Bb, D11, D12, D44, Jsh[el][LX][9], K);
     }
+#endif
     if (IC) {  // condense (3dIC.f90:206-209)
 #pragma unroll
       for (int i = 0; i < 3; i++)
@@ -393,6 +399,10 @@ __global__ __launch_bounds__(FXA_BS(ELEMOPT)) void k_assemble_c3d8(int32_t n_ele
         }
       continue;
     }
+#ifdef FXA_EXP_NOSCATTER  // timing experiment: the arithmetic alone (one word written so that nothing is optimised away)
+    if (K[0] + K[4] + K[8] == 1.2345e300) dst[0] = K[0];
+    continue;
+#endif
     if (elem_list) {
 #pragma unroll
       for (int e = 0; e < 9; e++) dst[e] = old[e] + K[e];

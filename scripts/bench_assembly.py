@@ -6,6 +6,8 @@ import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from frontistr_amd import hecmw as hip          # noqa: E402
+if os.environ.get("FX_LIBPATH"):
+    hip.LIBPATH = os.environ["FX_LIBPATH"]      # timing experiments: a library built with -DFXA_EXP_*
 from frontistr_amd.mesh import CubeMesh          # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 149
