@@ -110,6 +110,42 @@ __global__ void k_scatter_map(int32_t n_elem, const int32_t *__restrict__ conn, 
   pos[t] = k;
 }
 
+// First-write flags for the coloured scatter (round 4).  A block of the matrix receives one contribution from every element that holds
+// both of its nodes, in the order of the colour launches; the FIRST of them can be stored instead of added -- no read of the old value,
+// and no clearing of the matrix before the assembly.  Pass 1: per block the lowest colour among its contributions (atomicMin); pass 2: bit
+// 30 of the contribution's map entry (the diagonal's otherwise unused entry too) says "this one is the first".
+#define FXA_FIRST_BIT 0x40000000
+#define FXA_NO_COLOR 0x7F7F7F7F  // what hipMemset(0x7F) leaves: above every colour
+__global__ void k_scatter_first_min(int32_t n_elem, const int32_t *__restrict__ conn, const int32_t *__restrict__ pos,
+                                    const int32_t *__restrict__ elem_color, int32_t *__restrict__ minD, int32_t *__restrict__ minL,
+                                    int32_t *__restrict__ minU) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)64 * n_elem) return;
+  const int32_t elem = (int32_t)(t >> 6), a = (int)(t >> 3) & 7, b = (int)t & 7;
+  const int32_t inod = conn[(size_t)8 * elem + a], jnod = conn[(size_t)8 * elem + b], k = pos[t], col = elem_color[elem];
+  if (k < 0) return;
+  if (inod == jnod) atomicMin(minD + (inod - 1), col);
+  else if (jnod < inod) atomicMin(minL + k, col);
+  else atomicMin(minU + k, col);
+}
+__global__ void k_scatter_first_flag(int32_t n_elem, const int32_t *__restrict__ conn, int32_t *__restrict__ pos,
+                                     const int32_t *__restrict__ elem_color, const int32_t *__restrict__ minD,
+                                     const int32_t *__restrict__ minL, const int32_t *__restrict__ minU) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)64 * n_elem) return;
+  const int32_t elem = (int32_t)(t >> 6), a = (int)(t >> 3) & 7, b = (int)t & 7;
+  const int32_t inod = conn[(size_t)8 * elem + a], jnod = conn[(size_t)8 * elem + b], k = pos[t], col = elem_color[elem];
+  if (k < 0) return;
+  const int32_t m = inod == jnod ? minD[inod - 1] : (jnod < inod ? minL[k] : minU[k]);
+  if (m == col) pos[t] = k | FXA_FIRST_BIT;
+}
+// blocks that no element contributes to (a profile wider than the mesh's): they would keep stale values without the clearing
+__global__ void k_count_uncovered(int64_t n, const int32_t *__restrict__ m, unsigned long long *__restrict__ count) {
+  unsigned long long c = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) c += (m[i] == FXA_NO_COLOR);
+  if (c) atomicAdd(count, c);
+}
+
 // Global derivatives of node b's shape function at a Gauss point from the stored inverse Jacobian: the expression of
 // hex8_global_deriv for one node (hex8n.f90:24-53, element.f90:693-744).
 __device__ __forceinline__ void hex8_node_deriv(int b, double xi, double et, double ze, const double *inv, double *g) {
@@ -333,13 +369,15 @@ __global__ __launch_bounds__(FXA_BS(ELEMOPT)) void k_assemble_c3d8(int32_t n_ele
   // instead of 8; the transposed copies differ from separately accumulated ones in the last bit at most (sums of the same products in the
   // same order, transposed), far inside the 1e-12 of the parity tests.  No other element of the launch touches these rows (colouring).
   const int32_t inod = conn[(size_t)8 * elem + a];
-  auto block_ptr = [&](int ra, int rb, int32_t rnod, int32_t cnod) -> double * {  // hecmw_mat_add_node, hecmw_mat_ass.f90:72-134
+  auto block_ptr = [&](int ra, int rb, int32_t rnod, int32_t cnod, bool &first) -> double * {  // hecmw_mat_add_node, hecmw_mat_ass.f90:72-134
+    const int32_t raw = pos_map ? pos_map[(size_t)64 * elem + 8 * ra + rb] : 0;
+    first = pos_map && raw >= 0 && (raw & FXA_FIRST_BIT);  // k_scatter_first_flag: no earlier colour launch touches this block
     if (rnod == cnod) return D + (size_t)9 * (rnod - 1);
     if (cnod < rnod) {
-      const int32_t k = pos_map ? pos_map[(size_t)64 * elem + 8 * ra + rb] : item_search(itemL, indexL[rnod - 1], indexL[rnod], cnod);
+      const int32_t k = pos_map ? (raw < 0 ? raw : (raw & ~FXA_FIRST_BIT)) : item_search(itemL, indexL[rnod - 1], indexL[rnod], cnod);
       return k < 0 ? nullptr : AL + (size_t)9 * k;
     }
-    const int32_t k = pos_map ? pos_map[(size_t)64 * elem + 8 * ra + rb] : item_search(itemU, indexU[rnod - 1], indexU[rnod], cnod);
+    const int32_t k = pos_map ? (raw < 0 ? raw : (raw & ~FXA_FIRST_BIT)) : item_search(itemU, indexU[rnod - 1], indexU[rnod], cnod);
     return k < 0 ? nullptr : AU + (size_t)9 * k;
   };
 #pragma unroll 1
@@ -352,13 +390,16 @@ __global__ __launch_bounds__(FXA_BS(ELEMOPT)) void k_assemble_c3d8(int32_t n_ele
     double old[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, oldT[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if (!Kout) {
       const int32_t jnod = conn[(size_t)8 * elem + b];
-      dst = block_ptr(a, b, inod, jnod);
-      if (st > 0) dstT = block_ptr(b, a, jnod, inod);
+      bool first = false, firstT = false;
+      dst = block_ptr(a, b, inod, jnod, first);
+      if (st > 0) dstT = block_ptr(b, a, jnod, inod, firstT);
       if (!dst || (st > 0 && !dstT)) { if (err) atomicExch(err, 2); continue; }
 #ifndef FXA_EXP_NOSCATTER
-      if (elem_list) {
+      if (elem_list && !first) {  // the first contribution to a block is stored, not added: nothing to read
 #pragma unroll
         for (int e = 0; e < 9; e++) old[e] = dst[e];
+      }
+      if (elem_list && !firstT) {
         if (st > 0) {
 #pragma unroll
           for (int e = 0; e < 9; e++) oldT[e] = dstT[e];

@@ -169,7 +169,7 @@ static void elem_colors_free(ElemColors &ec) {
   ec = ElemColors();
 }
 // the position map of k_scatter_map for the resident profile and the device connectivity d_conn (FX_ASM_MAP=0: search every time)
-static int ensure_scatter_map(fx_context *c, ElemColors &ec, int32_t n_elem, const int32_t *d_conn) {
+static int ensure_scatter_map(fx_context *c, ElemColors &ec, int32_t n_elem, const int32_t *d_conn, bool with_first = false) {
   static const bool off = getenv("FX_ASM_MAP") && atoi(getenv("FX_ASM_MAP")) == 0;
   if (off || ec.pos || ec.offsets.empty()) return 0;
   if (dev_alloc(&ec.pos, (size_t)64 * n_elem)) { (void)hipGetLastError(); ec.pos = nullptr; return 0; }  // no memory: keep searching
@@ -177,6 +177,41 @@ static int ensure_scatter_map(fx_context *c, ElemColors &ec, int32_t n_elem, con
   hipLaunchKernelGGL(k_scatter_map, dim3((unsigned)(((int64_t)64 * n_elem + 255) / 256)), dim3(256), 0, c->stream, n_elem, d_conn,
                      A.indexL, A.itemL, A.indexU, A.itemU, ec.pos);
   HIP_TRY(hipGetLastError());
+  // first-write flags (FX_ASM_FIRST=0: off): which contribution to a block comes first in the order of the colour launches
+  static const bool no_first = getenv("FX_ASM_FIRST") && atoi(getenv("FX_ASM_FIRST")) == 0;
+  ec.first_write = false;
+  if (!with_first || no_first || ec.dup_nodes) return 0;  // (the nonlinear kernels keep their own map, without flags: fx_nonlinear_host.h)
+  {
+    DevScratch tmp;
+    int32_t *ecol = nullptr, *minD = nullptr, *minL = nullptr, *minU = nullptr;
+    unsigned long long *cnt = nullptr;
+    if (tmp.alloc(&ecol, (size_t)n_elem) || tmp.alloc(&minD, (size_t)A.NP) || tmp.alloc(&minL, (size_t)std::max(A.NPL, 1)) ||
+        tmp.alloc(&minU, (size_t)std::max(A.NPU, 1)) || tmp.alloc(&cnt, 1)) {
+      (void)hipGetLastError();
+      return 0;  // no memory for the temporaries: the scatter stays read-modify-write everywhere
+    }
+    std::vector<int32_t> order((size_t)n_elem), color((size_t)n_elem, 0);
+    HIP_TRY(hipMemcpy(order.data(), ec.order, (size_t)n_elem * 4, hipMemcpyDeviceToHost));
+    for (size_t k = 0; k + 1 < ec.offsets.size(); k++)
+      for (int32_t e = ec.offsets[k]; e < ec.offsets[k + 1]; e++) color[order[e]] = (int32_t)k;
+    HIP_TRY(hipMemcpyAsync(ecol, color.data(), (size_t)n_elem * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(minD, 0x7F, (size_t)A.NP * 4, c->stream));  // FXA_NO_COLOR = 0x7F7F7F7F: above every colour
+    HIP_TRY(hipMemsetAsync(minL, 0x7F, (size_t)std::max(A.NPL, 1) * 4, c->stream));
+    HIP_TRY(hipMemsetAsync(minU, 0x7F, (size_t)std::max(A.NPU, 1) * 4, c->stream));
+    HIP_TRY(hipMemsetAsync(cnt, 0, 8, c->stream));
+    const dim3 g((unsigned)(((int64_t)64 * n_elem + 255) / 256)), b(256);
+    hipLaunchKernelGGL(k_scatter_first_min, g, b, 0, c->stream, n_elem, d_conn, (const int32_t *)ec.pos, (const int32_t *)ecol, minD, minL, minU);
+    hipLaunchKernelGGL(k_scatter_first_flag, g, b, 0, c->stream, n_elem, d_conn, ec.pos, (const int32_t *)ecol, (const int32_t *)minD,
+                       (const int32_t *)minL, (const int32_t *)minU);
+    hipLaunchKernelGGL(k_count_uncovered, dim3(1024), b, 0, c->stream, (int64_t)A.NP, (const int32_t *)minD, cnt);
+    if (A.NPL > 0) hipLaunchKernelGGL(k_count_uncovered, dim3(1024), b, 0, c->stream, (int64_t)A.NPL, (const int32_t *)minL, cnt);
+    if (A.NPU > 0) hipLaunchKernelGGL(k_count_uncovered, dim3(1024), b, 0, c->stream, (int64_t)A.NPU, (const int32_t *)minU, cnt);
+    unsigned long long uncovered = 1;
+    HIP_TRY(hipMemcpyAsync(&uncovered, cnt, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // also: `color` is a host temporary
+    HIP_TRY(hipGetLastError());
+    ec.first_write = (uncovered == 0);  // a block nobody writes would keep what it held: then the matrix is cleared as before (the flags are harmless)
+  }
   return 0;
 }
 static int ensure_elem_colors(fx_context *c, ElemColors &ec, int32_t n_elem, const int32_t *conn, int32_t NP) {
@@ -186,7 +221,7 @@ static int ensure_elem_colors(fx_context *c, ElemColors &ec, int32_t n_elem, con
   const int64_t nw = (int64_t)8 * n_elem;
   const int nchunk = 64;
   uint64_t part[nchunk];
-  bool bad[nchunk];
+  bool bad[nchunk], dup[nchunk];
   parallel_for(nchunk, [&](int64_t a, int64_t b) {
     for (int64_t q = a; q < b; q++) {
       uint64_t h = 1469598103934665603ull;
@@ -195,7 +230,11 @@ static int ensure_elem_colors(fx_context *c, ElemColors &ec, int32_t n_elem, con
         h = (h ^ (uint32_t)conn[i]) * 1099511628211ull;
         oob |= (conn[i] < 1 || conn[i] > NP);
       }
-      part[q] = h; bad[q] = oob;
+      bool dp = false;  // an element that names a node twice (a collapsed hexahedron): two of its 64 blocks coincide
+      for (int64_t e = (int64_t)n_elem * q / nchunk; e < (int64_t)n_elem * (q + 1) / nchunk; e++)
+        for (int x = 0; x < 8; x++)
+          for (int y = x + 1; y < 8; y++) dp |= (conn[8 * e + x] == conn[8 * e + y]);
+      part[q] = h; bad[q] = oob; dup[q] = dp;
     }
   });
   uint64_t key = 1469598103934665603ull;
@@ -211,6 +250,8 @@ static int ensure_elem_colors(fx_context *c, ElemColors &ec, int32_t n_elem, con
   HIP_TRY(hipMemcpyAsync(ec.order, order.data(), (size_t)n_elem * 4, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   ec.n_elem = n_elem; ec.key = key; ec.offsets = off;
+  ec.dup_nodes = false;
+  for (int q = 0; q < nchunk; q++) ec.dup_nodes |= dup[q];
   return 0;
 }
 
@@ -252,7 +293,7 @@ static int assemble_c3d8_common(fx_context *c, const fx_mesh_view *mesh, double 
   HIP_TRY(hipMemcpyAsync(d_conn, mesh->conn, (size_t)8 * mesh->n_elem * 4, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemsetAsync(d_err, 0, 4, c->stream));
   if (ensure_elem_colors(c, c->asm_colors, mesh->n_elem, mesh->conn, mesh->n_node) ||
-      ensure_scatter_map(c, c->asm_colors, mesh->n_elem, d_conn))
+      ensure_scatter_map(c, c->asm_colors, mesh->n_elem, d_conn, true))
     return FX_ERROR_RUNTIME;  // both cached per (profile, mesh)
   double D11 = 0.0, D12 = 0.0, D44 = 0.0;
   int32_t *d_emat = nullptr;
@@ -271,9 +312,11 @@ static int assemble_c3d8_common(fx_context *c, const fx_mesh_view *mesh, double 
   }
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
   // hecmw_mat_clear (fstr_StiffMatrix.f90:40)
-  HIP_TRY(hipMemsetAsync(A.D, 0, (size_t)9 * A.NP * 8, c->stream));
-  HIP_TRY(hipMemsetAsync(A.AL, 0, (size_t)9 * A.NPL * 8, c->stream));
-  HIP_TRY(hipMemsetAsync(A.AU, 0, (size_t)9 * A.NPU * 8, c->stream));
+  if (!(c->asm_colors.first_write && c->asm_colors.pos && !c->asm_colors.offsets.empty())) {  // first-write scatter: every block is stored before it is added to
+    HIP_TRY(hipMemsetAsync(A.D, 0, (size_t)9 * A.NP * 8, c->stream));
+    HIP_TRY(hipMemsetAsync(A.AL, 0, (size_t)9 * A.NPL * 8, c->stream));
+    HIP_TRY(hipMemsetAsync(A.AU, 0, (size_t)9 * A.NPU * 8, c->stream));
+  }
   if (elemopt == 1) launch_assemble<1>(c, mesh->n_elem, d_coord, d_conn, D11, D12, D44, nullptr, d_err, d_emat, d_mtab, &c->asm_colors);
   else if (elemopt == 2) launch_assemble<2>(c, mesh->n_elem, d_coord, d_conn, D11, D12, D44, nullptr, d_err, d_emat, d_mtab, &c->asm_colors);
   else launch_assemble<3>(c, mesh->n_elem, d_coord, d_conn, D11, D12, D44, nullptr, d_err, d_emat, d_mtab, &c->asm_colors);

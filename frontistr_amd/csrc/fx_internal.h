@@ -175,6 +175,9 @@ struct ElemColors {
   int32_t *order = nullptr;         // device: element ids, colour by colour
   std::vector<int32_t> offsets;     // host: first position of each colour (+ end); empty = not coloured (atomics)
   int32_t *pos = nullptr;           // device: 64 per element, position of block (a, b) in AL / AU (k_scatter_map), or null
+  bool dup_nodes = false;           // an element names a node twice: two of its blocks coincide, no first-write flags
+  bool first_write = false;         // pos carries the first-write flags (k_scatter_first_flag) and every block of the profile is covered:
+                                    // the coloured scatter stores the first contribution to a block and the matrix is not cleared first
 };
 
 struct NlDev {
