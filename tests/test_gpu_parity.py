@@ -1201,3 +1201,47 @@ def test_march_in_the_krylov_loops(hip, oracle, meth, pc):
     assert out["fail"][5]["df_fallbacks"] == 1 and out["fail"][5]["df_mode"] == 0
     k = min(len(out["march"][3]), len(out["dataflow"][3]), 10)
     assert np.all(np.abs(out["march"][3][:k] - out["dataflow"][3][:k]) <= 1e-11 * out["dataflow"][3][:k])
+
+
+def test_first_write_scatter_clears_what_no_element_covers(hip):
+    """The coloured scatter stores the first contribution to a block instead of adding it and then skips the clearing of the matrix
+    (fx_assemble.h: k_scatter_first_flag) -- but only if every block of the profile receives a contribution.  A profile wider than
+    the mesh (here: the profile of the whole cube, assembled from all elements first and then from a subset of them on the SAME
+    context) must not keep the stale blocks of the first assembly: blocks no element of the subset covers are exactly zero, the covered
+    ones equal what a fresh context computes for the subset."""
+    from frontistr_amd.mesh import CubeMesh
+    mesh = CubeMesh(5, skew=0.03)
+    hm = hip.hecmwST_local_mesh(n_node=mesh.n_node)
+    hm.elem_node_item = mesh.conn.ravel()
+    m = hip.hecmw_mat_con(hm, hip.hecmwST_matrix())
+    sub = mesh.conn[:-37]                                   # the last elements missing: their private blocks are in the profile, uncovered
+    out = {}
+    for tag in ("reused", "fresh"):
+        ctx = hip.SolverContext()
+        ctx.upload(m, what=hip.FX_UP_PROFILE)
+        if tag == "reused":
+            ctx.assemble_c3d8(mesh.coord, mesh.conn, 210000.0, 0.3, elemopt=1, load=mesh.load(), bc=None)
+        ctx.assemble_c3d8(mesh.coord, sub, 210000.0, 0.3, elemopt=1, load=mesh.load(), bc=None)
+        ctx.download_matrix(m)
+        out[tag] = (m.D.copy(), m.AL.copy(), m.AU.copy())
+        ctx.close()
+    for a, b in zip(out["reused"], out["fresh"]):
+        assert np.array_equal(a, b)
+    # which off-diagonal blocks does the subset cover?
+    pairs = set()
+    for e in sub:
+        for x in e:
+            for y in e:
+                pairs.add((int(x), int(y)))
+    D, AL, AU = out["reused"]
+    unc = 0
+    for i in range(1, m.N + 1):
+        for k in range(m.indexL[i - 1], m.indexL[i]):
+            if (i, int(m.itemL[k])) not in pairs:
+                unc += 1
+                assert not AL[9 * k:9 * k + 9].any()
+        for k in range(m.indexU[i - 1], m.indexU[i]):
+            if (i, int(m.itemU[k])) not in pairs:
+                unc += 1
+                assert not AU[9 * k:9 * k + 9].any()
+    assert unc > 0 and np.abs(AL).max() > 0
